@@ -1,0 +1,110 @@
+"""ctypes binding of liblabrador_hip.so (the C ABI in include/labrador_hip.h).
+
+The product has no CPU fallback: if the shared object is missing this module
+raises ImportError naming the build command, and if no GPU is usable
+lab_ctx_create returns LAB_ERR_NO_DEVICE which `check()` raises as
+`NoDeviceError`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "liblabrador_hip.so")
+
+LAB_OK = 0
+LAB_ERR_ARG = -1
+LAB_ERR_LEN_MISMATCH = -2
+LAB_ERR_RANGE = -3
+LAB_ERR_HIP = -4
+LAB_ERR_NO_DEVICE = -5
+LAB_ERR_JL_REJECTED = -6
+LAB_ERR_BPP_CHECK = -7
+LAB_ERR_DECOMPOSE = -8
+
+_STATUS_NAMES = {
+    -1: "LAB_ERR_ARG", -2: "LAB_ERR_LEN_MISMATCH", -3: "LAB_ERR_RANGE", -4: "LAB_ERR_HIP",
+    -5: "LAB_ERR_NO_DEVICE", -6: "LAB_ERR_JL_REJECTED", -7: "LAB_ERR_BPP_CHECK", -8: "LAB_ERR_DECOMPOSE",
+}
+
+
+class LabradorError(RuntimeError):
+    def __init__(self, code, msg=""):
+        self.code = code
+        super().__init__("%s (%d): %s" % (_STATUS_NAMES.get(code, "LAB_ERR"), code, msg))
+
+
+class NoDeviceError(LabradorError):
+    pass
+
+
+class LengthMismatch(LabradorError, AssertionError):
+    """The reference's `assert!(v1.len() == v2.len(), ...)` panic (src/util.rs:497-502)."""
+
+
+class lab_info(C.Structure):
+    _fields_ = [("q", C.c_uint64), ("nlimbs", C.c_int), ("primes", C.c_uint32 * 4), ("max_len", C.c_uint64),
+                ("device", C.c_int)]
+
+
+# name -> (restype, argtypes); also the list the "exports every symbol" test walks
+SIGNATURES = {
+    "lab_ctx_create": (C.c_int, [C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "lab_ctx_destroy": (None, [C.c_void_p]),
+    "lab_ctx_info": (C.c_int, [C.c_void_p, C.POINTER(lab_info)]),
+    "lab_last_error": (C.c_char_p, [C.c_void_p]),
+    "lab_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lab_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "lab_negacyclic_polymul_u64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "lab_ntt_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "lab_ntt_inverse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "lab_vec_create": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "lab_vec_destroy": (None, [C.c_void_p]),
+    "lab_vec_count": (C.c_size_t, [C.c_void_p]),
+    "lab_vec_load_u64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "lab_vec_store_u64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "lab_vec_fill_synthetic": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint64,
+                                         C.c_uint64]),
+    "lab_inner_product": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                    C.c_size_t, C.c_size_t]),
+    "lab_matvec_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
+                                 C.c_size_t, C.c_void_p, C.c_size_t]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared object and binds every entry point declared in the header."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            "labrador_snark_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C labrador_snark_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback." % SO_PATH)
+    # torch bundles its own libamdhip64.so (SONAME libamdhip64.so.7).  Import it FIRST so the dynamic loader
+    # satisfies our NEEDED libamdhip64.so.7 with that already-loaded runtime: one HIP runtime per process, and
+    # torch tensors' device pointers / streams are valid inside the library.  (Loaded the other way round the
+    # process ends up with two runtimes and torch reports "No HIP GPUs are available".)
+    import torch  # noqa: F401
+    lib = C.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here means the .so is stale: rebuild
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(ctx_handle, rc):
+    if rc == LAB_OK:
+        return
+    msg = ""
+    if ctx_handle:
+        m = load().lab_last_error(ctx_handle)
+        msg = m.decode() if m else ""
+    if rc == LAB_ERR_NO_DEVICE:
+        raise NoDeviceError(rc, "no usable GPU; the product path has no CPU fallback")
+    if rc == LAB_ERR_LEN_MISMATCH:
+        raise LengthMismatch(rc, msg or "inner product not defined on vectors of unequal length")
+    raise LabradorError(rc, msg)

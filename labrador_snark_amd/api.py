@@ -1,0 +1,186 @@
+"""Host-side mirror of the reference's ring/vector interface over the C ABI.
+
+Names follow the Rust reference so parity tests read like its own tests:
+`Context` stands for the (Q, PLAN) globals (src/constants.rs:193-198),
+`negacyclic_polymul` for `PLAN.negacyclic_polymul` (src/algebraic.rs:396),
+`polynomial_vec_inner_product` for src/util.rs:496-509, and so on.
+
+Arrays at this level are numpy uint64 (host) or torch tensors on the GPU
+(uint64/int64 storage): both are passed to the library as raw pointers.
+PyTorch is only the device-memory / stream plumbing.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+D = 64
+
+
+def _ptr(a):
+    """Raw pointer + keep-alive for a numpy array or a torch tensor."""
+    if isinstance(a, np.ndarray):
+        if not a.flags["C_CONTIGUOUS"]:
+            raise ValueError("array must be C-contiguous")
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):
+        if not a.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return a.data_ptr()
+    raise TypeError("expected numpy array or torch tensor, got %r" % type(a))
+
+
+def _as_u64(a):
+    if isinstance(a, np.ndarray):
+        return np.ascontiguousarray(a, dtype=np.uint64)
+    if hasattr(a, "data_ptr"):
+        if a.element_size() != 8:
+            raise TypeError("device coefficient tensors must have 8-byte elements")
+        return a.contiguous()
+    return np.ascontiguousarray(np.asarray(a, dtype=np.uint64))
+
+
+def _nelems(a):
+    n = a.size if isinstance(a, np.ndarray) else a.numel()
+    if n % D:
+        raise ValueError("coefficient array size must be a multiple of 64")
+    return n // D
+
+
+class Context:
+    """One modulus q on one GPU.  `max_len` bounds inner-product lengths (it fixes the RNS limb count)."""
+
+    def __init__(self, q, device=0, max_len=0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        rc = self._lib.lab_ctx_create(int(q), int(device), int(max_len), C.byref(h))
+        _lib.check(None, rc)
+        self._h = h
+        info = _lib.lab_info()
+        _lib.check(self._h, self._lib.lab_ctx_info(self._h, C.byref(info)))
+        self.q = int(info.q)
+        self.nlimbs = int(info.nlimbs)
+        self.primes = [int(info.primes[i]) for i in range(self.nlimbs)]
+        self.max_len = int(info.max_len)
+        self.device = int(info.device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lab_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        _lib.check(self._h, rc)
+
+    def synchronize(self):
+        self._check(self._lib.lab_ctx_synchronize(self._h))
+
+    def use_torch_stream(self):
+        """Run on torch's current HIP stream (so torch.cuda.Event timing and tensor lifetimes line up)."""
+        import torch
+        self._check(self._lib.lab_ctx_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    # ---- PLAN.negacyclic_polymul + transform_slice_u64_to_zq (src/algebraic.rs:396-397), batched
+    def negacyclic_polymul(self, lhs, rhs, out=None):
+        lhs, rhs = _as_u64(lhs), _as_u64(rhs)
+        n = _nelems(lhs)
+        if _nelems(rhs) != n:
+            raise _lib.LengthMismatch(_lib.LAB_ERR_LEN_MISMATCH, "operands of unequal length")
+        if out is None:
+            if isinstance(lhs, np.ndarray):
+                out = np.empty(lhs.shape, dtype=np.uint64)
+            else:
+                import torch
+                out = torch.empty_like(lhs)
+        self._check(self._lib.lab_negacyclic_polymul_u64(self._h, _ptr(out), _ptr(lhs), _ptr(rhs), n))
+        return out
+
+    # ---- raw batched transforms on device residues u32 [nlimbs][batch][64]
+    def ntt_forward(self, residues, batch):
+        self._check(self._lib.lab_ntt_forward(self._h, _ptr(residues), batch))
+
+    def ntt_inverse(self, residues, batch):
+        self._check(self._lib.lab_ntt_inverse(self._h, _ptr(residues), batch))
+
+    # ---- hat vectors
+    def vec(self, count):
+        return HatVec(self, count)
+
+    def vec_from(self, coeffs):
+        coeffs = _as_u64(coeffs)
+        v = HatVec(self, _nelems(coeffs))
+        v.load(coeffs)
+        return v
+
+
+class HatVec:
+    """Device-resident ring elements in the transform domain (lab_vec)."""
+
+    def __init__(self, ctx, count):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._check(ctx._lib.lab_vec_create(ctx._h, int(count), C.byref(h)))
+        self._h = h
+        self.count = int(count)
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            self.ctx._lib.lab_vec_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.count
+
+    def load(self, coeffs, offset=0):
+        coeffs = _as_u64(coeffs)
+        self.ctx._check(self.ctx._lib.lab_vec_load_u64(self.ctx._h, self._h, offset, _ptr(coeffs), _nelems(coeffs)))
+        return self
+
+    def store(self, offset=0, count=None, out=None):
+        count = self.count - offset if count is None else count
+        if out is None:
+            out = np.empty((count, D), dtype=np.uint64)
+        self.ctx._check(self.ctx._lib.lab_vec_store_u64(self.ctx._h, self._h, offset, count, _ptr(out)))
+        return out
+
+    def fill_synthetic(self, seed, first_elem=0, bound=None, offset=0, count=None):
+        count = self.count - offset if count is None else count
+        bound = self.ctx.q if bound is None else bound
+        self.ctx._check(self.ctx._lib.lab_vec_fill_synthetic(self.ctx._h, self._h, offset, count, seed, first_elem,
+                                                            bound))
+        return self
+
+
+def polynomial_vec_inner_product(ctx, v1, v2, off1=0, off2=0, length=None, out=None, out_off=0):
+    """src/util.rs:496-509.  Raises LengthMismatch (an AssertionError) like the reference's assert!."""
+    if length is None:
+        if v1.count - off1 != v2.count - off2:
+            raise _lib.LengthMismatch(_lib.LAB_ERR_LEN_MISMATCH,
+                                      "inner product not defined on vectors of unequal length. v1 length: %d, v2 length: %d"
+                                      % (v1.count - off1, v2.count - off2))
+        length = v1.count - off1
+    if out is None:
+        out = HatVec(ctx, 1)
+    ctx._check(ctx._lib.lab_inner_product(ctx._h, out._h, out_off, v1._h, off1, v2._h, off2, length))
+    return out
+
+
+def matvec_sum(ctx, M, V, nmat, rows, cols, m_off=0, v_off=0, out=None, out_off=0):
+    """out[rho] = sum_m <M[m][rho,:], V[m][:]> — src/proofgen.rs:41-49 (nmat=1) and :101-132 (nmat=r*t1)."""
+    if out is None:
+        out = HatVec(ctx, rows)
+    ctx._check(ctx._lib.lab_matvec_sum(ctx._h, out._h, out_off, M._h, m_off, nmat, rows, cols, V._h, v_off))
+    return out

@@ -1,0 +1,437 @@
+// capi.hip — implementation of the C ABI in include/labrador_hip.h: context
+// construction (limb primes, twiddle and CRT tables), device vectors, and the
+// per-operation entry points that sequence the gfx950 kernels on the context's
+// stream.  There is NO CPU fallback: without a GPU lab_ctx_create fails with
+// LAB_ERR_NO_DEVICE.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "context.h"
+
+using namespace lab;
+typedef unsigned __int128 u128;
+
+// ------------------------------------------------------------- utilities
+namespace lab {
+
+int fail(const lab_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+int ensure_scratch(lab_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->scratch_bytes) return LAB_OK;
+  LAB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->scratch) LAB_HIP(ctx, hipFree(ctx->scratch));
+  ctx->scratch = nullptr;
+  ctx->scratch_bytes = 0;
+  size_t want = bytes + bytes / 8 + (1u << 20);
+  LAB_HIP(ctx, hipMalloc(&ctx->scratch, want));
+  ctx->scratch_bytes = want;
+  return LAB_OK;
+}
+
+bool is_device_pointer(const void* p) {
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // plain malloc memory: clear the sticky error
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+}  // namespace lab
+
+// ------------------------------------------------------------- number theory (host)
+static uint64_t powmod(uint64_t b, uint64_t e, uint64_t m) {
+  u128 r = 1, x = b % m;
+  while (e) {
+    if (e & 1) r = r * x % m;
+    x = x * x % m;
+    e >>= 1;
+  }
+  return (uint64_t)r;
+}
+static uint64_t invmod_prime(uint64_t a, uint64_t p) { return powmod(a % p, p - 2, p); }
+
+static bool is_prime_u64(uint64_t n) {
+  if (n < 2) return false;
+  static const uint64_t small[] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37};
+  for (uint64_t s : small) {
+    if (n % s == 0) return n == s;
+  }
+  uint64_t d = n - 1;
+  int r = 0;
+  while ((d & 1) == 0) { d >>= 1; r++; }
+  for (uint64_t a : small) {
+    uint64_t x = powmod(a, d, n);
+    if (x == 1 || x == n - 1) continue;
+    bool comp = true;
+    for (int i = 1; i < r; i++) {
+      x = (uint64_t)((u128)x * x % n);
+      if (x == n - 1) { comp = false; break; }
+    }
+    if (comp) return false;
+  }
+  return true;
+}
+
+static uint32_t brv6(uint32_t k) {
+  uint32_t r = 0;
+  for (int i = 0; i < LOGD; i++) r |= ((k >> i) & 1u) << (LOGD - 1 - i);
+  return r;
+}
+static uint32_t shoup(uint32_t w, uint32_t p) { return (uint32_t)(((uint64_t)w << 32) / p); }
+
+// NTT-friendly primes below 2^30 (p == 1 mod 128), largest first.
+static const uint32_t kLimbPrimes[MAX_LIMBS] = {1073741441u, 1073739649u, 1073738753u, 1073736449u};
+
+static bool build_limb_table(uint32_t p, LimbTable* t) {
+  memset(t, 0, sizeof *t);
+  t->p = p;
+  t->p2 = 2 * p;
+  // p^-1 mod 2^32 by Newton iteration
+  uint32_t inv = p;
+  for (int i = 0; i < 5; i++) inv *= 2u - p * inv;
+  t->pinv = inv;
+  t->r1 = (uint32_t)(((uint64_t)1 << 32) % p);
+  t->r2 = (uint32_t)((u128)t->r1 * t->r1 % p);
+  t->q_hi_mul = t->r1;
+  t->q_hi_mul_sh = shoup(t->r1, p);
+  // primitive 128th root of unity: psi^64 == -1
+  uint64_t psi = 0;
+  for (uint64_t g = 2; g < 2000; g++) {
+    uint64_t c = powmod(g, (p - 1) / (2 * D), p);
+    if (powmod(c, D, p) == p - 1) { psi = c; break; }
+  }
+  if (!psi) return false;
+  uint64_t psi_inv = invmod_prime(psi, p);
+  for (uint32_t k = 0; k < (uint32_t)D; k++) {
+    uint32_t w = (uint32_t)powmod(psi, brv6(k), p), wi = (uint32_t)powmod(psi_inv, brv6(k), p);
+    t->fwd[k][0] = w;  t->fwd[k][1] = shoup(w, p);
+    t->inv[k][0] = wi; t->inv[k][1] = shoup(wi, p);
+  }
+  uint64_t ninv = invmod_prime(D, p);
+  uint64_t re = 1;
+  for (int e = 0; e < 4; e++) {
+    uint32_t lo = (uint32_t)((u128)ninv * re % p);
+    uint32_t hi = (uint32_t)((u128)lo * t->inv[1][0] % p);
+    t->scale_lo[e][0] = lo; t->scale_lo[e][1] = shoup(lo, p);
+    t->scale_hi[e][0] = hi; t->scale_hi[e][1] = shoup(hi, p);
+    re = (uint64_t)((u128)re * t->r1 % p);
+  }
+  return true;
+}
+
+static void build_crt_table(const lab_ctx* c, CrtTable* t) {
+  memset(t, 0, sizeof *t);
+  t->q = c->q;
+  t->nlimbs = c->nlimbs;
+  u128 M = 1;
+  for (int a = 0; a < c->nlimbs; a++) {
+    t->p[a] = c->primes[a];
+    t->prefix_mod_q[a] = (uint64_t)(M % c->q);
+    M *= c->primes[a];
+    for (int b = 0; b < a; b++) {
+      uint32_t g = (uint32_t)invmod_prime(c->primes[b] % c->primes[a], c->primes[a]);
+      t->ginv[a][b][0] = g;
+      t->ginv[a][b][1] = shoup(g, c->primes[a]);
+    }
+  }
+  t->m_mod_q = (uint64_t)(M % c->q);
+  u128 h = (M - 1) / 2;
+  for (int a = 0; a < c->nlimbs; a++) {
+    t->half_digits[a] = (uint32_t)(h % c->primes[a]);
+    h /= c->primes[a];
+  }
+}
+
+// ------------------------------------------------------------- context
+extern "C" int lab_ctx_create(uint64_t q, int device, uint64_t max_len, lab_ctx** out) {
+  if (!out) return LAB_ERR_ARG;
+  *out = nullptr;
+  if (q < 3 || (q & 1) == 0 || q >= (1ull << 40)) return LAB_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return LAB_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) return LAB_ERR_ARG;
+  lab_ctx* c = new lab_ctx();
+  c->q = q;
+  c->device = device;
+  if (max_len == 0) max_len = 65536;
+  if (q < (1ull << 30) && q % (2 * D) == 1 && is_prime_u64(q)) {
+    c->direct = true;
+    c->nlimbs = 1;
+    c->primes[0] = (uint32_t)q;
+    c->max_len = 1ull << 40;  // arithmetic is mod q itself: any length is exact
+  } else {
+    u128 M = 1;
+    u128 unit = (u128)D * (u128)(q - 1) * (u128)(q - 1);
+    for (int L = 1; L <= MAX_LIMBS; L++) {
+      M *= kLimbPrimes[L - 1];
+      u128 cap = ((M - 1) / 2) / unit;
+      if (cap >= max_len) {
+        c->nlimbs = L;
+        c->max_len = cap > (u128)(1ull << 62) ? (1ull << 62) : (uint64_t)cap;
+        break;
+      }
+    }
+    if (!c->nlimbs) { delete c; return LAB_ERR_RANGE; }
+    for (int l = 0; l < c->nlimbs; l++) c->primes[l] = kLimbPrimes[l];
+  }
+  for (int l = 0; l < c->nlimbs; l++)
+    if (!build_limb_table(c->primes[l], &c->h_tabs[l])) { delete c; return LAB_ERR_ARG; }
+  build_crt_table(c, &c->h_crt);
+
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) { c->own_stream = true; e = hipMalloc(&c->d_tabs, sizeof(LimbTable) * c->nlimbs); }
+  if (e == hipSuccess) e = hipMalloc(&c->d_crt, sizeof(CrtTable));
+  if (e == hipSuccess) e = hipMemcpy(c->d_tabs, c->h_tabs, sizeof(LimbTable) * c->nlimbs, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(c->d_crt, &c->h_crt, sizeof(CrtTable), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    lab_ctx_destroy(c);
+    return LAB_ERR_HIP;
+  }
+  *out = c;
+  return LAB_OK;
+}
+
+extern "C" void lab_ctx_destroy(lab_ctx* c) {
+  if (!c) return;
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->scratch) (void)hipFree(c->scratch);
+  if (c->d_tabs) (void)hipFree(c->d_tabs);
+  if (c->d_crt) (void)hipFree(c->d_crt);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int lab_ctx_info(const lab_ctx* c, lab_info* out) {
+  if (!c || !out) return LAB_ERR_ARG;
+  out->q = c->q;
+  out->nlimbs = c->nlimbs;
+  for (int l = 0; l < 4; l++) out->primes[l] = l < c->nlimbs ? c->primes[l] : 0;
+  out->max_len = c->max_len;
+  out->device = c->device;
+  return LAB_OK;
+}
+
+extern "C" const char* lab_last_error(const lab_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int lab_ctx_set_stream(lab_ctx* c, void* hip_stream) {
+  if (!c) return LAB_ERR_ARG;
+  LAB_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->own_stream && c->stream) LAB_HIP(c, hipStreamDestroy(c->stream));
+  c->stream = static_cast<hipStream_t>(hip_stream);
+  c->own_stream = false;
+  return LAB_OK;
+}
+
+extern "C" int lab_ctx_synchronize(lab_ctx* c) {
+  if (!c) return LAB_ERR_ARG;
+  LAB_HIP(c, hipStreamSynchronize(c->stream));
+  return LAB_OK;
+}
+
+// ------------------------------------------------------------- staging helpers
+// Returns a device pointer holding `bytes` of `p`: `p` itself if it is device
+// memory, otherwise a copy placed in `stage` (device scratch).
+static int stage_in(lab_ctx* c, const void* p, void* stage, size_t bytes, const void** dev) {
+  if (is_device_pointer(p)) { *dev = p; return LAB_OK; }
+  LAB_HIP(c, hipMemcpyAsync(stage, p, bytes, hipMemcpyHostToDevice, c->stream));
+  *dev = stage;
+  return LAB_OK;
+}
+
+// ------------------------------------------------------------- polymul seam
+extern "C" int lab_negacyclic_polymul_u64(lab_ctx* c, uint64_t* prod, const uint64_t* lhs, const uint64_t* rhs,
+                                          size_t batch) {
+  if (!c || (batch && (!prod || !lhs || !rhs))) return fail(c, LAB_ERR_ARG, "lab_negacyclic_polymul_u64: null argument");
+  if (batch == 0) return LAB_OK;
+  LAB_HIP(c, hipSetDevice(c->device));
+  const size_t words = batch * D, L = c->nlimbs;
+  const size_t hat_bytes = Carver::padded(L * words * 4), u64_bytes = Carver::padded(words * 8);
+  int rc = ensure_scratch(c, 2 * hat_bytes + 3 * u64_bytes);
+  if (rc) return rc;
+  Carver cv(c->scratch);
+  uint32_t* ha = cv.take<uint32_t>(L * words);
+  uint32_t* hb = cv.take<uint32_t>(L * words);
+  uint64_t* sa = cv.take<uint64_t>(words);
+  uint64_t* sb = cv.take<uint64_t>(words);
+  uint64_t* so = cv.take<uint64_t>(words);
+  const void *da, *db;
+  if ((rc = stage_in(c, lhs, sa, words * 8, &da))) return rc;
+  if ((rc = stage_in(c, rhs, sb, words * 8, &db))) return rc;
+  HatView va{ha, words}, vb{hb, words};
+  LAB_HIP(c, launch_reduce_u64((const uint64_t*)da, va, batch, c->nlimbs, c->d_tabs, c->stream));
+  LAB_HIP(c, launch_reduce_u64((const uint64_t*)db, vb, batch, c->nlimbs, c->d_tabs, c->stream));
+  LAB_HIP(c, launch_ntt(true, va, va, batch, c->nlimbs, c->d_tabs, 0, c->stream));
+  LAB_HIP(c, launch_ntt(true, vb, vb, batch, c->nlimbs, c->d_tabs, 0, c->stream));
+  LAB_HIP(c, launch_pointwise(PW_MUL_KEEP_SCALE, va, va, vb, batch, c->nlimbs, c->d_tabs, c->stream));
+  LAB_HIP(c, launch_ntt(false, va, va, batch, c->nlimbs, c->d_tabs, 1, c->stream));  // scale n^-1 * 2^32 undoes the REDC factor
+  const bool out_dev = is_device_pointer(prod);
+  uint64_t* dout = out_dev ? prod : so;
+  LAB_HIP(c, launch_crt_to_u64(va, dout, batch, c->d_crt, c->stream));
+  if (!out_dev) {
+    LAB_HIP(c, hipMemcpyAsync(prod, so, words * 8, hipMemcpyDeviceToHost, c->stream));
+    LAB_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  return LAB_OK;
+}
+
+// ------------------------------------------------------------- raw NTT (config 2)
+static int ntt_inplace(lab_ctx* c, uint32_t* dev, size_t batch, bool fwd) {
+  if (!c || (batch && !dev)) return fail(c, LAB_ERR_ARG, "lab_ntt: null argument");
+  if (batch == 0) return LAB_OK;
+  if (!is_device_pointer(dev)) return fail(c, LAB_ERR_ARG, "lab_ntt: residues must be device memory");
+  LAB_HIP(c, hipSetDevice(c->device));
+  HatView v{dev, batch * D};
+  LAB_HIP(c, launch_ntt(fwd, v, v, batch, c->nlimbs, c->d_tabs, 0, c->stream));
+  return LAB_OK;
+}
+extern "C" int lab_ntt_forward(lab_ctx* c, uint32_t* dev, size_t batch) { return ntt_inplace(c, dev, batch, true); }
+extern "C" int lab_ntt_inverse(lab_ctx* c, uint32_t* dev, size_t batch) { return ntt_inplace(c, dev, batch, false); }
+
+// ------------------------------------------------------------- vectors
+extern "C" int lab_vec_create(lab_ctx* c, size_t count, lab_vec** out) {
+  if (!c || !out || count == 0) return fail(c, LAB_ERR_ARG, "lab_vec_create: bad argument");
+  *out = nullptr;
+  LAB_HIP(c, hipSetDevice(c->device));
+  lab_vec* v = new lab_vec();
+  v->ctx = c;
+  v->count = count;
+  hipError_t e = hipMalloc(&v->d, (size_t)c->nlimbs * count * D * sizeof(uint32_t));
+  if (e != hipSuccess) {
+    delete v;
+    return fail(c, LAB_ERR_HIP, "hipMalloc(%zu elements x %d limbs): %s", count, c->nlimbs, hipGetErrorString(e));
+  }
+  *out = v;
+  return LAB_OK;
+}
+
+extern "C" void lab_vec_destroy(lab_vec* v) {
+  if (!v) return;
+  if (v->ctx && v->ctx->stream) (void)hipStreamSynchronize(v->ctx->stream);
+  if (v->d) (void)hipFree(v->d);
+  delete v;
+}
+
+extern "C" size_t lab_vec_count(const lab_vec* v) { return v ? v->count : 0; }
+
+static int check_range(lab_ctx* c, const lab_vec* v, size_t off, size_t n, const char* what) {
+  if (!v) return fail(c, LAB_ERR_ARG, "%s: null vector", what);
+  if (v->ctx != c) return fail(c, LAB_ERR_ARG, "%s: vector belongs to another context", what);
+  if (off > v->count || n > v->count - off)
+    return fail(c, LAB_ERR_LEN_MISMATCH, "%s: range [%zu,%zu) exceeds vector of %zu elements", what, off, off + n, v->count);
+  return LAB_OK;
+}
+
+extern "C" int lab_vec_load_u64(lab_ctx* c, lab_vec* dst, size_t dst_off, const uint64_t* coeffs, size_t count) {
+  if (!c) return LAB_ERR_ARG;
+  int rc = check_range(c, dst, dst_off, count, "lab_vec_load_u64");
+  if (rc) return rc;
+  if (count == 0) return LAB_OK;
+  if (!coeffs) return fail(c, LAB_ERR_ARG, "lab_vec_load_u64: null coefficients");
+  LAB_HIP(c, hipSetDevice(c->device));
+  const void* dsrc = coeffs;
+  if (!is_device_pointer(coeffs)) {
+    if ((rc = ensure_scratch(c, count * D * 8))) return rc;
+    if ((rc = stage_in(c, coeffs, c->scratch, count * D * 8, &dsrc))) return rc;
+  }
+  HatView v = dst->view(dst_off);
+  LAB_HIP(c, launch_reduce_u64((const uint64_t*)dsrc, v, count, c->nlimbs, c->d_tabs, c->stream));
+  LAB_HIP(c, launch_ntt(true, v, v, count, c->nlimbs, c->d_tabs, 0, c->stream));
+  if (dsrc != coeffs) LAB_HIP(c, hipStreamSynchronize(c->stream));  // the staged host buffer may be reused by the caller
+  return LAB_OK;
+}
+
+extern "C" int lab_vec_store_u64(lab_ctx* c, const lab_vec* src, size_t src_off, size_t count, uint64_t* coeffs) {
+  if (!c) return LAB_ERR_ARG;
+  int rc = check_range(c, src, src_off, count, "lab_vec_store_u64");
+  if (rc) return rc;
+  if (count == 0) return LAB_OK;
+  if (!coeffs) return fail(c, LAB_ERR_ARG, "lab_vec_store_u64: null output");
+  LAB_HIP(c, hipSetDevice(c->device));
+  const size_t words = count * D, L = c->nlimbs;
+  const bool out_dev = is_device_pointer(coeffs);
+  if ((rc = ensure_scratch(c, Carver::padded(L * words * 4) + Carver::padded(words * 8)))) return rc;
+  Carver cv(c->scratch);
+  uint32_t* tmp = cv.take<uint32_t>(L * words);
+  uint64_t* so = cv.take<uint64_t>(words);
+  HatView t{tmp, words};
+  LAB_HIP(c, launch_ntt(false, src->view(src_off), t, count, c->nlimbs, c->d_tabs, 0, c->stream));
+  LAB_HIP(c, launch_crt_to_u64(t, out_dev ? coeffs : so, count, c->d_crt, c->stream));
+  if (!out_dev) {
+    LAB_HIP(c, hipMemcpyAsync(coeffs, so, words * 8, hipMemcpyDeviceToHost, c->stream));
+    LAB_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  return LAB_OK;
+}
+
+extern "C" int lab_vec_fill_synthetic(lab_ctx* c, lab_vec* dst, size_t dst_off, size_t count, uint64_t seed,
+                                      uint64_t first_elem, uint64_t bound) {
+  if (!c) return LAB_ERR_ARG;
+  int rc = check_range(c, dst, dst_off, count, "lab_vec_fill_synthetic");
+  if (rc) return rc;
+  if (bound == 0 || bound > c->q) return fail(c, LAB_ERR_ARG, "lab_vec_fill_synthetic: bound must be in [1,q]");
+  LAB_HIP(c, hipSetDevice(c->device));
+  // generate coefficient-domain residues in chunks, then transform in place
+  const size_t chunk = 1u << 18;  // 128 MiB of u64 staging at most
+  if ((rc = ensure_scratch(c, (count < chunk ? count : chunk) * D * 8))) return rc;
+  uint64_t* stage = static_cast<uint64_t*>(c->scratch);
+  for (size_t done = 0; done < count; done += chunk) {
+    size_t n = count - done < chunk ? count - done : chunk;
+    HatView v = dst->view(dst_off + done);
+    LAB_HIP(c, launch_synth_fill_u64(stage, n, seed, first_elem + done, bound, c->stream));
+    LAB_HIP(c, launch_reduce_u64(stage, v, n, c->nlimbs, c->d_tabs, c->stream));
+    LAB_HIP(c, launch_ntt(true, v, v, n, c->nlimbs, c->d_tabs, 0, c->stream));
+  }
+  return LAB_OK;
+}
+
+// ------------------------------------------------------------- inner products / mat-vec
+extern "C" int lab_matvec_sum(lab_ctx* c, lab_vec* out, size_t out_off, const lab_vec* M, size_t m_off, size_t nmat,
+                              size_t rows, size_t cols, const lab_vec* V, size_t v_off) {
+  if (!c) return LAB_ERR_ARG;
+  int rc;
+  if ((rc = check_range(c, out, out_off, rows, "lab_matvec_sum(out)"))) return rc;
+  if (nmat && rows && cols > ((size_t)-1) / nmat / rows) return fail(c, LAB_ERR_ARG, "lab_matvec_sum: size overflow");
+  if ((rc = check_range(c, M, m_off, nmat * rows * cols, "lab_matvec_sum(M)"))) return rc;
+  if ((rc = check_range(c, V, v_off, nmat * cols, "lab_matvec_sum(V)"))) return rc;
+  if (nmat == 0 || rows == 0 || cols == 0) return fail(c, LAB_ERR_ARG, "lab_matvec_sum: empty dimension");
+  if ((u128)nmat * cols > c->max_len)
+    return fail(c, LAB_ERR_RANGE, "lab_matvec_sum: reduction length %zu exceeds the exactness bound %llu of this context",
+                nmat * cols, (unsigned long long)c->max_len);
+  if (rows > 0x7fffffffu || cols > 0x7fffffffu / 64 || nmat > 65535) return fail(c, LAB_ERR_ARG, "lab_matvec_sum: dimension too large");
+  LAB_HIP(c, hipSetDevice(c->device));
+  if (nmat == 1) {
+    LAB_HIP(c, launch_matvec_partial(out->view(out_off), M->view(m_off), V->view(v_off), 1, rows, cols, c->nlimbs,
+                                     c->d_tabs, c->stream));
+    return LAB_OK;
+  }
+  const size_t pw = nmat * rows * D;
+  if ((rc = ensure_scratch(c, (size_t)c->nlimbs * pw * 4))) return rc;
+  HatView partial{static_cast<uint32_t*>(c->scratch), pw};
+  LAB_HIP(c, launch_matvec_partial(partial, M->view(m_off), V->view(v_off), nmat, rows, cols, c->nlimbs, c->d_tabs,
+                                   c->stream));
+  LAB_HIP(c, launch_sum_terms(out->view(out_off), partial, nmat, rows, c->nlimbs, c->d_tabs, c->stream));
+  return LAB_OK;
+}
+
+extern "C" int lab_inner_product(lab_ctx* c, lab_vec* out, size_t out_off, const lab_vec* v1, size_t off1,
+                                 const lab_vec* v2, size_t off2, size_t len) {
+  return lab_matvec_sum(c, out, out_off, v1, off1, 1, 1, len, v2, off2);
+}

@@ -1,0 +1,63 @@
+// kernels.h — host-callable launchers for the gfx950 kernels (implemented in
+// ntt_kernels.hip / linalg_kernels.hip / proof_kernels.hip).  Internal to the
+// shared library; the public surface is include/labrador_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "zq_device.h"
+
+namespace lab {
+
+// A view of `count` ring elements inside a hat-domain allocation:
+// limb l, element k, slot j at base[l * plane_stride + (k) * 64 + j].
+struct HatView {
+  uint32_t* base;        // already offset to the first element of limb 0
+  size_t plane_stride;   // u32 words between consecutive limb planes
+};
+struct ConstHatView {
+  const uint32_t* base;
+  size_t plane_stride;
+  ConstHatView() : base(nullptr), plane_stride(0) {}
+  ConstHatView(const uint32_t* b, size_t s) : base(b), plane_stride(s) {}
+  ConstHatView(const HatView& v) : base(v.base), plane_stride(v.plane_stride) {}
+};
+
+// CRT constants for hat -> coefficient conversion (device resident).
+struct CrtTable {
+  uint64_t q;
+  int nlimbs;
+  uint32_t p[MAX_LIMBS];
+  // Garner: inv[i][j] = p_j^-1 mod p_i (j < i), with Shoup companions
+  uint32_t ginv[MAX_LIMBS][MAX_LIMBS][2];
+  // prefix[i] = (p_0*...*p_{i-1}) mod q ; mmodq = (p_0*...*p_{L-1}) mod q
+  uint64_t prefix_mod_q[MAX_LIMBS];
+  uint64_t m_mod_q;
+  // half-modulus test in mixed radix: M/2 digits (floor), for the sign decision
+  uint32_t half_digits[MAX_LIMBS];
+};
+
+// ---- ntt_kernels.hip
+hipError_t launch_ntt(bool forward, ConstHatView src, HatView dst, size_t count, int nlimbs, const LimbTable* tabs,
+                      int escale, hipStream_t s);
+hipError_t launch_reduce_u64(const uint64_t* coeffs, HatView dst, size_t count, int nlimbs, const LimbTable* tabs,
+                             hipStream_t s);
+hipError_t launch_crt_to_u64(ConstHatView src, uint64_t* coeffs, size_t count, const CrtTable* crt, hipStream_t s);
+hipError_t launch_synth_fill_u64(uint64_t* coeffs, size_t count, uint64_t seed, uint64_t first_elem, uint64_t bound,
+                                 hipStream_t s);
+
+// ---- linalg_kernels.hip
+enum PointwiseOp { PW_MUL = 0, PW_ADD = 1, PW_SUB = 2, PW_MUL_KEEP_SCALE = 3 };
+// out[k] = a[k] (op) b[k] for k < count; PW_MUL returns plain (e=0) products, PW_MUL_KEEP_SCALE leaves the 2^-32 factor.
+hipError_t launch_pointwise(PointwiseOp op, HatView out, ConstHatView a, ConstHatView b, size_t count, int nlimbs,
+                            const LimbTable* tabs, hipStream_t s);
+// partial[(m*rows + rho)] = <M[m][rho][:], V[m][:]>   (hat elements, plain scale)
+hipError_t launch_matvec_partial(HatView partial, ConstHatView M, ConstHatView V, size_t nmat, size_t rows,
+                                 size_t cols, int nlimbs, const LimbTable* tabs, hipStream_t s);
+// out[rho] = sum_{m<nterms} partial[m*rows + rho]
+hipError_t launch_sum_terms(HatView out, ConstHatView partial, size_t nterms, size_t rows, int nlimbs,
+                            const LimbTable* tabs, hipStream_t s);
+const char* matvec_kernel_name();
+
+}  // namespace lab

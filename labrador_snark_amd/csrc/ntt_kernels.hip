@@ -1,0 +1,154 @@
+// ntt_kernels.hip — batched 64-point negacyclic NTT/INTT and the conversions
+// between the boundary's coefficient form (u64 mod q) and the device's hat form
+// (u32 residues per RNS limb, NTT domain).  gfx950 only.
+//
+// Replaces the transform inside `PLAN.negacyclic_polymul` and the u64<->Zq
+// marshalling around it (src/algebraic.rs:385-399, 407-420).
+#include "kernels.h"
+
+namespace lab {
+
+// One polynomial per thread, one wave per block: the wave's 64 polynomials
+// (16 KiB) are fetched with 16-byte coalesced loads, transposed through LDS,
+// transformed entirely in registers (192 lazy butterflies, twiddles from
+// scalar loads) and written back the same way.
+// Algorithmic traffic: 256 B in + 256 B out per polynomial per limb.
+template <bool FWD>
+__global__ void __launch_bounds__(64)
+k_ntt64(const uint32_t* __restrict__ src, size_t src_ps, uint32_t* __restrict__ dst, size_t dst_ps, size_t count,
+        const LimbTable* __restrict__ tabs, int escale) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[TILE_WORDS];
+  const int limb = blockIdx.y;
+  const LimbTable* tab = tabs + limb;
+  const size_t base = (size_t)blockIdx.x * 64;
+  const int lane = threadIdx.x;
+  uint32_t x[D];
+  tile_load_u32(x, src + (size_t)limb * src_ps, base, count, lds, lane);
+  if (FWD) ntt64_forward(x, tab); else ntt64_inverse(x, tab, escale);
+  tile_store_u32(x, dst + (size_t)limb * dst_ps, base, count, lds, lane);
+}
+
+hipError_t launch_ntt(bool forward, ConstHatView src, HatView dst, size_t count, int nlimbs, const LimbTable* tabs,
+                      int escale, hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  dim3 grid((unsigned)((count + 63) / 64), (unsigned)nlimbs);
+  if (forward)
+    hipLaunchKernelGGL(k_ntt64<true>, grid, dim3(64), 0, s, src.base, src.plane_stride, dst.base, dst.plane_stride,
+                       count, tabs, escale);
+  else
+    hipLaunchKernelGGL(k_ntt64<false>, grid, dim3(64), 0, s, src.base, src.plane_stride, dst.base, dst.plane_stride,
+                       count, tabs, escale);
+  return hipGetLastError();
+}
+
+// coefficient u64 in [0,q) -> residue mod each limb prime (q < 2^40, so x = hi*2^32 + lo with hi < 2^8).
+__global__ void __launch_bounds__(256)
+k_reduce_u64(const uint64_t* __restrict__ coeffs, uint32_t* __restrict__ dst, size_t dst_ps, size_t nwords,
+             int nlimbs, const LimbTable* __restrict__ tabs) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 2;
+  for (; i < nwords; i += stride) {
+    // nwords is a multiple of 64, so the pair (i, i+1) is always in range
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(coeffs + i);
+    for (int l = 0; l < nlimbs; l++) {
+      const uint32_t p = tabs[l].p, r1 = tabs[l].r1;
+      uint32_t a = (uint32_t)(((v.x >> 32) * r1 + (uint32_t)v.x) % p);
+      uint32_t b = (uint32_t)(((v.y >> 32) * r1 + (uint32_t)v.y) % p);
+      *reinterpret_cast<uint2*>(dst + (size_t)l * dst_ps + i) = make_uint2(a, b);
+    }
+  }
+}
+
+hipError_t launch_reduce_u64(const uint64_t* coeffs, HatView dst, size_t count, int nlimbs, const LimbTable* tabs,
+                             hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  size_t nwords = count * D;
+  unsigned blocks = (unsigned)((nwords / 2 + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_reduce_u64, dim3(blocks), dim3(256), 0, s, coeffs, dst.base, dst.plane_stride, nwords, nlimbs,
+                     tabs);
+  return hipGetLastError();
+}
+
+__device__ __forceinline__ uint64_t mulmod_q(uint32_t d, uint64_t c, uint64_t q) {
+  // d < 2^30, c < q < 2^40: split c so every intermediate fits 64 bits
+  uint64_t chi = c >> 20, clo = c & 0xFFFFF;
+  uint64_t t = ((uint64_t)d * chi) % q;
+  t = (t << 20) % q;
+  return (t + (uint64_t)d * clo) % q;
+}
+
+// hat residues (already inverse-transformed, canonical) -> signed CRT -> mod q.
+// The integer being reconstructed is the exact negacyclic result; it lies in
+// (-M/2, M/2), which lab_ctx guarantees through max_len.
+__global__ void __launch_bounds__(256)
+k_crt_to_u64(const uint32_t* __restrict__ src, size_t src_ps, uint64_t* __restrict__ coeffs, size_t nwords,
+             const CrtTable* __restrict__ crt) {
+  const int L = crt->nlimbs;
+  const uint64_t q = crt->q;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < nwords; i += stride) {
+    uint32_t r[MAX_LIMBS], d[MAX_LIMBS];
+    for (int l = 0; l < L; l++) r[l] = src[(size_t)l * src_ps + i];
+    if (L == 1 && (uint64_t)crt->p[0] == q) { coeffs[i] = r[0]; continue; }
+    // Garner mixed-radix digits
+    d[0] = r[0];
+    for (int a = 1; a < L; a++) {
+      const uint32_t p = crt->p[a];
+      uint32_t t = r[a];
+      for (int b = 0; b < a; b++) {
+        uint32_t db = d[b] % p;                       // digits of other limbs may exceed p by < 2^30/p
+        uint32_t diff = t >= db ? t - db : t + p - db;
+        t = csub(mul_shoup_lazy(diff, crt->ginv[a][b][0], crt->ginv[a][b][1], p), p);
+      }
+      d[a] = t;
+    }
+    // sign: value > (M-1)/2 ?
+    bool neg = false;
+    for (int a = L - 1; a >= 0; a--) {
+      if (d[a] != crt->half_digits[a]) { neg = d[a] > crt->half_digits[a]; break; }
+    }
+    uint64_t acc = d[0] % q;
+    for (int a = 1; a < L; a++) acc = (acc + mulmod_q(d[a], crt->prefix_mod_q[a], q)) % q;
+    if (neg) acc = acc >= crt->m_mod_q ? acc - crt->m_mod_q : acc + q - crt->m_mod_q;
+    coeffs[i] = acc;
+  }
+}
+
+hipError_t launch_crt_to_u64(ConstHatView src, uint64_t* coeffs, size_t count, const CrtTable* crt, hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  size_t nwords = count * D;
+  unsigned blocks = (unsigned)((nwords + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_crt_to_u64, dim3(blocks), dim3(256), 0, s, src.base, src.plane_stride, coeffs, nwords, crt);
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256)
+k_synth_fill_u64(uint64_t* __restrict__ coeffs, size_t nwords, uint64_t seed_mixed, uint64_t first_word,
+                 uint64_t bound) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < nwords; i += stride) coeffs[i] = synth_residue(seed_mixed, first_word + i, bound);
+}
+
+static uint64_t host_splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+hipError_t launch_synth_fill_u64(uint64_t* coeffs, size_t count, uint64_t seed, uint64_t first_elem, uint64_t bound,
+                                 hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  size_t nwords = count * D;
+  unsigned blocks = (unsigned)((nwords + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_synth_fill_u64, dim3(blocks), dim3(256), 0, s, coeffs, nwords, host_splitmix64(seed),
+                     first_elem * D, bound);
+  return hipGetLastError();
+}
+
+}  // namespace lab

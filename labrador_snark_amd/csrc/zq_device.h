@@ -1,0 +1,208 @@
+// zq_device.h — modular arithmetic and the in-register 64-point negacyclic NTT
+// for gfx950 (CDNA4).  Device-only; included by the *.hip kernel files.
+//
+// Replaces, on the device, the arithmetic the reference performs one i128 `%`
+// at a time (src/algebraic.rs:24-38, 95-134) and the transform hidden inside
+// `PLAN.negacyclic_polymul` (src/algebraic.rs:396).
+//
+// Design facts (measured with tools/ubench_valu.hip on MI355X):
+//  * every 32-bit integer VALU op — add, min, mul_lo, mul_hi — issues at the
+//    same rate (4 cycles / wave64); v_mad_u64_u32 ~1.2x that.  So the cost of a
+//    modular multiply is its instruction COUNT, and 32-bit multiplies are not
+//    the quarter-rate ops they are on older GCN parts.
+//  * limb primes are < 2^30 so that Harvey's lazy butterflies keep values in
+//    [0,4p) inside 32 bits and 8 products of canonical residues can be summed
+//    in a 64-bit accumulator before its high word needs a reduction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lab {
+
+constexpr int D = 64;          // src/constants.rs:15
+constexpr int LOGD = 6;
+constexpr int MAX_LIMBS = 4;
+
+// Per-limb constants, resident in device memory (one per RNS prime).
+struct LimbTable {
+  uint32_t p;            // prime, p == 1 (mod 128), p < 2^30
+  uint32_t p2;           // 2p
+  uint32_t pinv;         // p^-1 mod 2^32  (signed Montgomery REDC)
+  uint32_t r1;           // 2^32 mod p
+  uint32_t r2;           // 2^64 mod p
+  uint32_t pad[3];
+  uint32_t q_hi_mul;     // 2^32 mod p, used to fold 64-bit coefficients: x = hi*2^32+lo
+  uint32_t q_hi_mul_sh;  // Shoup companion of q_hi_mul
+  uint32_t pad2[6];
+  // twiddles: index m+i of stage m (m = 1,2,4,...,32), psi^brv(m+i); [k][0]=w, [k][1]=floor(w*2^32/p)
+  uint32_t fwd[D][2];
+  uint32_t inv[D][2];    // inverse twiddles for Gentleman-Sande, same indexing
+  // final INTT scaling n^-1 * R^e (e = 0..3) and the same times inv[1] (last-stage twiddle), Shoup pairs
+  uint32_t scale_lo[4][2];
+  uint32_t scale_hi[4][2];
+};
+
+__device__ __forceinline__ uint32_t csub(uint32_t x, uint32_t m) {  // x in [0,2m) -> [0,m)
+  return min(x, x - m);
+}
+
+// Shoup multiplication by a constant w with companion wp = floor(w*2^32/p).
+// Valid for any y < 2^32; result in [0,2p).
+__device__ __forceinline__ uint32_t mul_shoup_lazy(uint32_t y, uint32_t w, uint32_t wp, uint32_t p) {
+  uint32_t qh = __umulhi(y, wp);
+  return y * w - qh * p;
+}
+
+// Signed Montgomery reduction of a 64-bit value T < p*2^32: returns T*2^-32 mod p, canonical.
+__device__ __forceinline__ uint32_t redc64(uint64_t T, uint32_t p, uint32_t pinv) {
+  uint32_t lo = (uint32_t)T, hi = (uint32_t)(T >> 32);
+  uint32_t m = lo * pinv;
+  uint32_t t = hi - __umulhi(m, p);  // in (-p, p) as a wrapped u32
+  return min(t, t + p);
+}
+
+// a*b*2^-32 mod p for canonical a,b.
+__device__ __forceinline__ uint32_t mont_mul(uint32_t a, uint32_t b, uint32_t p, uint32_t pinv) {
+  return redc64((uint64_t)a * b, p, pinv);
+}
+
+// Bring the high word of a 64-bit accumulator back below p.  Precondition:
+// acc < p*2^32 + 8*p^2 (at most 8 canonical products were added since the last call), so hi < 3p.
+__device__ __forceinline__ uint64_t acc_fold(uint64_t acc, uint32_t p, uint32_t p2) {
+  uint32_t hi = (uint32_t)(acc >> 32);
+  hi = min(hi, hi - p2);
+  hi = min(hi, hi - p);
+  return ((uint64_t)hi << 32) | (uint32_t)acc;
+}
+
+// ---- 64-point negacyclic NTT, one polynomial per thread, fully unrolled.
+// Forward: Cooley-Tukey, natural order in, bit-reversed order out, values kept
+// lazily in [0,4p) (Harvey), canonical on exit.  Twiddle indices are compile
+// time constants and `tab` is wave-uniform, so the twiddles arrive through
+// scalar loads.
+__device__ __forceinline__ void ntt64_forward(uint32_t (&x)[D], const LimbTable* __restrict__ tab) {
+  const uint32_t p = tab->p, p2 = tab->p2;
+  int t = D;
+#pragma unroll
+  for (int m = 1; m < D; m <<= 1) {
+    t >>= 1;
+#pragma unroll
+    for (int i = 0; i < m; i++) {
+      const uint32_t w = tab->fwd[m + i][0], wp = tab->fwd[m + i][1];
+#pragma unroll
+      for (int j = 2 * i * t; j < 2 * i * t + t; j++) {
+        uint32_t X = x[j];
+        if (m > 1) X = csub(X, p2);            // stage 1 inputs are canonical already
+        uint32_t T = mul_shoup_lazy(x[j + t], w, wp, p);
+        x[j] = X + T;
+        x[j + t] = X - T + p2;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < D; j++) x[j] = csub(csub(x[j], p2), p);
+}
+
+// Inverse: Gentleman-Sande, bit-reversed in, natural out, values in [0,2p),
+// the n^-1 * R^e scaling folded into the last stage, canonical on exit.
+__device__ __forceinline__ void ntt64_inverse(uint32_t (&x)[D], const LimbTable* __restrict__ tab, int e) {
+  const uint32_t p = tab->p, p2 = tab->p2;
+  int t = 1;
+#pragma unroll
+  for (int m = D; m > 2; m >>= 1) {
+    const int h = m >> 1;
+#pragma unroll
+    for (int i = 0; i < h; i++) {
+      const uint32_t w = tab->inv[h + i][0], wp = tab->inv[h + i][1];
+#pragma unroll
+      for (int j = 2 * i * t; j < 2 * i * t + t; j++) {
+        uint32_t U = x[j], V = x[j + t];
+        x[j] = csub(U + V, p2);
+        x[j + t] = mul_shoup_lazy(U - V + p2, w, wp, p);
+      }
+    }
+    t <<= 1;
+  }
+  const uint32_t s0 = tab->scale_lo[e][0], s0p = tab->scale_lo[e][1];
+  const uint32_t s1 = tab->scale_hi[e][0], s1p = tab->scale_hi[e][1];
+#pragma unroll
+  for (int j = 0; j < D / 2; j++) {
+    uint32_t U = x[j], V = x[j + D / 2];
+    x[j] = csub(mul_shoup_lazy(U + V, s0, s0p, p), p);
+    x[j + D / 2] = csub(mul_shoup_lazy(U - V + p2, s1, s1p, p), p);
+  }
+}
+
+// ---- wave-tile transposition through LDS: a one-wave block owns 64 consecutive
+// polynomials (16 KiB of u32).  Global accesses are 16 B per lane, fully
+// coalesced (1 KiB per instruction); each thread ends up with one whole
+// polynomial in registers.  Row pitch 68 words keeps ds_read_b128/ds_write_b128
+// conflict-free in both directions.
+constexpr int TILE_PITCH = D + 4;
+constexpr int TILE_WORDS = D * TILE_PITCH;
+
+// Loads polys [base, base+64) of `plane` (u32 [count][64]); rows past `count` read as zero.
+__device__ __forceinline__ void tile_load_u32(uint32_t (&x)[D], const uint32_t* __restrict__ plane, size_t base,
+                                              size_t count, uint32_t* lds, int lane) {
+  const uint4* g = reinterpret_cast<const uint4*>(plane + base * D);
+  if (base + 64 <= count) {  // wave-uniform: full tile, 16 independent loads in flight
+    uint4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = g[i * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+      *reinterpret_cast<uint4*>(lds + (i * 4 + (lane >> 4)) * TILE_PITCH + (lane & 15) * 4) = v[i];
+  } else {
+#pragma unroll 1
+    for (int i = 0; i < 16; i++) {
+      int poly = i * 4 + (lane >> 4);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (base + poly < count) v = g[i * 64 + lane];
+      *reinterpret_cast<uint4*>(lds + poly * TILE_PITCH + (lane & 15) * 4) = v;
+    }
+  }
+  __syncthreads();  // block == one wave (launch_bounds 64): lowers to a wave-level barrier
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    uint4 v = *reinterpret_cast<const uint4*>(lds + lane * TILE_PITCH + c * 4);
+    x[c * 4 + 0] = v.x; x[c * 4 + 1] = v.y; x[c * 4 + 2] = v.z; x[c * 4 + 3] = v.w;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void tile_store_u32(const uint32_t (&x)[D], uint32_t* __restrict__ plane, size_t base,
+                                               size_t count, uint32_t* lds, int lane) {
+#pragma unroll
+  for (int c = 0; c < 16; c++)
+    *reinterpret_cast<uint4*>(lds + lane * TILE_PITCH + c * 4) =
+        make_uint4(x[c * 4 + 0], x[c * 4 + 1], x[c * 4 + 2], x[c * 4 + 3]);
+  __syncthreads();
+  uint4* g = reinterpret_cast<uint4*>(plane + base * D);
+  if (base + 64 <= count) {
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+      g[i * 64 + lane] = *reinterpret_cast<const uint4*>(lds + (i * 4 + (lane >> 4)) * TILE_PITCH + (lane & 15) * 4);
+  } else {
+#pragma unroll 1
+    for (int i = 0; i < 16; i++) {
+      int poly = i * 4 + (lane >> 4);
+      uint4 v = *reinterpret_cast<const uint4*>(lds + poly * TILE_PITCH + (lane & 15) * 4);
+      if (base + poly < count) g[i * 64 + lane] = v;
+    }
+  }
+  __syncthreads();
+}
+
+// splitmix64-based synthetic residues, identical to oracle orc_synth_residue (test/bench inputs).
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ uint64_t synth_residue(uint64_t seed_mixed, uint64_t idx, uint64_t bound) {
+  uint64_t h = splitmix64(seed_mixed ^ (idx * 0xD1342543DE82EF95ull + 0x2545F4914F6CDD1Dull));
+  return __umul64hi(h, bound);
+}
+
+}  // namespace lab
