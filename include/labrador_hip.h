@@ -137,6 +137,100 @@ int lab_inner_product(lab_ctx *ctx, lab_vec *out, size_t out_off, const lab_vec 
 int lab_matvec_sum(lab_ctx *ctx, lab_vec *out, size_t out_off, const lab_vec *M, size_t m_off, size_t nmat,
                    size_t rows, size_t cols, const lab_vec *V, size_t v_off);
 
+/* The inner Ajtai commitments for all r witness columns at once
+ * (src/proofgen.rs:41-49; also verifier check 15, src/verification.rs:274-279):
+ *   out[out_off + i*rows + rho] = < A[a_off + rho*inner ..+inner], S[:, i] >,  S = [inner][ncols] row-major
+ * i.e. t_i_all[i][rho] with A = [kappa][n], S = witness [n][r]. */
+int lab_ajtai_commit(lab_ctx *ctx, lab_vec *out, size_t out_off, const lab_vec *A, size_t a_off, size_t rows,
+                     size_t inner, const lab_vec *S, size_t s_off, size_t ncols);
+
+/* Gram-type products over witness-shaped arrays P, S = [n][r] row-major:
+ *   out[out_off + i*r + k] = sum_x P[p_off + x*r + i] * S[s_off + x*r + k]
+ * g_mat = S^T S (src/proofgen.rs:59-70); the two inner products of each h_ij (src/proofgen.rs:334-335). */
+int lab_gram(lab_ctx *ctx, lab_vec *out, size_t out_off, const lab_vec *P, size_t p_off, const lab_vec *S,
+             size_t s_off, size_t n, size_t r);
+
+/* sum_m poly_by_poly_vec(G[m], C[m]) — the C and D parts of the outer commitments
+ * (src/proofgen.rs:137-148 `rhs`, 364-378 `u_2`):
+ *   out[out_off + rho] = sum_{m<nterms} G[g_off + m] * C[c_off + m*len + rho] */
+int lab_axpy_commit(lab_ctx *ctx, lab_vec *out, size_t out_off, const lab_vec *G, size_t g_off, const lab_vec *C,
+                    size_t c_off, size_t nterms, size_t len);
+
+/* z = sum_i c_i * s_i (src/proofgen.rs:380-399): out[out_off + x] = sum_{i<r} S[s_off + x*r + i] * c[c_off + i] */
+int lab_amortize_z(lab_ctx *ctx, lab_vec *out, size_t out_off, const lab_vec *S, size_t s_off, size_t n, size_t r,
+                   const lab_vec *c, size_t c_off);
+
+/* Element-wise ring ops on hat vectors: Rq Mul / Add / Sub (src/algebraic.rs:441-531), add_poly_vec (src/util.rs:298-309) */
+typedef enum { LAB_OP_MUL = 0, LAB_OP_ADD = 1, LAB_OP_SUB = 2 } lab_op;
+int lab_pointwise(lab_ctx *ctx, lab_op op, lab_vec *out, size_t out_off, const lab_vec *a, size_t a_off,
+                  const lab_vec *b, size_t b_off, size_t count);
+/* poly_by_poly_vec (src/util.rs:289-296): out[k] = p * v[k] */
+int lab_poly_by_poly_vec(lab_ctx *ctx, lab_vec *out, size_t out_off, const lab_vec *p, size_t p_off,
+                         const lab_vec *v, size_t v_off, size_t len);
+
+/* ---- coefficient-domain helpers (u64 residues mod q, host or device pointers) ---- */
+
+/* decompose_polynomial_vec, bug-compatible with src/util.rs:360-442 (non-negative digits, sign of the centred
+ * representative lost, digits beyond `exp` dropped).  coeffs [count][64] -> out [exp][count][64]. */
+int lab_decompose(lab_ctx *ctx, uint64_t *out, const uint64_t *coeffs, size_t count, int64_t base, int exp);
+/* poly_norm (src/util.rs:195-202): exact sum of squares of the raw residues of each polynomial as a 128-bit
+ * integer norm = hi[k]*2^64 + lo[k]; the caller casts to f64 and folds in index order like
+ * vec_poly_norm_squared (src/util.rs:188-192). */
+int lab_norm_sq(lab_ctx *ctx, const uint64_t *coeffs, size_t count, uint64_t *lo, uint64_t *hi);
+/* scale_poly_vec (src/util.rs:167-180): out[k] = s * v[k] mod q */
+int lab_scale(lab_ctx *ctx, uint64_t *out, const uint64_t *coeffs, size_t count, uint64_t s);
+/* sigma_inv_vec (src/util.rs:107-137) */
+int lab_sigma_inv(lab_ctx *ctx, uint64_t *out, const uint64_t *coeffs, size_t count);
+/* Prover::jl_project's integer mat-vecs (src/proofgen.rs:429-456, src/util.rs:511-526):
+ *   proj[m] = sum_{i<r} sum_col Pi[i][m][col] * S[col/64][i][col%64]   over the integers (no reduction)
+ * Pi: int8 [r][256][n*64], S: witness coefficients [n][r][64], proj: int64[256] (|proj| < r*n*64*q < 2^63). */
+int lab_jl_project(lab_ctx *ctx, int64_t *proj, const int8_t *Pi, const uint64_t *S, size_t n, size_t r);
+
+/* ---- Prover::proof_gen as one deterministic call (src/proofgen.rs:30-427) ----
+ * The verifier's interactive randomness (src/verification.rs:441-513, 553-566) is supplied as a challenge tape and
+ * the CRS rows (regenerated from a ChaCha20 seed on every fetch in the reference, src/structs.rs:55-171) as
+ * resident transform-domain matrices.  kappa, kappa1, kappa2 are explicit (the reference hard-wires all three to
+ * n*64, src/constants.rs:237-239).  Pair index of (i<=j): i*r - i(i-1)/2 + (j-i) (src/structs.rs:101-106). */
+typedef struct {
+  size_t n, r, kappa, kappa1, kappa2;
+  int64_t b1, b2;          /* RuntimeConstants::B_1, B_2 (src/constants.rs:245,247) */
+  int t1, t2;              /* RuntimeConstants::T_1, T_2 (src/constants.rs:244,246) */
+  int64_t beta_bound;      /* RuntimeConstants::BETA_BOUND (src/constants.rs:241) */
+  const uint64_t *S;       /* witness            [n][r][64]  (src/proofgen.rs:16)        */
+  const uint64_t *phi;     /* st.phi_k[0]        [n][r][64]  (src/structs.rs:278)        */
+  const uint64_t *a;       /* st.a_prime_k[0]    [r][r][64]  (src/structs.rs:284)        */
+  uint64_t b_prime;        /* st.b_prime_k[0]                (src/structs.rs:285,373)    */
+  const lab_vec *A;  size_t a_off;   /* [kappa][n]              fetch_A_row    (src/structs.rs:55-72)   */
+  const lab_vec *B;  size_t b_off;   /* [r*t1][kappa1][kappa]   fetch_B_ik_row (src/structs.rs:74-88)   */
+  const lab_vec *C;  size_t c_off;   /* [pairs*t2][kappa2]      fetch_C_ijk    (src/structs.rs:90-114)  */
+  const lab_vec *Dm; size_t d_off;   /* [pairs*t1][kappa2]      fetch_D_ijk    (src/structs.rs:116-144) */
+  const int8_t *Pi;        /* [r][256][n*64] in {-1,0,1}  sample_jl_projection (src/verification.rs:553-566) */
+  uint64_t psi;            /* generate_psi, L = 1          (src/verification.rs:491-501) */
+  const uint64_t *omega;   /* [256] generate_omega         (src/verification.rs:503-513) */
+  const uint64_t *alpha;   /* [64]  fetch_alpha, K = 1     (src/verification.rs:441-447) */
+  const uint64_t *beta;    /* [64]  fetch_beta             (src/verification.rs:449-456) */
+  const uint64_t *c;       /* [r][64] fetch_challenge      (src/verification.rs:460-489) */
+} lab_prove_input;
+
+/* The computed fields of `Transcript` (src/structs.rs:192-209); pi_i_all, psi, omega, alpha, beta, c are the tape.
+ * All buffers are caller-allocated (host or device); any pointer may be NULL to skip that copy-out. */
+typedef struct {
+  uint64_t *u_1;            /* [kappa1][64] */
+  int64_t *projection_int;  /* [256] integers before Zq::lift (src/proofgen.rs:163) */
+  uint64_t *projection;     /* [256] (src/proofgen.rs:186) */
+  uint64_t *b_prime_prime;  /* [64]  */
+  uint64_t *u_2;            /* [kappa2][64] */
+  uint64_t *z;              /* [n][64] */
+  uint64_t *t_i_all;        /* [r][kappa][64] */
+  uint64_t *g_mat;          /* [r][r][64] */
+  uint64_t *h_mat;          /* [r][r][64] */
+} lab_transcript;
+
+/* Returns LAB_OK, LAB_ERR_JL_REJECTED when Verifier::valid_projection would reject this Pi (the reference then
+ * resamples up to 5 times, src/proofgen.rs:169-181 — the caller does that with a fresh tape), or
+ * LAB_ERR_BPP_CHECK when verify_b_prime_prime's assertion would fire (src/verification.rs:550). */
+int lab_prove_core(lab_ctx *ctx, const lab_prove_input *in, lab_transcript *out);
+
 #ifdef __cplusplus
 }
 #endif

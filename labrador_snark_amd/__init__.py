@@ -3,5 +3,8 @@
 HIP kernels for gfx950 behind the C ABI in include/labrador_hip.h; this package
 is the thin host-side mirror of the reference's interface for that path.
 """
-from ._lib import (LabradorError, LengthMismatch, NoDeviceError, SO_PATH, load)  # noqa: F401
-from .api import (Context, HatVec, D, matvec_sum, polynomial_vec_inner_product)  # noqa: F401
+from ._lib import (BppCheckFailed, JLRejected, LabradorError, LengthMismatch, NoDeviceError, SO_PATH,  # noqa: F401
+                   load)
+from .api import *  # noqa: F401,F403
+from .api import Context, HatVec, D  # noqa: F401
+from .prover import Prover, ResidentCRS, RuntimeConstants, State, Transcript, prove_core  # noqa: F401

@@ -41,6 +41,30 @@ class LengthMismatch(LabradorError, AssertionError):
     """The reference's `assert!(v1.len() == v2.len(), ...)` panic (src/util.rs:497-502)."""
 
 
+class JLRejected(LabradorError):
+    """Verifier::valid_projection returned false (src/verification.rs:568-579); the reference resamples Pi."""
+
+
+class BppCheckFailed(LabradorError, AssertionError):
+    """verify_b_prime_prime's assert! fired (src/verification.rs:550)."""
+
+
+class lab_prove_input(C.Structure):
+    _fields_ = [("n", C.c_size_t), ("r", C.c_size_t), ("kappa", C.c_size_t), ("kappa1", C.c_size_t),
+                ("kappa2", C.c_size_t), ("b1", C.c_int64), ("b2", C.c_int64), ("t1", C.c_int), ("t2", C.c_int),
+                ("beta_bound", C.c_int64), ("S", C.c_void_p), ("phi", C.c_void_p), ("a", C.c_void_p),
+                ("b_prime", C.c_uint64), ("A", C.c_void_p), ("a_off", C.c_size_t), ("B", C.c_void_p),
+                ("b_off", C.c_size_t), ("C", C.c_void_p), ("c_off", C.c_size_t), ("Dm", C.c_void_p),
+                ("d_off", C.c_size_t), ("Pi", C.c_void_p), ("psi", C.c_uint64), ("omega", C.c_void_p),
+                ("alpha", C.c_void_p), ("beta", C.c_void_p), ("c", C.c_void_p)]
+
+
+class lab_transcript(C.Structure):
+    _fields_ = [("u_1", C.c_void_p), ("projection_int", C.c_void_p), ("projection", C.c_void_p),
+                ("b_prime_prime", C.c_void_p), ("u_2", C.c_void_p), ("z", C.c_void_p), ("t_i_all", C.c_void_p),
+                ("g_mat", C.c_void_p), ("h_mat", C.c_void_p)]
+
+
 class lab_info(C.Structure):
     _fields_ = [("q", C.c_uint64), ("nlimbs", C.c_int), ("primes", C.c_uint32 * 4), ("max_len", C.c_uint64),
                 ("device", C.c_int)]
@@ -68,6 +92,24 @@ SIGNATURES = {
                                     C.c_size_t, C.c_size_t]),
     "lab_matvec_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
                                  C.c_size_t, C.c_void_p, C.c_size_t]),
+    "lab_ajtai_commit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
+                                   C.c_void_p, C.c_size_t, C.c_size_t]),
+    "lab_gram": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                           C.c_size_t, C.c_size_t]),
+    "lab_axpy_commit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                  C.c_size_t, C.c_size_t]),
+    "lab_amortize_z": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
+                                 C.c_void_p, C.c_size_t]),
+    "lab_pointwise": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                C.c_size_t, C.c_size_t]),
+    "lab_poly_by_poly_vec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                       C.c_size_t, C.c_size_t]),
+    "lab_decompose": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int]),
+    "lab_norm_sq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "lab_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64]),
+    "lab_sigma_inv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "lab_jl_project": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
+    "lab_prove_core": (C.c_int, [C.c_void_p, C.POINTER(lab_prove_input), C.POINTER(lab_transcript)]),
 }
 
 _lib = None
@@ -107,4 +149,8 @@ def check(ctx_handle, rc):
         raise NoDeviceError(rc, "no usable GPU; the product path has no CPU fallback")
     if rc == LAB_ERR_LEN_MISMATCH:
         raise LengthMismatch(rc, msg or "inner product not defined on vectors of unequal length")
+    if rc == LAB_ERR_JL_REJECTED:
+        raise JLRejected(rc, msg)
+    if rc == LAB_ERR_BPP_CHECK:
+        raise BppCheckFailed(rc, msg)
     raise LabradorError(rc, msg)

@@ -184,3 +184,126 @@ def matvec_sum(ctx, M, V, nmat, rows, cols, m_off=0, v_off=0, out=None, out_off=
         out = HatVec(ctx, rows)
     ctx._check(ctx._lib.lab_matvec_sum(ctx._h, out._h, out_off, M._h, m_off, nmat, rows, cols, V._h, v_off))
     return out
+
+
+def ajtai_commit(ctx, A, S, rows, inner, ncols, a_off=0, s_off=0, out=None, out_off=0):
+    """t_i_all[i][rho] = <A[rho,:], s_i> for every witness column (src/proofgen.rs:41-49). out: [ncols][rows]."""
+    if out is None:
+        out = HatVec(ctx, rows * ncols)
+    ctx._check(ctx._lib.lab_ajtai_commit(ctx._h, out._h, out_off, A._h, a_off, rows, inner, S._h, s_off, ncols))
+    return out
+
+
+def gram(ctx, P, S, n, r, p_off=0, s_off=0, out=None, out_off=0):
+    """out[i][k] = sum_x P[x][i] * S[x][k] (src/proofgen.rs:59-70, 334-335)."""
+    if out is None:
+        out = HatVec(ctx, r * r)
+    ctx._check(ctx._lib.lab_gram(ctx._h, out._h, out_off, P._h, p_off, S._h, s_off, n, r))
+    return out
+
+
+def axpy_commit(ctx, G, Cm, nterms, length, g_off=0, c_off=0, out=None, out_off=0):
+    """out[rho] = sum_m G[m] * C[m][rho] (src/proofgen.rs:137-148, 364-378)."""
+    if out is None:
+        out = HatVec(ctx, length)
+    ctx._check(ctx._lib.lab_axpy_commit(ctx._h, out._h, out_off, G._h, g_off, Cm._h, c_off, nterms, length))
+    return out
+
+
+def amortize_z(ctx, S, c, n, r, s_off=0, c_off=0, out=None, out_off=0):
+    """z = sum_i c_i s_i (src/proofgen.rs:380-399)."""
+    if out is None:
+        out = HatVec(ctx, n)
+    ctx._check(ctx._lib.lab_amortize_z(ctx._h, out._h, out_off, S._h, s_off, n, r, c._h, c_off))
+    return out
+
+
+_OPS = {"mul": 0, "add": 1, "sub": 2}
+
+
+def pointwise(ctx, op, a, b, count=None, a_off=0, b_off=0, out=None, out_off=0):
+    """Element-wise Rq Mul/Add/Sub (src/algebraic.rs:441-531); `add` is add_poly_vec (src/util.rs:298-309)."""
+    count = a.count - a_off if count is None else count
+    if out is None:
+        out = HatVec(ctx, count)
+    ctx._check(ctx._lib.lab_pointwise(ctx._h, _OPS[op], out._h, out_off, a._h, a_off, b._h, b_off, count))
+    return out
+
+
+def add_poly_vec(ctx, a, b):
+    if a.count != b.count:
+        raise _lib.LengthMismatch(_lib.LAB_ERR_LEN_MISMATCH, "summation not defined on vectors of unequal length")
+    return pointwise(ctx, "add", a, b)
+
+
+def poly_by_poly_vec(ctx, p, v, length=None, p_off=0, v_off=0, out=None, out_off=0):
+    """src/util.rs:289-296."""
+    length = v.count - v_off if length is None else length
+    if out is None:
+        out = HatVec(ctx, length)
+    ctx._check(ctx._lib.lab_poly_by_poly_vec(ctx._h, out._h, out_off, p._h, p_off, v._h, v_off, length))
+    return out
+
+
+def _like(a, shape):
+    if isinstance(a, np.ndarray):
+        return np.empty(shape, dtype=np.uint64)
+    import torch
+    return torch.empty(shape, dtype=a.dtype, device=a.device)
+
+
+def decompose_polynomial_vec(ctx, coeffs, base, exp):
+    """src/util.rs:360-442 (bug-compatible). coeffs [count][64] -> [exp][count][64]."""
+    coeffs = _as_u64(coeffs)
+    n = _nelems(coeffs)
+    out = _like(coeffs, (max(exp, 0), n, D))
+    ctx._check(ctx._lib.lab_decompose(ctx._h, _ptr(out), _ptr(coeffs), n, int(base), int(exp)))
+    return out
+
+
+def poly_norm_exact(ctx, coeffs):
+    """Exact squared norms (python ints) of each polynomial's raw residues (src/util.rs:195-202 before the f64 cast)."""
+    coeffs = _as_u64(coeffs)
+    n = _nelems(coeffs)
+    lo, hi = np.empty(n, dtype=np.uint64), np.empty(n, dtype=np.uint64)
+    ctx._check(ctx._lib.lab_norm_sq(ctx._h, _ptr(coeffs), n, _ptr(lo), _ptr(hi)))
+    return [(int(h) << 64) | int(l) for l, h in zip(lo, hi)]
+
+
+def poly_norm(ctx, p):
+    """src/util.rs:195-202: `norm as f64`."""
+    return float(poly_norm_exact(ctx, p)[0])
+
+
+def vec_poly_norm_squared(ctx, v):
+    """src/util.rs:188-192: sequential f64 sum of poly_norm, in index order."""
+    s = 0.0
+    for x in poly_norm_exact(ctx, v):
+        s += float(x)
+    return s
+
+
+def scale_poly_vec(ctx, coeffs, s):
+    """src/util.rs:167-180."""
+    coeffs = _as_u64(coeffs)
+    out = _like(coeffs, tuple(coeffs.shape))
+    ctx._check(ctx._lib.lab_scale(ctx._h, _ptr(out), _ptr(coeffs), _nelems(coeffs), int(s)))
+    return out
+
+
+def sigma_inv_vec(ctx, coeffs):
+    """src/util.rs:107-137."""
+    coeffs = _as_u64(coeffs)
+    out = _like(coeffs, tuple(coeffs.shape))
+    ctx._check(ctx._lib.lab_sigma_inv(ctx._h, _ptr(out), _ptr(coeffs), _nelems(coeffs)))
+    return out
+
+
+def jl_project(ctx, Pi, S, n, r):
+    """Integer projection of Prover::jl_project (src/proofgen.rs:429-456). Pi int8 [r][256][n*64]; S [n][r][64]."""
+    S = _as_u64(S)
+    if isinstance(Pi, np.ndarray):
+        Pi = np.ascontiguousarray(Pi, dtype=np.int8)
+    out = np.zeros(256, dtype=np.int64)
+    ctx._check(ctx._lib.lab_jl_project(ctx._h, _ptr(out), _ptr(Pi), _ptr(S), n, r))
+    return out

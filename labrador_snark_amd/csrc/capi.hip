@@ -331,11 +331,24 @@ extern "C" void lab_vec_destroy(lab_vec* v) {
 
 extern "C" size_t lab_vec_count(const lab_vec* v) { return v ? v->count : 0; }
 
-static int check_range(lab_ctx* c, const lab_vec* v, size_t off, size_t n, const char* what) {
+int lab::check_range(lab_ctx* c, const lab_vec* v, size_t off, size_t n, const char* what) {
   if (!v) return fail(c, LAB_ERR_ARG, "%s: null vector", what);
   if (v->ctx != c) return fail(c, LAB_ERR_ARG, "%s: vector belongs to another context", what);
   if (off > v->count || n > v->count - off)
     return fail(c, LAB_ERR_LEN_MISMATCH, "%s: range [%zu,%zu) exceeds vector of %zu elements", what, off, off + n, v->count);
+  return LAB_OK;
+}
+
+int lab::from_hat(lab_ctx* c, ConstHatView src, size_t count, uint32_t* tmp, uint64_t* dcoeffs) {
+  HatView t{tmp, count * D};
+  LAB_HIP(c, launch_ntt(false, src, t, count, c->nlimbs, c->d_tabs, 0, c->stream));
+  LAB_HIP(c, launch_crt_to_u64(t, dcoeffs, count, c->d_crt, c->stream));
+  return LAB_OK;
+}
+
+int lab::to_hat(lab_ctx* c, const uint64_t* dcoeffs, HatView dst, size_t count) {
+  LAB_HIP(c, launch_reduce_u64(dcoeffs, dst, count, c->nlimbs, c->d_tabs, c->stream));
+  LAB_HIP(c, launch_ntt(true, dst, dst, count, c->nlimbs, c->d_tabs, 0, c->stream));
   return LAB_OK;
 }
 
@@ -431,7 +444,219 @@ extern "C" int lab_matvec_sum(lab_ctx* c, lab_vec* out, size_t out_off, const la
   return LAB_OK;
 }
 
+namespace lab {
+// number of equal chunks a long inner product is cut into (a single block would otherwise stream it alone)
+size_t inner_product_splits(size_t len) {
+  size_t k = 1;
+  while (k < 512 && len % (2 * k) == 0 && len / (2 * k) >= 64) k *= 2;
+  return k;
+}
+// out[0] = <v1, v2>; `partial` must hold inner_product_splits(len) elements
+int inner_product_impl(lab_ctx* c, HatView out, ConstHatView v1, ConstHatView v2, size_t len, HatView partial) {
+  const size_t k = inner_product_splits(len);
+  if (k == 1) {
+    LAB_HIP(c, launch_matvec_partial(out, v1, v2, 1, 1, len, c->nlimbs, c->d_tabs, c->stream));
+    return LAB_OK;
+  }
+  LAB_HIP(c, launch_matvec_partial(partial, v1, v2, k, 1, len / k, c->nlimbs, c->d_tabs, c->stream));
+  LAB_HIP(c, launch_sum_terms(out, partial, k, 1, c->nlimbs, c->d_tabs, c->stream));
+  return LAB_OK;
+}
+}  // namespace lab
+
 extern "C" int lab_inner_product(lab_ctx* c, lab_vec* out, size_t out_off, const lab_vec* v1, size_t off1,
                                  const lab_vec* v2, size_t off2, size_t len) {
-  return lab_matvec_sum(c, out, out_off, v1, off1, 1, 1, len, v2, off2);
+  if (!c) return LAB_ERR_ARG;
+  int rc;
+  if ((rc = check_range(c, out, out_off, 1, "lab_inner_product(out)"))) return rc;
+  if ((rc = check_range(c, v1, off1, len, "lab_inner_product(v1)"))) return rc;
+  if ((rc = check_range(c, v2, off2, len, "lab_inner_product(v2)"))) return rc;
+  if (len == 0) return fail(c, LAB_ERR_ARG, "lab_inner_product: empty vectors");
+  if (len > c->max_len) return fail(c, LAB_ERR_RANGE, "lab_inner_product: length %zu exceeds the exactness bound %llu of this context", len, (unsigned long long)c->max_len);
+  if (len > 0x7fffffffu / 64) return fail(c, LAB_ERR_ARG, "lab_inner_product: length too large");
+  LAB_HIP(c, hipSetDevice(c->device));
+  const size_t k = inner_product_splits(len);
+  if ((rc = ensure_scratch(c, (size_t)c->nlimbs * k * D * 4))) return rc;
+  return inner_product_impl(c, out->view(out_off), v1->view(off1), v2->view(off2), len, HatView{static_cast<uint32_t*>(c->scratch), k * D});
+}
+
+// ------------------------------------------------------------- remaining hat-domain ops
+extern "C" int lab_ajtai_commit(lab_ctx* c, lab_vec* out, size_t out_off, const lab_vec* A, size_t a_off, size_t rows,
+                                size_t inner, const lab_vec* S, size_t s_off, size_t ncols) {
+  if (!c) return LAB_ERR_ARG;
+  int rc;
+  if (rows == 0 || inner == 0 || ncols == 0) return fail(c, LAB_ERR_ARG, "lab_ajtai_commit: empty dimension");
+  if (rows > 0x7fffffffu || inner > 0x1ffffffu || ncols > 0xffffffu) return fail(c, LAB_ERR_ARG, "lab_ajtai_commit: dimension too large");
+  if ((rc = check_range(c, out, out_off, rows * ncols, "lab_ajtai_commit(out)"))) return rc;
+  if ((rc = check_range(c, A, a_off, rows * inner, "lab_ajtai_commit(A)"))) return rc;
+  if ((rc = check_range(c, S, s_off, inner * ncols, "lab_ajtai_commit(S)"))) return rc;
+  if (inner > c->max_len) return fail(c, LAB_ERR_RANGE, "lab_ajtai_commit: reduction length %zu exceeds the exactness bound %llu", inner, (unsigned long long)c->max_len);
+  LAB_HIP(c, hipSetDevice(c->device));
+  LAB_HIP(c, launch_matmul_t(out->view(out_off), A->view(a_off), S->view(s_off), rows, inner, ncols, c->nlimbs, c->d_tabs, c->stream));
+  return LAB_OK;
+}
+
+extern "C" int lab_gram(lab_ctx* c, lab_vec* out, size_t out_off, const lab_vec* P, size_t p_off, const lab_vec* S,
+                        size_t s_off, size_t n, size_t r) {
+  if (!c) return LAB_ERR_ARG;
+  int rc;
+  if (n == 0 || r == 0 || r > 65535 || n > 0x7fffffffu / 64) return fail(c, LAB_ERR_ARG, "lab_gram: bad dimension");
+  if ((rc = check_range(c, out, out_off, r * r, "lab_gram(out)"))) return rc;
+  if ((rc = check_range(c, P, p_off, n * r, "lab_gram(P)"))) return rc;
+  if ((rc = check_range(c, S, s_off, n * r, "lab_gram(S)"))) return rc;
+  if (n > c->max_len) return fail(c, LAB_ERR_RANGE, "lab_gram: reduction length %zu exceeds the exactness bound %llu", n, (unsigned long long)c->max_len);
+  LAB_HIP(c, hipSetDevice(c->device));
+  LAB_HIP(c, launch_gram(out->view(out_off), P->view(p_off), S->view(s_off), n, r, c->nlimbs, c->d_tabs, c->stream));
+  return LAB_OK;
+}
+
+namespace lab {
+// shared by lab_axpy_commit and prove_core; `tmp_partial` must hold nlimbs * chunks * len * 64 u32
+int axpy_commit_impl(lab_ctx* c, HatView out, ConstHatView G, ConstHatView C, size_t nterms, size_t len, HatView partial) {
+  const size_t chunks = axpy_num_chunks(nterms);
+  if (chunks == 1) {
+    LAB_HIP(c, launch_axpy_partial(out, G, C, nterms, len, c->nlimbs, c->d_tabs, c->stream));
+    return LAB_OK;
+  }
+  LAB_HIP(c, launch_axpy_partial(partial, G, C, nterms, len, c->nlimbs, c->d_tabs, c->stream));
+  LAB_HIP(c, launch_sum_terms(out, partial, chunks, len, c->nlimbs, c->d_tabs, c->stream));
+  return LAB_OK;
+}
+}  // namespace lab
+
+extern "C" int lab_axpy_commit(lab_ctx* c, lab_vec* out, size_t out_off, const lab_vec* G, size_t g_off,
+                               const lab_vec* Cm, size_t c_off, size_t nterms, size_t len) {
+  if (!c) return LAB_ERR_ARG;
+  int rc;
+  if (nterms == 0 || len == 0 || len > 0x7fffffffu / 64 || nterms > 0x3fffffu) return fail(c, LAB_ERR_ARG, "lab_axpy_commit: bad dimension");
+  if ((rc = check_range(c, out, out_off, len, "lab_axpy_commit(out)"))) return rc;
+  if ((rc = check_range(c, G, g_off, nterms, "lab_axpy_commit(G)"))) return rc;
+  if ((rc = check_range(c, Cm, c_off, nterms * len, "lab_axpy_commit(C)"))) return rc;
+  if (nterms > c->max_len) return fail(c, LAB_ERR_RANGE, "lab_axpy_commit: %zu terms exceed the exactness bound %llu", nterms, (unsigned long long)c->max_len);
+  LAB_HIP(c, hipSetDevice(c->device));
+  const size_t chunks = axpy_num_chunks(nterms);
+  if ((rc = ensure_scratch(c, (size_t)c->nlimbs * chunks * len * D * 4))) return rc;
+  return axpy_commit_impl(c, out->view(out_off), G->view(g_off), Cm->view(c_off), nterms, len,
+                          HatView{static_cast<uint32_t*>(c->scratch), chunks * len * D});
+}
+
+extern "C" int lab_amortize_z(lab_ctx* c, lab_vec* out, size_t out_off, const lab_vec* S, size_t s_off, size_t n,
+                              size_t r, const lab_vec* cv, size_t c_off) {
+  // z[x] = <S[x,:], c>: a mat-vec with rows = n, cols = r (src/proofgen.rs:387-399)
+  return lab_matvec_sum(c, out, out_off, S, s_off, 1, n, r, cv, c_off);
+}
+
+extern "C" int lab_pointwise(lab_ctx* c, lab_op op, lab_vec* out, size_t out_off, const lab_vec* a, size_t a_off,
+                             const lab_vec* b, size_t b_off, size_t count) {
+  if (!c) return LAB_ERR_ARG;
+  int rc;
+  if ((rc = check_range(c, out, out_off, count, "lab_pointwise(out)"))) return rc;
+  if ((rc = check_range(c, a, a_off, count, "lab_pointwise(a)"))) return rc;
+  if ((rc = check_range(c, b, b_off, count, "lab_pointwise(b)"))) return rc;
+  PointwiseOp k;
+  switch (op) {
+    case LAB_OP_MUL: k = PW_MUL; break;
+    case LAB_OP_ADD: k = PW_ADD; break;
+    case LAB_OP_SUB: k = PW_SUB; break;
+    default: return fail(c, LAB_ERR_ARG, "lab_pointwise: unknown op %d", (int)op);
+  }
+  LAB_HIP(c, hipSetDevice(c->device));
+  LAB_HIP(c, launch_pointwise(k, out->view(out_off), a->view(a_off), b->view(b_off), count, c->nlimbs, c->d_tabs, c->stream));
+  return LAB_OK;
+}
+
+extern "C" int lab_poly_by_poly_vec(lab_ctx* c, lab_vec* out, size_t out_off, const lab_vec* p, size_t p_off,
+                                    const lab_vec* v, size_t v_off, size_t len) {
+  if (!c) return LAB_ERR_ARG;
+  int rc;
+  if ((rc = check_range(c, out, out_off, len, "lab_poly_by_poly_vec(out)"))) return rc;
+  if ((rc = check_range(c, p, p_off, 1, "lab_poly_by_poly_vec(p)"))) return rc;
+  if ((rc = check_range(c, v, v_off, len, "lab_poly_by_poly_vec(v)"))) return rc;
+  LAB_HIP(c, hipSetDevice(c->device));
+  LAB_HIP(c, launch_poly_by_vec(out->view(out_off), p->view(p_off), v->view(v_off), len, c->nlimbs, c->d_tabs, c->stream));
+  return LAB_OK;
+}
+
+// ------------------------------------------------------------- coefficient-domain ops
+extern "C" int lab_decompose(lab_ctx* c, uint64_t* out, const uint64_t* coeffs, size_t count, int64_t base, int exp) {
+  if (!c) return LAB_ERR_ARG;
+  if (base < 2) return fail(c, LAB_ERR_DECOMPOSE, "lab_decompose: base %lld < 2 never terminates in the reference (src/util.rs:410-417)", (long long)base);
+  if (exp < 0 || exp > 64) return fail(c, LAB_ERR_DECOMPOSE, "lab_decompose: exp %d out of range", exp);
+  if (count == 0 || exp == 0) return LAB_OK;
+  if (!out || !coeffs) return fail(c, LAB_ERR_ARG, "lab_decompose: null argument");
+  LAB_HIP(c, hipSetDevice(c->device));
+  const size_t nin = count * D, nout = nin * (size_t)exp;
+  int rc = ensure_scratch(c, Staging::need(coeffs, nin * 8) + Staging::need(out, nout * 8));
+  if (rc) return rc;
+  Carver cv(c->scratch);
+  Staging st(c, &cv);
+  const uint64_t* din;
+  if ((rc = st.in(coeffs, nin, &din))) return rc;
+  uint64_t* dout = st.out(out, nout);
+  LAB_HIP(c, launch_decompose(dout, din, count, c->q, (uint64_t)base, exp, count, c->stream));
+  return st.finish();
+}
+
+extern "C" int lab_norm_sq(lab_ctx* c, const uint64_t* coeffs, size_t count, uint64_t* lo, uint64_t* hi) {
+  if (!c) return LAB_ERR_ARG;
+  if (count == 0) return LAB_OK;
+  if (!coeffs || !lo || !hi) return fail(c, LAB_ERR_ARG, "lab_norm_sq: null argument");
+  LAB_HIP(c, hipSetDevice(c->device));
+  int rc = ensure_scratch(c, Staging::need(coeffs, count * D * 8) + Staging::need(lo, count * 8) + Staging::need(hi, count * 8));
+  if (rc) return rc;
+  Carver cv(c->scratch);
+  Staging st(c, &cv);
+  const uint64_t* din;
+  if ((rc = st.in(coeffs, count * D, &din))) return rc;
+  uint64_t* dlo = st.out(lo, count);
+  uint64_t* dhi = st.out(hi, count);
+  LAB_HIP(c, launch_norm_sq(dlo, dhi, din, count, c->stream));
+  return st.finish();
+}
+
+static int coef_unary(lab_ctx* c, uint64_t* out, const uint64_t* coeffs, size_t count, uint64_t s, int mode, const char* what) {
+  if (!c) return LAB_ERR_ARG;
+  if (count == 0) return LAB_OK;
+  if (!out || !coeffs) return fail(c, LAB_ERR_ARG, "%s: null argument", what);
+  LAB_HIP(c, hipSetDevice(c->device));
+  const size_t nw = count * D;
+  int rc = ensure_scratch(c, Staging::need(coeffs, nw * 8) + Staging::need(out, nw * 8));
+  if (rc) return rc;
+  Carver cv(c->scratch);
+  Staging st(c, &cv);
+  const uint64_t* din;
+  if ((rc = st.in(coeffs, nw, &din))) return rc;
+  uint64_t* dout = st.out(out, nw);
+  if (mode == 3 && dout == din) return fail(c, LAB_ERR_ARG, "%s: in-place operation not supported", what);
+  LAB_HIP(c, launch_coef_elementwise(dout, din, nullptr, count, c->q, s % c->q, mode, c->stream));
+  return st.finish();
+}
+
+extern "C" int lab_scale(lab_ctx* c, uint64_t* out, const uint64_t* coeffs, size_t count, uint64_t s) {
+  return coef_unary(c, out, coeffs, count, s, 0, "lab_scale");
+}
+extern "C" int lab_sigma_inv(lab_ctx* c, uint64_t* out, const uint64_t* coeffs, size_t count) {
+  return coef_unary(c, out, coeffs, count, 0, 3, "lab_sigma_inv");
+}
+
+extern "C" int lab_jl_project(lab_ctx* c, int64_t* proj, const int8_t* Pi, const uint64_t* S, size_t n, size_t r) {
+  if (!c) return LAB_ERR_ARG;
+  if (!proj || !Pi || !S || n == 0 || r == 0) return fail(c, LAB_ERR_ARG, "lab_jl_project: bad argument");
+  if (r > 65535 || n > (1u << 24)) return fail(c, LAB_ERR_ARG, "lab_jl_project: dimension too large");
+  // |proj| <= r*n*64*(q-1) must fit int64
+  if ((u128)r * n * D * (c->q - 1) >= ((u128)1 << 63)) return fail(c, LAB_ERR_RANGE, "lab_jl_project: projection does not fit 64 bits");
+  LAB_HIP(c, hipSetDevice(c->device));
+  const size_t npi = r * 256 * n * D, ns = n * r * D;
+  int rc = ensure_scratch(c, Staging::need(Pi, npi) + Staging::need(S, ns * 8) + Staging::need(proj, 256 * 8));
+  if (rc) return rc;
+  Carver cv(c->scratch);
+  Staging st(c, &cv);
+  const int8_t* dpi;
+  const uint64_t* ds;
+  if ((rc = st.in(Pi, npi, &dpi))) return rc;
+  if ((rc = st.in(S, ns, &ds))) return rc;
+  int64_t* dproj = st.out(proj, 256);
+  LAB_HIP(c, hipMemsetAsync(dproj, 0, 256 * 8, c->stream));
+  LAB_HIP(c, launch_jl_project(dproj, dpi, ds, n, r, c->stream));
+  return st.finish();
 }

@@ -62,3 +62,47 @@ struct Carver {
 };
 
 }  // namespace lab
+
+namespace lab {
+
+// Host/device staging for boundary pointers.  Usage: sum need() over all
+// pointers (+ temporaries), ensure_scratch, then in()/out() carve and copy, and
+// finish() copies results back (synchronising only if something went to the host).
+struct Staging {
+  lab_ctx* c;
+  Carver* cv;
+  struct Pending { void* host; const void* dev; size_t bytes; };
+  Pending pend[16];
+  int npend = 0;
+  Staging(lab_ctx* ctx, Carver* carver) : c(ctx), cv(carver) {}
+  static size_t need(const void* p, size_t bytes) { return (p && !is_device_pointer(p)) ? Carver::padded(bytes) : 0; }
+  template <typename T>
+  int in(const T* p, size_t n, const T** dev) {
+    if (!p || is_device_pointer(p)) { *dev = p; return LAB_OK; }
+    T* slot = cv->take<T>(n);
+    LAB_HIP(c, hipMemcpyAsync(slot, p, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    *dev = slot;
+    return LAB_OK;
+  }
+  template <typename T>
+  T* out(T* p, size_t n) {
+    if (!p || is_device_pointer(p)) return p;
+    T* slot = cv->take<T>(n);
+    pend[npend++] = Pending{p, slot, n * sizeof(T)};
+    return slot;
+  }
+  int finish() {
+    if (!npend) return LAB_OK;
+    for (int i = 0; i < npend; i++)
+      LAB_HIP(c, hipMemcpyAsync(pend[i].host, pend[i].dev, pend[i].bytes, hipMemcpyDeviceToHost, c->stream));
+    LAB_HIP(c, hipStreamSynchronize(c->stream));
+    return LAB_OK;
+  }
+};
+
+int check_range(lab_ctx* c, const lab_vec* v, size_t off, size_t n, const char* what);
+// hat -> coefficient conversion of `count` elements of `src` into device memory `dcoeffs`, using `tmp` (>= count elements of hat scratch)
+int from_hat(lab_ctx* c, ConstHatView src, size_t count, uint32_t* tmp, uint64_t* dcoeffs);
+int to_hat(lab_ctx* c, const uint64_t* dcoeffs, HatView dst, size_t count);
+
+}  // namespace lab

@@ -59,5 +59,31 @@ hipError_t launch_matvec_partial(HatView partial, ConstHatView M, ConstHatView V
 hipError_t launch_sum_terms(HatView out, ConstHatView partial, size_t nterms, size_t rows, int nlimbs,
                             const LimbTable* tabs, hipStream_t s);
 const char* matvec_kernel_name();
+// out[i*rows + rho] = <A[rho,:], S[:,i]>   A: [rows][inner], S: [inner][ncols]
+hipError_t launch_matmul_t(HatView out, ConstHatView A, ConstHatView S, size_t rows, size_t inner, size_t ncols,
+                           int nlimbs, const LimbTable* tabs, hipStream_t s);
+// out[i*r + k] = sum_x P[x*r+i] * S[x*r+k]
+hipError_t launch_gram(HatView out, ConstHatView P, ConstHatView S, size_t n, size_t r, int nlimbs,
+                       const LimbTable* tabs, hipStream_t s);
+// partial[chunk*len + rho] = sum_{m in chunk} G[m] * C[m*len + rho]; axpy_num_chunks(nterms) chunks
+size_t axpy_num_chunks(size_t nterms);
+hipError_t launch_axpy_partial(HatView partial, ConstHatView G, ConstHatView C, size_t nterms, size_t len, int nlimbs,
+                               const LimbTable* tabs, hipStream_t s);
+hipError_t launch_poly_by_vec(HatView out, ConstHatView poly, ConstHatView v, size_t len, int nlimbs,
+                              const LimbTable* tabs, hipStream_t s);
+
+// ---- proof_kernels.hip (coefficient domain, residues mod q as u64)
+hipError_t launch_decompose(uint64_t* out, const uint64_t* in, size_t count, uint64_t q, uint64_t base, int exp,
+                            size_t group, hipStream_t s);
+hipError_t launch_gather_upper(uint64_t* out, const uint64_t* in, size_t r, hipStream_t s);
+hipError_t launch_lift_i64(uint64_t* out, const int64_t* in, size_t n, uint64_t q, hipStream_t s);
+hipError_t launch_norm_sq(uint64_t* lo, uint64_t* hi, const uint64_t* in, size_t count, hipStream_t s);
+// mode 0: s1*a ; 1: s1*a + b ; 2: a + b ; 3: sigma_inv(a)
+hipError_t launch_coef_elementwise(uint64_t* out, const uint64_t* a, const uint64_t* b, size_t count, uint64_t q,
+                                   uint64_t s1, int mode, hipStream_t s);
+hipError_t launch_symmetrize_half(uint64_t* H, const uint64_t* X, size_t r, uint64_t q, uint64_t inv2, hipStream_t s);
+hipError_t launch_jl_project(int64_t* proj, const int8_t* Pi, const uint64_t* S, size_t n, size_t r, hipStream_t s);
+hipError_t launch_phi_pi_part(uint64_t* W, const int8_t* Pi, const uint64_t* omega, size_t n, size_t r, uint64_t q,
+                              hipStream_t s);
 
 }  // namespace lab

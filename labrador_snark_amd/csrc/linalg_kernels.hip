@@ -226,3 +226,211 @@ hipError_t launch_sum_terms(HatView out, ConstHatView partial, size_t nterms, si
 }
 
 }  // namespace lab
+
+namespace lab {
+
+// ------------------------------------------------ multi right-hand-side commitment
+// out[i][rho][j] = sum_x A[rho][x][j] * S[x][i][j]        (inner Ajtai commitment,
+// src/proofgen.rs:41-49: t_i = A s_i for all i < r at once).
+// Per NTT slot this is a (rows x inner)(inner x ncols) product; with ncols = 32
+// it is VALU-bound (32 multiply-adds per 4 bytes of A), so the tile is shaped
+// for register reuse: a lane owns one slot j, MM_RT rows and MM_CT columns
+// (MM_RT*MM_CT 64-bit accumulators); wave w of the block owns columns
+// MM_CT*w..; A values are shared by the block's waves through L1, S by all
+// blocks through L2.
+constexpr int MM_RT = 4;
+constexpr int MM_CT = 8;
+
+__global__ void __launch_bounds__(1024)
+k_matmul_t(uint32_t* __restrict__ out, size_t out_ps, const uint32_t* __restrict__ A, size_t a_ps,
+           const uint32_t* __restrict__ S, size_t s_ps, unsigned rows, unsigned inner, unsigned ncols,
+           const LimbTable* __restrict__ tabs) {
+  const int limb = blockIdx.z;
+  const uint32_t p = tabs[limb].p, p2 = tabs[limb].p2, pinv = tabs[limb].pinv, r2 = tabs[limb].r2;
+  const int j = threadIdx.x;                               // slot
+  const unsigned col0 = (blockIdx.y * blockDim.y + threadIdx.y) * MM_CT;
+  const unsigned row0 = blockIdx.x * MM_RT;
+  const uint32_t* Ap = A + (size_t)limb * a_ps;
+  const uint32_t* Sp = S + (size_t)limb * s_ps;
+  if (col0 >= ncols) return;
+
+  size_t arow[MM_RT];
+#pragma unroll
+  for (int r = 0; r < MM_RT; r++) arow[r] = (size_t)min(row0 + r, rows - 1) * inner * D + j;
+  unsigned scol[MM_CT];
+#pragma unroll
+  for (int c = 0; c < MM_CT; c++) scol[c] = min(col0 + c, ncols - 1) * D + j;
+
+  uint64_t acc[MM_RT][MM_CT];
+#pragma unroll
+  for (int r = 0; r < MM_RT; r++)
+#pragma unroll
+    for (int c = 0; c < MM_CT; c++) acc[r][c] = 0;
+
+  unsigned x = 0;
+  while (x < inner) {
+    const unsigned xe = min(x + 8, inner);
+    for (; x < xe; x++) {
+      uint32_t a[MM_RT], s[MM_CT];
+#pragma unroll
+      for (int r = 0; r < MM_RT; r++) a[r] = Ap[arow[r] + (size_t)x * D];
+#pragma unroll
+      for (int c = 0; c < MM_CT; c++) s[c] = Sp[(size_t)x * ncols * D + scol[c]];
+#pragma unroll
+      for (int r = 0; r < MM_RT; r++)
+#pragma unroll
+        for (int c = 0; c < MM_CT; c++) acc[r][c] += (uint64_t)a[r] * s[c];
+    }
+#pragma unroll
+    for (int r = 0; r < MM_RT; r++)
+#pragma unroll
+      for (int c = 0; c < MM_CT; c++) acc[r][c] = acc_fold(acc[r][c], p, p2);
+  }
+#pragma unroll
+  for (int r = 0; r < MM_RT; r++)
+#pragma unroll
+    for (int c = 0; c < MM_CT; c++) {
+      if (row0 + r < rows && col0 + c < ncols) {
+        uint32_t v = mont_mul(redc64(acc[r][c], p, pinv), r2, p, pinv);
+        out[(size_t)limb * out_ps + ((size_t)(col0 + c) * rows + row0 + r) * D + j] = v;
+      }
+    }
+}
+
+hipError_t launch_matmul_t(HatView out, ConstHatView A, ConstHatView S, size_t rows, size_t inner, size_t ncols,
+                           int nlimbs, const LimbTable* tabs, hipStream_t s) {
+  if (rows == 0 || ncols == 0) return hipSuccess;
+  unsigned col_groups = (unsigned)((ncols + MM_CT - 1) / MM_CT);
+  unsigned wy = col_groups < 16 ? col_groups : 16;
+  dim3 block(64, wy);
+  dim3 grid((unsigned)((rows + MM_RT - 1) / MM_RT), (col_groups + wy - 1) / wy, (unsigned)nlimbs);
+  hipLaunchKernelGGL(k_matmul_t, grid, block, 0, s, out.base, out.plane_stride, A.base, A.plane_stride, S.base,
+                     S.plane_stride, (unsigned)rows, (unsigned)inner, (unsigned)ncols, tabs);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------ Gram-type products
+// out[i][k][j] = sum_x P[x][i][j] * S[x][k][j]   for i,k < r   (P, S: [n][r][64])
+// G = S^T S (src/proofgen.rs:59-70) and the two inner products of every h_ij
+// (src/proofgen.rs:334-335).  One block per (i,k); 4 waves split x; lanes are slots.
+__global__ void __launch_bounds__(256)
+k_gram(uint32_t* __restrict__ out, size_t out_ps, const uint32_t* __restrict__ P, size_t p_ps,
+       const uint32_t* __restrict__ S, size_t s_ps, unsigned n, unsigned r, const LimbTable* __restrict__ tabs) {
+  __shared__ uint32_t red[4][D];
+  const int limb = blockIdx.z;
+  const uint32_t p = tabs[limb].p, p2 = tabs[limb].p2, pinv = tabs[limb].pinv, r2 = tabs[limb].r2;
+  const unsigned i = blockIdx.y, k = blockIdx.x;
+  const int j = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t* Pp = P + (size_t)limb * p_ps + (size_t)i * D + j;
+  const uint32_t* Sp = S + (size_t)limb * s_ps + (size_t)k * D + j;
+  const size_t xstride = (size_t)r * D;
+  uint64_t acc = 0;
+  unsigned x = wave;
+  while (x < n) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      if (x < n) acc += (uint64_t)Pp[x * xstride] * Sp[x * xstride];
+      x += 4;
+    }
+    acc = acc_fold(acc, p, p2);
+  }
+  red[wave][j] = redc64(acc, p, pinv);
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t v = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+    v = csub(csub(v, p2), p);
+    out[(size_t)limb * out_ps + ((size_t)i * r + k) * D + j] = mont_mul(v, r2, p, pinv);
+  }
+}
+
+hipError_t launch_gram(HatView out, ConstHatView P, ConstHatView S, size_t n, size_t r, int nlimbs,
+                       const LimbTable* tabs, hipStream_t s) {
+  if (r == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_gram, dim3((unsigned)r, (unsigned)r, (unsigned)nlimbs), dim3(256), 0, s, out.base,
+                     out.plane_stride, P.base, P.plane_stride, S.base, S.plane_stride, (unsigned)n, (unsigned)r, tabs);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------ sum of polynomial-times-vector terms
+// partial[chunk][rho][j] = sum_{m in chunk} G[m][j] * C[m][rho][j]
+// The C and D parts of the outer commitments (src/proofgen.rs:137-148, 364-378:
+// rhs += poly_by_poly_vec(g_ij^(k), C_ijk)).  C is streamed once; a wave
+// instruction covers 4 consecutive rho (1 KiB contiguous).
+constexpr int AX_CHUNK = 64;
+
+__global__ void __launch_bounds__(256)
+k_axpy_partial(uint32_t* __restrict__ partial, size_t partial_ps, const uint32_t* __restrict__ G, size_t g_ps,
+               const uint32_t* __restrict__ C, size_t c_ps, unsigned nterms, unsigned len,
+               const LimbTable* __restrict__ tabs) {
+  const int limb = blockIdx.z;
+  const uint32_t p = tabs[limb].p, p2 = tabs[limb].p2, pinv = tabs[limb].pinv, r2 = tabs[limb].r2;
+  const unsigned rho = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int jq = threadIdx.x & 15;
+  const unsigned m0 = blockIdx.y * AX_CHUNK, m1 = min(m0 + AX_CHUNK, nterms);
+  if (rho >= len) return;
+  const uint4* Gp = reinterpret_cast<const uint4*>(G + (size_t)limb * g_ps) + jq;
+  const uint4* Cp = reinterpret_cast<const uint4*>(C + (size_t)limb * c_ps) + (size_t)rho * 16 + jq;
+  uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  unsigned m = m0;
+  while (m < m1) {
+    const unsigned me = min(m + 8, m1);
+    for (; m < me; m++) {
+      const uint4 g = Gp[(size_t)m * 16];
+      const uint4 c = Cp[(size_t)m * len * 16];
+      a0 += (uint64_t)g.x * c.x; a1 += (uint64_t)g.y * c.y; a2 += (uint64_t)g.z * c.z; a3 += (uint64_t)g.w * c.w;
+    }
+    a0 = acc_fold(a0, p, p2); a1 = acc_fold(a1, p, p2); a2 = acc_fold(a2, p, p2); a3 = acc_fold(a3, p, p2);
+  }
+  uint4 o;
+  o.x = mont_mul(redc64(a0, p, pinv), r2, p, pinv);
+  o.y = mont_mul(redc64(a1, p, pinv), r2, p, pinv);
+  o.z = mont_mul(redc64(a2, p, pinv), r2, p, pinv);
+  o.w = mont_mul(redc64(a3, p, pinv), r2, p, pinv);
+  reinterpret_cast<uint4*>(partial + (size_t)limb * partial_ps)[((size_t)blockIdx.y * len + rho) * 16 + jq] = o;
+}
+
+size_t axpy_num_chunks(size_t nterms) { return (nterms + AX_CHUNK - 1) / AX_CHUNK; }
+
+hipError_t launch_axpy_partial(HatView partial, ConstHatView G, ConstHatView C, size_t nterms, size_t len, int nlimbs,
+                               const LimbTable* tabs, hipStream_t s) {
+  if (nterms == 0 || len == 0) return hipSuccess;
+  dim3 grid((unsigned)((len + 15) / 16), (unsigned)axpy_num_chunks(nterms), (unsigned)nlimbs);
+  hipLaunchKernelGGL(k_axpy_partial, grid, dim3(256), 0, s, partial.base, partial.plane_stride, G.base,
+                     G.plane_stride, C.base, C.plane_stride, (unsigned)nterms, (unsigned)len, tabs);
+  return hipGetLastError();
+}
+
+// out[k] = poly * v[k]  (poly_by_poly_vec, src/util.rs:289-296); plain products
+__global__ void __launch_bounds__(256)
+k_poly_by_vec(uint32_t* __restrict__ out, size_t out_ps, const uint32_t* __restrict__ poly, size_t poly_ps,
+              const uint32_t* __restrict__ v, size_t v_ps, size_t nquads, const LimbTable* __restrict__ tabs) {
+  const int limb = blockIdx.y;
+  const uint32_t p = tabs[limb].p, pinv = tabs[limb].pinv, r2 = tabs[limb].r2;
+  const uint4* Pq = reinterpret_cast<const uint4*>(poly + (size_t)limb * poly_ps);
+  const uint4* Vq = reinterpret_cast<const uint4*>(v + (size_t)limb * v_ps);
+  uint4* O = reinterpret_cast<uint4*>(out + (size_t)limb * out_ps);
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < nquads; i += stride) {
+    const uint4 a = Pq[i & 15], b = Vq[i];
+    uint4 r;
+    r.x = mont_mul(mont_mul(a.x, b.x, p, pinv), r2, p, pinv);
+    r.y = mont_mul(mont_mul(a.y, b.y, p, pinv), r2, p, pinv);
+    r.z = mont_mul(mont_mul(a.z, b.z, p, pinv), r2, p, pinv);
+    r.w = mont_mul(mont_mul(a.w, b.w, p, pinv), r2, p, pinv);
+    O[i] = r;
+  }
+}
+
+hipError_t launch_poly_by_vec(HatView out, ConstHatView poly, ConstHatView v, size_t len, int nlimbs,
+                              const LimbTable* tabs, hipStream_t s) {
+  if (len == 0) return hipSuccess;
+  size_t nquads = len * D / 4;
+  unsigned blocks = (unsigned)((nquads + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_poly_by_vec, dim3(blocks, (unsigned)nlimbs), dim3(256), 0, s, out.base, out.plane_stride,
+                     poly.base, poly.plane_stride, v.base, v.plane_stride, nquads, tabs);
+  return hipGetLastError();
+}
+
+}  // namespace lab

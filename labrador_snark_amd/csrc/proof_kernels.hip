@@ -1,0 +1,279 @@
+// proof_kernels.hip — coefficient-domain kernels of the prover: digit
+// decomposition, exact norm sums, the JL projection, the phi'' aggregation and
+// the small mod-q elementwise steps.  All integer; gfx950 only.
+//
+// These replace src/util.rs:107-223, 360-442, 511-526 and the loops of
+// src/proofgen.rs:227-255, 320-358, 429-456 of the reference.
+#include "kernels.h"
+
+namespace lab {
+
+// (a*b) mod q for a,b < q < 2^40 without 128-bit division: split b at bit 20.
+__device__ __forceinline__ uint64_t mulmod40(uint64_t a, uint64_t b, uint64_t q) {
+  uint64_t t = (a * (b >> 20)) % q;          // < 2^60
+  t = (t << 20) % q;
+  return (t + a * (b & 0xFFFFF)) % q;        // < 2^61
+}
+__device__ __forceinline__ uint64_t addmod(uint64_t a, uint64_t b, uint64_t q) { uint64_t s = a + b; return s >= q ? s - q : s; }
+__device__ __forceinline__ uint64_t submod(uint64_t a, uint64_t b, uint64_t q) { return a >= b ? a - b : a + q - b; }
+
+// ---- decompose_polynomial_vec, bug-compatible (src/util.rs:360-442):
+// per coefficient v: while v != 0 { r0 = v % b; r = r0 > b/2 ? (b - r0) % b : r0; push r; v = (v - r)/b }
+// digits are non-negative (the centred sign is lost), digits past `exp` dropped.
+// Output element (e, digit k) goes to index ((e/group)*exp + k)*group + e%group:
+// group = count gives the reference's [exp][count] layout, group = 1 gives
+// [count][exp], group = kappa gives [i][k][rho] for the t_i decomposition.
+__global__ void __launch_bounds__(256)
+k_decompose(uint64_t* __restrict__ out, const uint64_t* __restrict__ in, size_t nwords, uint64_t q, uint64_t base,
+            int exp, size_t group) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const uint64_t half = (base / 2) % q;  // `val > b/2` compares with mod_positive(b/2, Q) (algebraic.rs:293-297)
+  for (; i < nwords; i += stride) {
+    uint64_t v = in[i];
+    for (int k = 0; k < exp; k++) {
+      uint64_t r = 0;
+      if (v != 0) {
+        uint64_t r0 = (v % base) % q;
+        r = r0 > half ? ((base - r0) % base) % q : r0;
+        v = (submod(v, r, q) / base) % q;
+      }
+      const size_t e = i / D;
+      out[(((e / group) * exp + k) * group + e % group) * D + i % D] = r;
+    }
+  }
+}
+
+hipError_t launch_decompose(uint64_t* out, const uint64_t* in, size_t count, uint64_t q, uint64_t base, int exp,
+                            size_t group, hipStream_t s) {
+  if (count == 0 || exp == 0) return hipSuccess;
+  size_t nwords = count * D;
+  unsigned blocks = (unsigned)((nwords + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_decompose, dim3(blocks), dim3(256), 0, s, out, in, nwords, q, base, exp, group);
+  return hipGetLastError();
+}
+
+// ---- poly_norm (src/util.rs:195-202): exact sum of squares of the RAW residues
+// of each polynomial as a 128-bit integer (lo,hi).  One wave per polynomial, one
+// coefficient per lane, wave shuffle reduction with carry.
+__global__ void __launch_bounds__(256)
+k_norm_sq(uint64_t* __restrict__ lo, uint64_t* __restrict__ hi, const uint64_t* __restrict__ in, size_t count) {
+  const int lane = threadIdx.x & 63;
+  size_t poly = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const size_t stride = (size_t)gridDim.x * 4;
+  for (; poly < count; poly += stride) {
+    const uint64_t v = in[poly * D + lane];
+    uint64_t l = v * v, h = __umul64hi(v, v);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint64_t ol = __shfl_down(l, off), oh = __shfl_down(h, off);
+      const uint64_t nl = l + ol;
+      h = h + oh + (nl < l ? 1 : 0);
+      l = nl;
+    }
+    if (lane == 0) { lo[poly] = l; hi[poly] = h; }
+  }
+}
+
+hipError_t launch_norm_sq(uint64_t* lo, uint64_t* hi, const uint64_t* in, size_t count, hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  unsigned blocks = (unsigned)((count + 3) / 4);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_norm_sq, dim3(blocks), dim3(256), 0, s, lo, hi, in, count);
+  return hipGetLastError();
+}
+
+// ---- elementwise mod-q helpers on coefficient arrays
+// mode 0: out = s1*a                       (scale_polynomial, src/util.rs:176-180)
+// mode 1: out = s1*a + b                   (phi'' = psi*phi' + W, src/proofgen.rs:236-254)
+// mode 2: out = a + b
+// mode 3: out = sigma_inv(a) per polynomial (src/util.rs:118-137)
+__global__ void __launch_bounds__(256)
+k_coef_elementwise(uint64_t* __restrict__ out, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b,
+                   size_t nwords, uint64_t q, uint64_t s1, int mode) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < nwords; i += stride) {
+    uint64_t r;
+    if (mode == 0) r = mulmod40(a[i], s1, q);
+    else if (mode == 1) r = addmod(mulmod40(a[i], s1, q), b[i], q);
+    else if (mode == 2) r = addmod(a[i], b[i], q);
+    else {
+      const size_t poly = i / D, k = i % D;
+      const uint64_t src = a[poly * D + (k == 0 ? 0 : D - k)];
+      r = k == 0 ? src : (src == 0 ? 0 : q - src);
+    }
+    out[i] = r;
+  }
+}
+
+hipError_t launch_coef_elementwise(uint64_t* out, const uint64_t* a, const uint64_t* b, size_t count, uint64_t q,
+                                   uint64_t s1, int mode, hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  size_t nwords = count * D;
+  unsigned blocks = (unsigned)((nwords + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_coef_elementwise, dim3(blocks), dim3(256), 0, s, out, a, b, nwords, q, s1, mode);
+  return hipGetLastError();
+}
+
+// H[i][k] = inv2 * (X[i][k] + X[k][i])   (src/proofgen.rs:334-350), X: [r][r][64]
+__global__ void __launch_bounds__(256)
+k_symmetrize_half(uint64_t* __restrict__ H, const uint64_t* __restrict__ X, unsigned r, uint64_t q, uint64_t inv2) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)r * r * D;
+  if (i >= n) return;
+  const unsigned c = i % D, e = i / D, row = e / r, col = e % r;
+  const uint64_t s = addmod(X[i], X[((size_t)col * r + row) * D + c], q);
+  H[i] = mulmod40(s, inv2, q);
+}
+
+hipError_t launch_symmetrize_half(uint64_t* H, const uint64_t* X, size_t r, uint64_t q, uint64_t inv2, hipStream_t s) {
+  if (r == 0) return hipSuccess;
+  size_t n = r * r * D;
+  hipLaunchKernelGGL(k_symmetrize_half, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, H, X, (unsigned)r, q, inv2);
+  return hipGetLastError();
+}
+
+// upper triangle (i <= j) of an [r][r][64] array in pair order i*r - i(i-1)/2 + (j-i) (src/structs.rs:101-106)
+__global__ void __launch_bounds__(256)
+k_gather_upper(uint64_t* __restrict__ out, const uint64_t* __restrict__ in, unsigned r) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)r * r * D;
+  if (idx >= n) return;
+  const unsigned c = idx % D, e = idx / D, i = e / r, j = e % r;
+  if (j < i) return;
+  const size_t pair = (size_t)i * r - ((size_t)i * (i - 1)) / 2 + (j - i);
+  out[pair * D + c] = in[idx];
+}
+
+hipError_t launch_gather_upper(uint64_t* out, const uint64_t* in, size_t r, hipStream_t s) {
+  if (r == 0) return hipSuccess;
+  size_t n = r * r * D;
+  hipLaunchKernelGGL(k_gather_upper, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, in, (unsigned)r);
+  return hipGetLastError();
+}
+
+// proj[m] mod q (Zq::lift, src/proofgen.rs:186)
+__global__ void k_lift_i64(uint64_t* __restrict__ out, const int64_t* __restrict__ in, unsigned n, uint64_t q) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t v = in[i];
+  const uint64_t m = (uint64_t)(v < 0 ? -v : v) % q;
+  out[i] = v < 0 ? (m == 0 ? 0 : q - m) : m;
+}
+
+hipError_t launch_lift_i64(uint64_t* out, const int64_t* in, size_t n, uint64_t q, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_lift_i64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, in, (unsigned)n, q);
+  return hipGetLastError();
+}
+
+// ---- JL projection (src/proofgen.rs:429-456, src/util.rs:511-526):
+//   p[m] += sum_col Pi_i[m][col] * s_i[col]     over the integers, Pi in {-1,0,1}
+// Pi: int8 [r][256][cols]; S: coefficient form [n][r][64] (s_i[col] = S[col/64][i][col%64]).
+// HBM-bound on Pi.  A block owns 16 rows m of one i and a 4096-column chunk:
+// each thread keeps 16 witness coefficients in registers and reuses them for
+// the 16 rows (16 B of Pi per row per thread).  Row sums are reduced with wave
+// shuffles, then one 64-bit atomic per row per block (exact, order independent).
+constexpr int JL_ROWS = 16;
+constexpr int JL_COLS_PER_THREAD = 16;
+
+__global__ void __launch_bounds__(256)
+k_jl_project(unsigned long long* __restrict__ proj, const int8_t* __restrict__ Pi, const uint64_t* __restrict__ S,
+             unsigned n, unsigned r) {
+  __shared__ long long red[4][JL_ROWS];
+  const size_t cols = (size_t)n * D;
+  const unsigned i = blockIdx.z, m0 = blockIdx.y * JL_ROWS;
+  const size_t col0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * JL_COLS_PER_THREAD;
+  long long acc[JL_ROWS];
+#pragma unroll
+  for (int m = 0; m < JL_ROWS; m++) acc[m] = 0;
+  if (col0 < cols) {
+    // 16 consecutive columns lie inside one polynomial (16 | 64)
+    const uint64_t* sp = S + ((col0 / D) * r + i) * D + (col0 % D);
+    long long s[JL_COLS_PER_THREAD];
+#pragma unroll
+    for (int c = 0; c < JL_COLS_PER_THREAD; c += 2) {
+      const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(sp + c);
+      s[c] = (long long)v.x; s[c + 1] = (long long)v.y;
+    }
+    const int8_t* pp = Pi + ((size_t)i * 256 + m0) * cols + col0;
+#pragma unroll
+    for (int m = 0; m < JL_ROWS; m++) {
+      const uint4 w = *reinterpret_cast<const uint4*>(pp + (size_t)m * cols);
+      const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+      long long a = 0;
+#pragma unroll
+      for (int c = 0; c < JL_COLS_PER_THREAD; c++) {
+        const int8_t e = (int8_t)(ww[c >> 2] >> ((c & 3) * 8));
+        a += e > 0 ? s[c] : (e < 0 ? -s[c] : 0);
+      }
+      acc[m] = a;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int m = 0; m < JL_ROWS; m++) {
+    long long a = acc[m];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+    if (lane == 0) red[wave][m] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < JL_ROWS) {
+    const long long t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    atomicAdd(&proj[m0 + threadIdx.x], (unsigned long long)t);
+  }
+}
+
+hipError_t launch_jl_project(int64_t* proj /*[256], zeroed by caller*/, const int8_t* Pi, const uint64_t* S, size_t n,
+                             size_t r, hipStream_t s) {
+  if (n == 0 || r == 0) return hipSuccess;
+  const size_t cols = n * D;
+  dim3 grid((unsigned)((cols + 4095) / 4096), 256 / JL_ROWS, (unsigned)r);
+  hipLaunchKernelGGL(k_jl_project, grid, dim3(256), 0, s, reinterpret_cast<unsigned long long*>(proj), Pi, S,
+                     (unsigned)n, (unsigned)r);
+  return hipGetLastError();
+}
+
+// ---- the Pi part of phi'' (src/proofgen.rs:244-253):
+//   W[x][i] = sum_{m<256} omega[m] * sigma_inv( poly(Pi_i[m][64x .. 64x+63] lifted to Zq) )    (mod q)
+// With u[col] = sum_m omega[m]*Pi_i[m][col] this is W[x][i][0] = u[64x], W[x][i][64-k] = -u[64x+k].
+// Output layout [n][r][64] like phi'.  A thread owns one column; lanes run over
+// consecutive columns so every Pi row segment is read coalesced.
+__global__ void __launch_bounds__(256)
+k_phi_pi_part(uint64_t* __restrict__ W, const int8_t* __restrict__ Pi, const uint64_t* __restrict__ omega, unsigned n,
+              unsigned r, uint64_t q) {
+  __shared__ uint64_t om[256];
+  om[threadIdx.x] = omega[threadIdx.x];
+  __syncthreads();
+  const size_t cols = (size_t)n * D;
+  const unsigned i = blockIdx.y;
+  const size_t col = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (col >= cols) return;
+  const int8_t* pp = Pi + (size_t)i * 256 * cols + col;
+  uint64_t pos = 0, neg = 0;  // 256 terms below 2^40 each
+#pragma unroll 8
+  for (int m = 0; m < 256; m++) {
+    const int8_t e = pp[(size_t)m * cols];
+    pos += e > 0 ? om[m] : 0;
+    neg += e < 0 ? om[m] : 0;
+  }
+  const uint64_t u = submod(pos % q, neg % q, q);
+  const size_t x = col / D, k = col % D;
+  const uint64_t val = k == 0 ? u : (u == 0 ? 0 : q - u);
+  W[(x * r + i) * D + (k == 0 ? 0 : D - k)] = val;
+}
+
+hipError_t launch_phi_pi_part(uint64_t* W, const int8_t* Pi, const uint64_t* omega, size_t n, size_t r, uint64_t q,
+                              hipStream_t s) {
+  if (n == 0 || r == 0) return hipSuccess;
+  const size_t cols = n * D;
+  hipLaunchKernelGGL(k_phi_pi_part, dim3((unsigned)((cols + 255) / 256), (unsigned)r), dim3(256), 0, s, W, Pi, omega,
+                     (unsigned)n, (unsigned)r, q);
+  return hipGetLastError();
+}
+
+}  // namespace lab

@@ -1,0 +1,152 @@
+"""Host-side mirror of the reference's `Prover` (src/proofgen.rs:14-28) over lab_prove_core.
+
+`Prover(witness, verifier, constants).proof_gen(st, crs)` keeps the reference's
+call shape.  The verifier object supplies the interactive randomness through the
+same method names the reference calls (sample_jl_projection, valid_projection is
+evaluated inside the core, generate_psi, generate_omega, fetch_alpha, fetch_beta,
+fetch_challenge); the CRS object holds the four matrices resident on the GPU in
+the transform domain instead of regenerating rows from a ChaCha20 seed
+(src/structs.rs:55-171 — on-device expansion is a later row of SURVEY §8f).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .api import D, HatVec, _as_u64, _ptr
+
+
+class RuntimeConstants:
+    """src/constants.rs:205-264.  kappa/kappa1/kappa2 are explicit here (the reference hard-wires n*64)."""
+
+    def __init__(self, q, N, R, kappa=None, kappa1=None, kappa2=None):
+        import math
+        TAU = 71.0
+        Q = float(q)
+        self.N, self.R = N, R
+        self.KAPPA = N * D if kappa is None else kappa
+        self.KAPPA_1 = N * D if kappa1 is None else kappa1
+        self.KAPPA_2 = N * D if kappa2 is None else kappa2
+
+        def rround(x):  # f64::round — half away from zero
+            return math.floor(x + 0.5) if x >= 0 else -math.floor(-x + 0.5)
+
+        self.BETA_BOUND = int(math.floor(math.sqrt(30.0 / 128.0) * Q / 125.0))
+        self.STD = float(self.BETA_BOUND) / math.sqrt(float(R * N * D))
+        self.B = int(rround(math.sqrt(math.sqrt(12.0 * float(R) * TAU) * self.STD)))
+        self.T_1 = int(rround(math.log2(Q) / math.log2(float(self.B))))
+        self.B_1 = int(math.pow(Q, 1.0 / float(self.T_1)))
+        self.T_2 = int(rround(math.log2(math.sqrt(24.0 * float(N * D)) * self.STD ** 2) / math.log2(float(self.B))))
+        self.B_2 = int(rround(math.pow(math.sqrt(float(24 * N * D)) * self.STD ** 2, 1.0 / float(self.T_2))))
+        b1, b2, t1, t2, r = float(self.B_1), float(self.B_2), float(self.T_1), float(self.T_2), float(R)
+        self.GAMMA = float(self.BETA_BOUND ** 2) * TAU
+        self.GAMMA_1 = ((b1 * b1 * t1) / 12.0) * r * float(self.KAPPA) * float(D) + \
+            ((b2 * b2 * t2) / 12.0) * ((r * r + r) / 2.0) * float(D)
+        self.GAMMA_2 = ((b1 * b1 * t1) / 12.0) * ((r * r + r) / 2.0) * float(D)
+        self.BETA_PRIME = (2.0 / float(self.B) ** 2) * self.GAMMA + self.GAMMA_1 + self.GAMMA_2
+
+
+class ResidentCRS:
+    """A, B_ik, C_ijk, D_ijk as transform-domain device matrices (stand-in for CRS::fetch_*, src/structs.rs:55-144)."""
+
+    def __init__(self, ctx, constants):
+        k = constants
+        pairs = k.R * (k.R + 1) // 2
+        self.ctx, self.constants = ctx, k
+        self.A = HatVec(ctx, k.KAPPA * k.N)
+        self.B = HatVec(ctx, k.R * k.T_1 * k.KAPPA_1 * k.KAPPA)
+        self.C = HatVec(ctx, pairs * k.T_2 * k.KAPPA_2)
+        self.Dm = HatVec(ctx, pairs * k.T_1 * k.KAPPA_2)
+
+    def fill_synthetic(self, seed):
+        """Uniform residues in [0,q) from the shared splitmix64 streams seed..seed+3 (oracle: orc_synth_fill)."""
+        self.A.fill_synthetic(seed)
+        self.B.fill_synthetic(seed + 1)
+        self.C.fill_synthetic(seed + 2)
+        self.Dm.fill_synthetic(seed + 3)
+        return self
+
+    def load(self, A, B, Cm, Dm):
+        self.A.load(A); self.B.load(B); self.C.load(Cm); self.Dm.load(Dm)
+        return self
+
+    def close(self):
+        for v in (self.A, self.B, self.C, self.Dm):
+            v.close()
+
+
+class State:
+    """The parts of src/structs.rs:269-286 the prover reads: phi_k[0], a_prime_k[0], b_prime_k[0]."""
+
+    def __init__(self, phi, a, b_prime):
+        self.phi, self.a, self.b_prime = phi, a, int(b_prime)
+
+
+class Transcript:
+    """Computed fields of src/structs.rs:192-209 (numpy uint64 / int64) plus the tape that produced them."""
+    pass
+
+
+class Prover:
+    def __init__(self, witness, verifier, constants, ctx):
+        self.witness, self.verifier, self.constants, self.ctx = witness, verifier, constants, ctx
+
+    def proof_gen(self, st, crs, max_rejections=5):
+        """src/proofgen.rs:30-427.  Raises RuntimeError("failed JL...") after >5 rejected projections (:175-177)
+        and BppCheckFailed (an AssertionError) where the reference's verify_b_prime_prime asserts."""
+        k, v = self.constants, self.verifier
+        rejections = 0
+        while True:
+            tape = dict(Pi=v.sample_jl_projection_all(), psi=v.generate_psi(), omega=v.generate_omega(),
+                        alpha=v.fetch_alpha(), beta=v.fetch_beta(), c=v.fetch_challenges())
+            try:
+                return prove_core(self.ctx, k, self.witness, st, crs, tape)
+            except _lib.JLRejected:
+                rejections += 1
+                if rejections > max_rejections:
+                    raise RuntimeError("failed JL...")
+
+
+def prove_core(ctx, k, witness, st, crs, tape, device_outputs=False):
+    """One call of lab_prove_core.  Arrays may be numpy (host) or torch cuda tensors (device resident)."""
+    n, r = k.N, k.R
+    pin = _lib.lab_prove_input()
+    pin.n, pin.r, pin.kappa, pin.kappa1, pin.kappa2 = n, r, k.KAPPA, k.KAPPA_1, k.KAPPA_2
+    pin.b1, pin.b2, pin.t1, pin.t2, pin.beta_bound = k.B_1, k.B_2, k.T_1, k.T_2, k.BETA_BOUND
+    keep = []
+
+    def p64(a):
+        a = _as_u64(a)
+        keep.append(a)
+        return _ptr(a)
+
+    pin.S, pin.phi, pin.a = p64(witness), p64(st.phi), p64(st.a)
+    pin.b_prime = st.b_prime
+    pin.A, pin.B, pin.C, pin.Dm = crs.A._h, crs.B._h, crs.C._h, crs.Dm._h
+    pin.a_off = pin.b_off = pin.c_off = pin.d_off = 0
+    Pi = tape["Pi"]
+    if isinstance(Pi, np.ndarray):
+        Pi = np.ascontiguousarray(Pi, dtype=np.int8)
+    keep.append(Pi)
+    pin.Pi = _ptr(Pi)
+    pin.psi = int(tape["psi"])
+    pin.omega, pin.alpha, pin.beta, pin.c = p64(tape["omega"]), p64(tape["alpha"]), p64(tape["beta"]), p64(tape["c"])
+
+    if device_outputs:
+        import torch
+
+        def mk(shape, dt=None):
+            return torch.empty(shape, dtype=dt or torch.int64, device="cuda")
+    else:
+        def mk(shape, dt=None):
+            return np.empty(shape, dtype=np.int64 if dt == "i64" else np.uint64)
+    T = Transcript()
+    T.u_1 = mk((k.KAPPA_1, D)); T.projection_int = mk((256,), None if device_outputs else "i64")
+    T.projection = mk((256,)); T.b_prime_prime = mk((D,)); T.u_2 = mk((k.KAPPA_2, D)); T.z = mk((n, D))
+    T.t_i_all = mk((r, k.KAPPA, D)); T.g_mat = mk((r, r, D)); T.h_mat = mk((r, r, D))
+    tr = _lib.lab_transcript()
+    for name in ("u_1", "projection_int", "projection", "b_prime_prime", "u_2", "z", "t_i_all", "g_mat", "h_mat"):
+        setattr(tr, name, _ptr(getattr(T, name)))
+    ctx._check(ctx._lib.lab_prove_core(ctx._h, C.byref(pin), C.byref(tr)))
+    T.tape = tape
+    return T

@@ -1,0 +1,152 @@
+"""GPU parity of the per-step operations (src/util.rs helpers and the loop nests of proof_gen) vs the oracle.
+Bit-exact integer work; every call goes through the C ABI."""
+import numpy as np
+import pytest
+
+from conftest import ALL_Q, Q_DEFAULT, Q_REF33
+
+pytestmark = pytest.mark.gpu
+D = 64
+
+
+def rp(rng, q, *shape):
+    return rng.integers(0, q, size=shape + (D,), dtype=np.uint64)
+
+
+@pytest.mark.parametrize("q", ALL_Q)
+@pytest.mark.parametrize("rows,inner,ncols", [(5, 7, 2), (9, 33, 16), (4, 64, 32), (13, 20, 35)])
+def test_ajtai_commit(contexts, q, rows, inner, ncols):
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    ctx = contexts(q)
+    rng = np.random.default_rng(rows * 31 + ncols)
+    A, S = rp(rng, q, rows, inner), rp(rng, q, inner, ncols)
+    got = lab.ajtai_commit(ctx, ctx.vec_from(A), ctx.vec_from(S), rows, inner, ncols).store().reshape(ncols, rows, D)
+    for i in range(ncols):
+        col = np.ascontiguousarray(S[:, i])
+        for rho in range(rows):
+            assert np.array_equal(got[i, rho], co.inner_product(q, A[rho], col)), (i, rho)
+
+
+@pytest.mark.parametrize("q", ALL_Q)
+@pytest.mark.parametrize("n,r", [(3, 2), (37, 5), (130, 4)])
+def test_gram(contexts, q, n, r):
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    ctx = contexts(q)
+    rng = np.random.default_rng(n + r)
+    P, S = rp(rng, q, n, r), rp(rng, q, n, r)
+    got = lab.gram(ctx, ctx.vec_from(P), ctx.vec_from(S), n, r).store().reshape(r, r, D)
+    for i in range(r):
+        for k in range(r):
+            want = co.inner_product(q, np.ascontiguousarray(P[:, i]), np.ascontiguousarray(S[:, k]))
+            assert np.array_equal(got[i, k], want)
+
+
+@pytest.mark.parametrize("q", ALL_Q)
+@pytest.mark.parametrize("nterms,length", [(1, 5), (12, 17), (64, 16), (130, 33)])
+def test_axpy_commit(contexts, q, nterms, length):
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    ctx = contexts(q)
+    rng = np.random.default_rng(nterms * 7 + length)
+    G, C = rp(rng, q, nterms), rp(rng, q, nterms, length)
+    got = lab.axpy_commit(ctx, ctx.vec_from(G), ctx.vec_from(C), nterms, length).store()
+    want = np.zeros((length, D), np.uint64)
+    for m in range(nterms):
+        prod = co.poly_by_poly_vec(q, G[m], C[m])
+        for rho in range(length):
+            want[rho] = co.poly_add(q, want[rho], prod[rho])
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("q", ALL_Q)
+def test_amortize_z_pointwise_and_poly_by_vec(contexts, q):
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    ctx = contexts(q)
+    rng = np.random.default_rng(9)
+    n, r = 21, 6
+    S, c = rp(rng, q, n, r), rp(rng, q, r)
+    z = lab.amortize_z(ctx, ctx.vec_from(S), ctx.vec_from(c), n, r).store()
+    for x in range(n):
+        assert np.array_equal(z[x], co.inner_product(q, S[x], c))
+    a, b = rp(rng, q, 70), rp(rng, q, 70)
+    va, vb = ctx.vec_from(a), ctx.vec_from(b)
+    assert np.array_equal(lab.pointwise(ctx, "mul", va, vb).store(), co.polymul_batch(q, a, b))
+    assert np.array_equal(lab.add_poly_vec(ctx, va, vb).store(), np.stack([co.poly_add(q, x, y) for x, y in zip(a, b)]))
+    assert np.array_equal(lab.pointwise(ctx, "sub", va, vb).store(), np.stack([co.poly_sub(q, x, y) for x, y in zip(a, b)]))
+    p = rp(rng, q, 1)
+    assert np.array_equal(lab.poly_by_poly_vec(ctx, ctx.vec_from(p), va).store(), co.poly_by_poly_vec(q, p[0], a))
+
+
+@pytest.mark.parametrize("q", ALL_Q)
+@pytest.mark.parametrize("base,exp", [(9, 4), (1625, 3), (14, 2), (638, 4), (2, 13), (3, 1)])
+def test_decompose_bug_compatible(contexts, q, base, exp):
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    ctx = contexts(q)
+    rng = np.random.default_rng(base)
+    v = rp(rng, q, 40)
+    v[0] = 0; v[1] = q - 1; v[2, :] = base // 2; v[3, :] = base // 2 + 1; v[4, 10:] = 0
+    got = lab.decompose_polynomial_vec(ctx, v, base, exp)
+    assert np.array_equal(got, co.decompose_vec(q, v, base, exp))
+
+
+def test_decompose_base_one_is_an_error(contexts):
+    import labrador_snark_amd as lab
+    ctx = contexts(Q_DEFAULT)
+    with pytest.raises(lab.LabradorError):
+        lab.decompose_polynomial_vec(ctx, np.ones((1, D), np.uint64), 1, 3)  # the reference loops forever (B_1 = 1 at n=1024)
+
+
+@pytest.mark.parametrize("q", ALL_Q)
+def test_norms_scale_sigma(contexts, q):
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    ctx = contexts(q)
+    rng = np.random.default_rng(12)
+    v = rp(rng, q, 33)
+    v[0] = 0; v[1] = q - 1
+    exact = lab.poly_norm_exact(ctx, v)
+    for k in range(33):
+        f, e = co.poly_norm(v[k])
+        assert exact[k] == e and float(exact[k]) == f
+    assert lab.vec_poly_norm_squared(ctx, v) == co.lib().orc_vec_poly_norm_squared(v, 33)
+    s = int(rng.integers(0, q))
+    assert np.array_equal(lab.scale_poly_vec(ctx, v, s), np.stack([co.poly_scale(q, row, s) for row in v]))
+    assert np.array_equal(lab.sigma_inv_vec(ctx, v), np.stack([co.sigma_inv(q, row) for row in v]))
+
+
+@pytest.mark.parametrize("q", ALL_Q)
+@pytest.mark.parametrize("n,r", [(1, 1), (2, 2), (5, 3), (64, 2)])
+def test_jl_project(contexts, q, n, r):
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    ctx = contexts(q)
+    rng = np.random.default_rng(n * 10 + r)
+    S = rp(rng, q, n, r)
+    Pi = rng.choice(np.array([-1, 0, 1], dtype=np.int8), size=(r, 256, n * D), p=[0.25, 0.5, 0.25]).astype(np.int8)
+    got = lab.jl_project(ctx, Pi, S, n, r)
+    s_cols = np.ascontiguousarray(S.transpose(1, 0, 2).reshape(r, n * D))
+    assert np.array_equal(got, co.jl_project(Pi, s_cols))
+
+
+def test_device_resident_io(contexts):
+    # same entry points with device pointers (torch tensors): nothing is staged through the host
+    import torch
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    q = Q_REF33
+    ctx = contexts(q)
+    rng = np.random.default_rng(77)
+    a, b = rp(rng, q, 128), rp(rng, q, 128)
+    da = torch.from_numpy(a.view(np.int64)).cuda()
+    db = torch.from_numpy(b.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    out = ctx.negacyclic_polymul(da, db)
+    ctx.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), co.polymul_batch(q, a, b))
+    dec = lab.decompose_polynomial_vec(ctx, da, 1625, 3)
+    ctx.synchronize()
+    assert np.array_equal(dec.cpu().numpy().view(np.uint64), co.decompose_vec(q, a, 1625, 3))

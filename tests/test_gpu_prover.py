@@ -1,0 +1,101 @@
+"""GPU parity of the fused prover core (lab_prove_core) vs the oracle's restatement of
+Prover::proof_gen (src/proofgen.rs:30-427): every transcript field bit-exact, then the oracle's restated
+Verifier::verify accepts the GPU transcript (the reference's CI invariant, src/main.rs:106-107)."""
+import numpy as np
+import pytest
+
+from conftest import ALL_Q, Q_DEFAULT, Q_REF33, Q_DIRECT
+
+import cases
+
+pytestmark = pytest.mark.gpu
+D = 64
+
+
+def run_gpu(ctx, p, S, phi, a, tape, b_prime, crs_seed=1000):
+    import labrador_snark_amd as lab
+    k = lab.RuntimeConstants(p.q, p.n, p.r, p.kappa, p.kappa1, p.kappa2)
+    assert (k.B_1, k.T_1, k.B_2, k.T_2, k.BETA_BOUND) == (p.b1, p.t1, p.b2, p.t2, p.beta_bound)
+    crs = lab.ResidentCRS(ctx, k).fill_synthetic(crs_seed)
+    st = lab.State(phi, a, b_prime)
+    try:
+        return lab.prove_core(ctx, k, S, st, crs, tape)
+    finally:
+        crs.close()
+
+
+@pytest.mark.parametrize("q,n,r,kappa,kappa1", [
+    (Q_DEFAULT, 2, 2, 4, 3),       # the reference's CI shape (src/main.rs:62-63) with small ranks
+    (Q_REF33, 2, 2, 5, 4),
+    (Q_REF33, 4, 3, 6, 5),
+    (Q_DIRECT, 3, 2, 7, 4),
+    (Q_REF33, 16, 8, 24, 16),
+    (Q_DEFAULT, 16, 16, 16, 8),
+])
+def test_prove_core_matches_oracle(contexts, q, n, r, kappa, kappa1):
+    ctx = contexts(q)
+    p = cases.Params(q, n, r, kappa, kappa1)
+    case, (S, phi, a, tape) = cases.oracle_case(p, seed=21)
+    want = case.prove()
+    assert want["bpp_ok"]
+    if not want["jl_valid"]:
+        pytest.skip("synthetic tape rejected by valid_projection")
+    T = run_gpu(ctx, p, S, phi, a, tape, case.b_prime)
+    assert np.array_equal(T.t_i_all, want["t"])
+    assert np.array_equal(T.g_mat, want["G"])
+    assert np.array_equal(T.u_1, want["u1"])
+    assert np.array_equal(T.projection_int, want["proj_int"])
+    assert np.array_equal(T.projection, want["proj"])
+    assert np.array_equal(T.b_prime_prime, want["bpp"])
+    assert np.array_equal(T.h_mat, want["H"])
+    assert np.array_equal(T.u_2, want["u2"])
+    assert np.array_equal(T.z, want["z"])
+    proof = dict(t=T.t_i_all, G=T.g_mat, H=T.h_mat, u1=T.u_1, u2=T.u_2, proj_int=T.projection_int, proj=T.projection,
+                 bpp=T.b_prime_prime, z=T.z)
+    rc, _ = case.verify(proof, p.b, float("inf"))
+    assert rc == 0
+
+
+def test_prove_core_rejections(contexts):
+    import labrador_snark_amd as lab
+    q, n, r = Q_REF33, 2, 2
+    ctx = contexts(q)
+    p = cases.Params(q, n, r, 4, 3)
+    case, (S, phi, a, tape) = cases.oracle_case(p, seed=5)
+    # a witness far above the norm bound makes Verifier::valid_projection reject (src/verification.rs:568-579)
+    S_big = np.full_like(S, q - 1)
+    with pytest.raises(lab.JLRejected):
+        run_gpu(ctx, p, S_big, phi, a, tape, case.b_prime)
+    # a wrong b' trips verify_b_prime_prime's assertion (src/verification.rs:550)
+    with pytest.raises(AssertionError):
+        run_gpu(ctx, p, S, phi, a, tape, (case.b_prime + 1) % q)
+    # kappa1 != kappa2: u_1 = lhs + rhs is undefined (add_poly_vec asserts, src/util.rs:299-302)
+    k = lab.RuntimeConstants(q, n, r, 4, 3, 2)
+    crs = lab.ResidentCRS(ctx, k).fill_synthetic(1)
+    with pytest.raises(AssertionError):
+        lab.prove_core(ctx, k, S, lab.State(phi, a, case.b_prime), crs, tape)
+    crs.close()
+
+
+def test_prover_class_mirrors_reference_call_shape(contexts):
+    # Prover::new(&witness, &verifier, &constants) / proof_gen(&st, &mut crs) with a scripted verifier
+    import labrador_snark_amd as lab
+    q, n, r = Q_REF33, 2, 2
+    ctx = contexts(q)
+    p = cases.Params(q, n, r, 4, 3)
+    case, (S, phi, a, tape) = cases.oracle_case(p, seed=8)
+
+    class ScriptedVerifier:
+        def sample_jl_projection_all(self): return tape["Pi"]
+        def generate_psi(self): return tape["psi"]
+        def generate_omega(self): return tape["omega"]
+        def fetch_alpha(self): return tape["alpha"]
+        def fetch_beta(self): return tape["beta"]
+        def fetch_challenges(self): return tape["c"]
+
+    k = lab.RuntimeConstants(q, n, r, 4, 3, 3)
+    crs = lab.ResidentCRS(ctx, k).fill_synthetic(1000)
+    T = lab.Prover(S, ScriptedVerifier(), k, ctx).proof_gen(lab.State(phi, a, case.b_prime), crs)
+    want = case.prove()
+    assert np.array_equal(T.u_1, want["u1"]) and np.array_equal(T.u_2, want["u2"]) and np.array_equal(T.z, want["z"])
+    crs.close()
