@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py — prover throughput on MI355X (driver contract: one JSON line on rank 0).
+
+Workload (BASELINE.json configs[2]): one full Prover::proof_gen
+(src/proofgen.rs:30-427) per step on a synthetic instance n=1024, r=32, d=64 with commitment ranks
+kappa = kappa1 = kappa2 = 1024 (stated explicitly: the reference hard-wires n*64 = 65536, which makes each
+B_ik a 1 TiB matrix).  Witness, state, challenge tape and the CRS matrices (transform domain) are resident
+in HBM before the timed region; CRS expansion from a seed (src/structs.rs:55-171) is NOT in the timed region
+(out of scope this round).  The modulus is the reference's "32-bit" choice
+q = 2^32+15 (src/constants.rs:196; 33 bits, not NTT-friendly -> exact 3-limb RNS path).
+
+metric  = prover constraints/sec  (K = 1 constraint per proof, src/constants.rs:26)  => proofs/sec.
+N > 1   = N independent instances, one per GPU (weak scaling, BASELINE configs[4]); the only collective is one
+          RCCL all-reduce of a 64-bit checksum of the aggregated commitments (u_1, u_2) after the timed steps.
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+D = 64
+Q_REF33 = (1 << 32) + 15
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def ring_products_per_proof(n, r, kappa, kappa1, kappa2, t1, t2):
+    """Counts of `&v1[i] * &v2[i]` in proof_gen, per step."""
+    pairs = r * (r + 1) // 2
+    return {"1_inner_ajtai": kappa * r * n, "2_gram": r * r * n, "3_outer_B": r * t1 * kappa1 * kappa,
+            "4_outer_C": pairs * t2 * kappa2, "6_aggregate": r * r * n + r * r + r * n, "7_phi": 2 * r * n,
+            "8_H": 2 * r * r * n, "9_u2": pairs * t1 * kappa2, "10_z": r * n}
+
+
+def cpu_baseline(q, products_per_proof, seconds=12.0):
+    """Reference-faithful CPU port (oracle orc_polymul_faithful: i128 `%` after every coefficient op, like
+    src/algebraic.rs:30-38,95-134) timed on this host on a bounded sample of ring products, all threads
+    busy; proofs/s is extrapolated from the measured products/s and the per-proof product count."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import coracle as co
+    lib = co.lib()
+    cores = max(1, min(16, os.cpu_count() or 1))
+    rng = np.random.default_rng(123)
+    length = 64
+    data = [(rng.integers(0, q, size=(length, D), dtype=np.uint64), rng.integers(0, q, size=(length, D), dtype=np.uint64))
+            for _ in range(cores)]
+    # calibrate
+    t0 = time.perf_counter()
+    lib.orc_bench_inner_product_faithful(q, data[0][0], data[0][1], length, 1)
+    per_call = max(time.perf_counter() - t0, 1e-6)
+    reps = max(1, int(seconds / per_call))
+
+    def work(i):
+        return lib.orc_bench_inner_product_faithful(q, data[i][0], data[i][1], length, reps)
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(work, range(cores)))
+    dt = time.perf_counter() - t0
+    products = cores * reps * length
+    rate = products / dt
+    return {"value": rate / products_per_proof, "unit": "constraints/s", "cores": cores, "kind": "port",
+            "products_per_s": rate, "extrapolated": True,
+            "sample": "%d reference-faithful ring products (schoolbook 64x64, i128 %% per op + X^64+1 fold + accumulate) "
+                      "on %d threads in %.1f s; proofs/s = products/s / %d products per proof"
+                      % (products, cores, dt, products_per_proof)}
+
+
+def checksum_u64(t):
+    """Order-independent 64-bit checksum of a device tensor of residues (sum mod 2^63)."""
+    return (t.to(torch.int64).sum() & ((1 << 62) - 1)).reshape(1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--q", type=int, default=Q_REF33)
+    ap.add_argument("--n", type=int, default=1024)
+    ap.add_argument("--r", type=int, default=32)
+    ap.add_argument("--kappa", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank)
+
+    import labrador_snark_amd as lab
+    import cases
+
+    q, n, r, kappa = args.q, args.n, args.r, args.kappa
+    p = cases.Params(q, n, r, kappa, kappa)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa, kappa)
+    # longest reduction in the prover: r*t1*kappa digit terms (small operands) — ask for enough CRT range
+    ctx = lab.Context(q, local_rank, max(65536, n * r + r * r))
+    ctx.use_torch_stream()
+
+    # instance `50 + rank`: witness/state/tape resident on the device
+    S, phi, a, tape = cases.make_inputs(p, seed=50 + rank)
+    from oracle import coracle as co
+    b_poly = np.empty(D, np.uint64)
+    # b' = const term of b = sum a_ij<s_i,s_j> + sum <phi_i,s_i> (src/structs.rs:320-341, 373): computed on the GPU
+    # with the product's own kernels (the oracle is not on the product path)
+    hS, hphi, ha = ctx.vec_from(S), ctx.vec_from(phi), ctx.vec_from(a)
+    G = lab.gram(ctx, hS, hS, n, r)
+    Gc = ctx.vec_from(G.store())
+    t1v = lab.polynomial_vec_inner_product(ctx, ha, Gc).store()[0]
+    t2v = lab.polynomial_vec_inner_product(ctx, hphi, hS).store()[0]
+    b_prime = int((int(t1v[0]) + int(t2v[0])) % q)
+    for v in (hS, hphi, ha, G, Gc):
+        v.close()
+
+    def dev64(x):
+        return torch.from_numpy(np.ascontiguousarray(x).view(np.int64)).to(dev)
+
+    dS, dphi, da = dev64(S), dev64(phi), dev64(a)
+    dtape = dict(Pi=torch.from_numpy(tape["Pi"]).to(dev), psi=tape["psi"], omega=dev64(tape["omega"]),
+                 alpha=dev64(tape["alpha"]), beta=dev64(tape["beta"]), c=dev64(tape["c"]))
+    st = lab.State(dphi, da, b_prime)
+    crs = lab.ResidentCRS(ctx, k).fill_synthetic(1000 + 10 * rank)
+    torch.cuda.synchronize()
+
+    def step():
+        return lab.prove_core(ctx, k, dS, st, crs, dtape, device_outputs=True)
+
+    for _ in range(args.warmup):
+        T = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ctx.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        T = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches, alg_bytes = ctx.profile_end()
+
+    # aggregate of the commitments across instances: one RCCL all-reduce of a checksum (outside the timed steps)
+    chk = checksum_u64(T.u_1) + checksum_u64(T.u_2)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(chk, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    result = None
+    if rank == 0:
+        proofs = world * args.steps
+        value = proofs / elapsed
+        per_launch_s = (kernel_ms / 1e3) / max(launches, 1)
+        achieved = (alg_bytes / max(launches, 1)) / per_launch_s / 1e9 if launches else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        counts = ring_products_per_proof(n, r, kappa, kappa, kappa, k.T_1, k.T_2)
+        result = {
+            "metric": "prover constraints/sec", "value": value, "unit": "constraints/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 residues (u64 accumulate)",
+            "data": "synthetic",
+            "config": {"workload": "full Prover::proof_gen n=%d r=%d d=64, kappa=kappa1=kappa2=%d, q=%d (%d RNS limbs), "
+                                   "CRS resident in transform domain, CRS expansion excluded" % (n, r, kappa, q, ctx.nlimbs),
+                       "q": q, "n": n, "r": r, "kappa": kappa, "t1": k.T_1, "t2": k.T_2, "b1": k.B_1, "b2": k.B_2,
+                       "nlimbs": ctx.nlimbs, "instances_per_gpu": 1, "parallelism": "instance-per-gpu x%d" % world},
+            "proofs_per_s": value, "witness_Rq_elems_per_s": value * n * r,
+            "ring_products_per_proof": sum(counts.values()),
+            "checksum_u1_u2": int(chk.item()),
+            "roofline": {"bound": "hbm", "kernel": "k_matvec_partial (outer commitment sum_ik B_ik t_i^(k), src/proofgen.rs:101-132)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "launches": launches, "avg_launch_ms": per_launch_s * 1e3,
+                         "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1),
+                         "kernel_share_of_step": (kernel_ms / 1e3) / elapsed if elapsed > 0 else None},
+        }
+
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras:
+        # release the big CRS before the side measurements
+        crs.close()
+        torch.cuda.synchronize()
+        extras = side_measurements(lab, ctx, q, dev)
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            counts = ring_products_per_proof(n, r, kappa, kappa, kappa, k.T_1, k.T_2)
+            result["cpu_baseline"] = cpu_baseline(q, sum(counts.values()))
+        else:
+            result["cpu_baseline"] = None
+        if extras:
+            result["extra"] = extras
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _time(fn, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def side_measurements(lab, ctx, q, dev):
+    """BASELINE configs[1] (batched NTT) and configs[3] (Ajtai mat-vec 2^14 x 2^10), reported next to the headline."""
+    out = {}
+    L = ctx.nlimbs
+    for batch in (4096, 1 << 20):
+        x = torch.randint(0, 1 << 29, (L, batch, D), dtype=torch.int32, device=dev)
+        tf = _time(lambda: ctx.ntt_forward(x, batch), 20)
+        ti = _time(lambda: ctx.ntt_inverse(x, batch), 20)
+        out["ntt_batch_%d" % batch] = {"limb_planes": L, "fwd_us": tf * 1e6, "inv_us": ti * 1e6,
+                                       "ntts_per_s": 2 * L * batch / (tf + ti),
+                                       "algorithmic_GBps": 2 * L * batch * 512 / (tf + ti) / 1e9}
+        del x
+    rows, cols = 1 << 14, 1 << 10
+    A = ctx.vec(rows * cols).fill_synthetic(4)
+    for ncols in (1, 32):
+        S = ctx.vec(cols * ncols).fill_synthetic(5)
+        o = ctx.vec(rows * ncols)
+        if ncols == 1:
+            t = _time(lambda: lab.matvec_sum(ctx, A, S, 1, rows, cols, out=o), 10)
+        else:
+            t = _time(lambda: lab.ajtai_commit(ctx, A, S, rows, cols, ncols, out=o), 5)
+        byt = L * (rows * cols + cols * ncols + rows * ncols) * 256
+        out["ajtai_2p14x2p10_rhs%d" % ncols] = {"ms": t * 1e3, "algorithmic_GBps": byt / t / 1e9,
+                                                "modmuladds_per_s": L * rows * cols * ncols * 64 / t}
+        S.close(); o.close()
+    A.close()
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -94,6 +94,13 @@ const char *lab_last_error(const lab_ctx *ctx);
 int lab_ctx_set_stream(lab_ctx *ctx, void *hip_stream);
 int lab_ctx_synchronize(lab_ctx *ctx);
 
+/* Measurement hook (no reference counterpart): between begin and end every launch of the streaming
+ * mat-vec kernel (the prover's dominant, HBM-bound kernel) is bracketed by HIP events on the context's
+ * stream.  end() synchronises and returns the summed kernel time, the launch count and the algorithmic
+ * bytes those launches moved (matrix + vector + output, all limbs). */
+int lab_ctx_profile_begin(lab_ctx *ctx);
+int lab_ctx_profile_end(lab_ctx *ctx, double *kernel_ms, uint64_t *launches, double *algorithmic_bytes);
+
 /* ---- the reference's operator seam -------------------------------------
  * (*PLAN).negacyclic_polymul(&mut prod, &lhs, &rhs) + transform_slice_u64_to_zq
  * (src/algebraic.rs:396-397; raw form benches/ntt_speed.rs:17-19), batched:

@@ -78,6 +78,9 @@ SIGNATURES = {
     "lab_last_error": (C.c_char_p, [C.c_void_p]),
     "lab_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lab_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "lab_ctx_profile_begin": (C.c_int, [C.c_void_p]),
+    "lab_ctx_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
+                                      C.POINTER(C.c_double)]),
     "lab_negacyclic_polymul_u64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "lab_ntt_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "lab_ntt_inverse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -87,6 +87,16 @@ class Context:
         import torch
         self._check(self._lib.lab_ctx_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
+    def profile_begin(self):
+        """Start bracketing every launch of the streaming mat-vec kernel with HIP events on the context's stream."""
+        self._check(self._lib.lab_ctx_profile_begin(self._h))
+
+    def profile_end(self):
+        """-> (kernel_ms_total, launches, algorithmic_bytes_total)"""
+        ms, n, b = C.c_double(), C.c_uint64(), C.c_double()
+        self._check(self._lib.lab_ctx_profile_end(self._h, C.byref(ms), C.byref(n), C.byref(b)))
+        return ms.value, int(n.value), b.value
+
     # ---- PLAN.negacyclic_polymul + transform_slice_u64_to_zq (src/algebraic.rs:396-397), batched
     def negacyclic_polymul(self, lhs, rhs, out=None):
         lhs, rhs = _as_u64(lhs), _as_u64(rhs)

@@ -212,6 +212,7 @@ extern "C" int lab_ctx_create(uint64_t q, int device, uint64_t max_len, lab_ctx*
 extern "C" void lab_ctx_destroy(lab_ctx* c) {
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& ev : c->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->d_tabs) (void)hipFree(c->d_tabs);
   if (c->d_crt) (void)hipFree(c->d_crt);
@@ -243,6 +244,51 @@ extern "C" int lab_ctx_set_stream(lab_ctx* c, void* hip_stream) {
 extern "C" int lab_ctx_synchronize(lab_ctx* c) {
   if (!c) return LAB_ERR_ARG;
   LAB_HIP(c, hipStreamSynchronize(c->stream));
+  return LAB_OK;
+}
+
+// ------------------------------------------------------------- measurement hook
+extern "C" int lab_ctx_profile_begin(lab_ctx* c) {
+  if (!c) return LAB_ERR_ARG;
+  LAB_HIP(c, hipStreamSynchronize(c->stream));
+  c->prof_on = true;
+  c->prof_used = 0;
+  c->prof_bytes = 0.0;
+  return LAB_OK;
+}
+
+extern "C" int lab_ctx_profile_end(lab_ctx* c, double* kernel_ms, uint64_t* launches, double* algorithmic_bytes) {
+  if (!c) return LAB_ERR_ARG;
+  LAB_HIP(c, hipStreamSynchronize(c->stream));
+  double ms = 0.0;
+  for (size_t i = 0; i < c->prof_used; i++) {
+    float t = 0.f;
+    LAB_HIP(c, hipEventElapsedTime(&t, c->prof_events[i].first, c->prof_events[i].second));
+    ms += t;
+  }
+  if (kernel_ms) *kernel_ms = ms;
+  if (launches) *launches = c->prof_used;
+  if (algorithmic_bytes) *algorithmic_bytes = c->prof_bytes;
+  c->prof_on = false;
+  return LAB_OK;
+}
+
+int lab::matvec_partial_timed(lab_ctx* c, HatView partial, ConstHatView M, ConstHatView V, size_t nmat, size_t rows, size_t cols) {
+  if (!c->prof_on) {
+    LAB_HIP(c, launch_matvec_partial(partial, M, V, nmat, rows, cols, c->nlimbs, c->d_tabs, c->stream));
+    return LAB_OK;
+  }
+  if (c->prof_used == c->prof_events.size()) {
+    hipEvent_t a, b;
+    LAB_HIP(c, hipEventCreate(&a));
+    LAB_HIP(c, hipEventCreate(&b));
+    c->prof_events.emplace_back(a, b);
+  }
+  auto& ev = c->prof_events[c->prof_used++];
+  LAB_HIP(c, hipEventRecord(ev.first, c->stream));
+  LAB_HIP(c, launch_matvec_partial(partial, M, V, nmat, rows, cols, c->nlimbs, c->d_tabs, c->stream));
+  LAB_HIP(c, hipEventRecord(ev.second, c->stream));
+  c->prof_bytes += (double)c->nlimbs * 256.0 * ((double)nmat * rows * cols + (double)nmat * cols + (double)nmat * rows);
   return LAB_OK;
 }
 
@@ -430,16 +476,11 @@ extern "C" int lab_matvec_sum(lab_ctx* c, lab_vec* out, size_t out_off, const la
                 nmat * cols, (unsigned long long)c->max_len);
   if (rows > 0x7fffffffu || cols > 0x7fffffffu / 64 || nmat > 65535) return fail(c, LAB_ERR_ARG, "lab_matvec_sum: dimension too large");
   LAB_HIP(c, hipSetDevice(c->device));
-  if (nmat == 1) {
-    LAB_HIP(c, launch_matvec_partial(out->view(out_off), M->view(m_off), V->view(v_off), 1, rows, cols, c->nlimbs,
-                                     c->d_tabs, c->stream));
-    return LAB_OK;
-  }
+  if (nmat == 1) return matvec_partial_timed(c, out->view(out_off), M->view(m_off), V->view(v_off), 1, rows, cols);
   const size_t pw = nmat * rows * D;
   if ((rc = ensure_scratch(c, (size_t)c->nlimbs * pw * 4))) return rc;
   HatView partial{static_cast<uint32_t*>(c->scratch), pw};
-  LAB_HIP(c, launch_matvec_partial(partial, M->view(m_off), V->view(v_off), nmat, rows, cols, c->nlimbs, c->d_tabs,
-                                   c->stream));
+  if ((rc = matvec_partial_timed(c, partial, M->view(m_off), V->view(v_off), nmat, rows, cols))) return rc;
   LAB_HIP(c, launch_sum_terms(out->view(out_off), partial, nmat, rows, c->nlimbs, c->d_tabs, c->stream));
   return LAB_OK;
 }

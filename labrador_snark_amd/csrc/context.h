@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/labrador_hip.h"
 #include "kernels.h"
@@ -25,6 +27,11 @@ struct lab_ctx {
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
   mutable std::string err;
+  // measurement hook (lab_ctx_profile_begin/end): HIP events around the mat-vec kernel
+  bool prof_on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  size_t prof_used = 0;
+  double prof_bytes = 0.0;
 };
 
 struct lab_vec {
@@ -101,6 +108,8 @@ struct Staging {
 };
 
 int check_range(lab_ctx* c, const lab_vec* v, size_t off, size_t n, const char* what);
+// launch_matvec_partial wrapped in the profiling events when the hook is active
+int matvec_partial_timed(lab_ctx* c, HatView partial, ConstHatView M, ConstHatView V, size_t nmat, size_t rows, size_t cols);
 // hat -> coefficient conversion of `count` elements of `src` into device memory `dcoeffs`, using `tmp` (>= count elements of hat scratch)
 int from_hat(lab_ctx* c, ConstHatView src, size_t count, uint32_t* tmp, uint64_t* dcoeffs);
 int to_hat(lab_ctx* c, const uint64_t* dcoeffs, HatView dst, size_t count);

@@ -147,7 +147,7 @@ extern "C" int lab_prove_core(lab_ctx* c, const lab_prove_input* in, lab_transcr
   // ---------------- step 3 (:101-132): lhs = sum_{i,k} B_ik t_i^(k)
   LAB_HIP(c, launch_decompose(cTdec, cT, rk, q, (uint64_t)in->b1, t1, kappa, s));  // [i][k][rho]
   if ((rc = to_hat(c, cTdec, HV(hTdec), rk * t1))) return rc;
-  LAB_HIP(c, launch_matvec_partial(HV(hpart), in->B->view(in->b_off), HV(hTdec), r * (size_t)t1, k1, kappa, L, tabs, s));
+  if ((rc = matvec_partial_timed(c, HV(hpart), in->B->view(in->b_off), HV(hTdec), r * (size_t)t1, k1, kappa))) return rc;
   LAB_HIP(c, launch_sum_terms(HV(hlhs), HV(hpart), r * (size_t)t1, k1, L, tabs, s));
 
   // ---------------- step 4 (:137-148): rhs = sum_{i<=j,k} g_ij^(k) C_ijk ; u_1 = lhs + rhs (:153)

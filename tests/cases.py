@@ -50,8 +50,15 @@ def make_inputs(p, seed, witness_bound=None):
     rng = np.random.default_rng(seed)
     q, n, r = p.q, p.n, p.r
     if witness_bound is None:
-        witness_bound = max(1, int(p.beta_bound / math.sqrt(n * r * D)))
-    S = rng.integers(0, witness_bound + 1, size=(n, r, D), dtype=np.uint64)
+        witness_bound = int(p.beta_bound / math.sqrt(n * r * D))
+    if witness_bound >= 1:
+        S = rng.integers(0, witness_bound + 1, size=(n, r, D), dtype=np.uint64)
+    else:
+        # default-Q regime (beta = 31): generate_witness's halving loop leaves an almost-all-zero witness
+        # (SURVEY Appendix B); restate that as beta^2/4 unit coefficients at random positions.
+        S = np.zeros(n * r * D, dtype=np.uint64)
+        S[rng.choice(n * r * D, size=max(1, p.beta_bound ** 2 // 4), replace=False)] = 1
+        S = S.reshape(n, r, D)
     phi = rng.integers(0, q, size=(n, r, D), dtype=np.uint64)
     a = rng.integers(0, q, size=(r, r, D), dtype=np.uint64)
     for i in range(r):
