@@ -97,13 +97,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # one process per GPU; LAB_DIST_BACKEND=gloo lets several ranks share one GPU for a functional rehearsal
+    backend = os.environ.get("LAB_DIST_BACKEND", "nccl")
+    gpu_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import labrador_snark_amd as lab
     import cases
@@ -112,7 +116,7 @@ def main():
     p = cases.Params(q, n, r, kappa, kappa)
     k = lab.RuntimeConstants(q, n, r, kappa, kappa, kappa)
     # longest reduction in the prover: r*t1*kappa digit terms (small operands) — ask for enough CRT range
-    ctx = lab.Context(q, local_rank, max(65536, n * r + r * r))
+    ctx = lab.Context(q, gpu_index, max(65536, n * r + r * r))
     ctx.use_torch_stream()
 
     # instance `50 + rank`: witness/state/tape resident on the device

@@ -129,6 +129,16 @@ int lab_vec_store_u64(lab_ctx *ctx, const lab_vec *src, size_t src_off, size_t c
 int lab_vec_fill_synthetic(lab_ctx *ctx, lab_vec *dst, size_t dst_off, size_t count, uint64_t seed,
                            uint64_t first_elem, uint64_t bound);
 
+/* CRS::fetch_next_n / random_oracle_gen on the device (src/structs.rs:35-45, 147-171):
+ * `count` polynomials whose 64*count coefficients are ChaCha20Rng::from_seed(seed).gen_range(0..q) for the
+ * consecutive 256-bit big-endian seeds base_seed + offset, +1 per coefficient (offset = offset_hi*2^64 + offset_lo,
+ * in coefficient units — the reference's fetch_* offsets are listed in INTEGRATION.md).  lab_crs_expand stores
+ * them in the transform domain, lab_crs_expand_u64 as coefficients (host or device pointer). */
+int lab_crs_expand(lab_ctx *ctx, lab_vec *dst, size_t dst_off, size_t count, const uint8_t base_seed[32],
+                   uint64_t offset_lo, uint64_t offset_hi);
+int lab_crs_expand_u64(lab_ctx *ctx, uint64_t *coeffs, size_t count, const uint8_t base_seed[32],
+                       uint64_t offset_lo, uint64_t offset_hi);
+
 /* ---- src/util.rs vector helpers on hat vectors ---------------------------- */
 
 /* polynomial_vec_inner_product (src/util.rs:496-509): out[out_off] = sum_i v1[off1+i]*v2[off2+i] */

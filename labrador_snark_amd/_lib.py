@@ -91,6 +91,8 @@ SIGNATURES = {
     "lab_vec_store_u64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
     "lab_vec_fill_synthetic": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint64,
                                          C.c_uint64]),
+    "lab_crs_expand": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_char_p, C.c_uint64, C.c_uint64]),
+    "lab_crs_expand_u64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_uint64, C.c_uint64]),
     "lab_inner_product": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                     C.c_size_t, C.c_size_t]),
     "lab_matvec_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,

@@ -461,6 +461,44 @@ extern "C" int lab_vec_fill_synthetic(lab_ctx* c, lab_vec* dst, size_t dst_off, 
   return LAB_OK;
 }
 
+// ------------------------------------------------------------- CRS expansion (ChaCha20 + gen_range)
+extern "C" int lab_crs_expand_u64(lab_ctx* c, uint64_t* coeffs, size_t count, const uint8_t base_seed[32],
+                                  uint64_t offset_lo, uint64_t offset_hi) {
+  if (!c) return LAB_ERR_ARG;
+  if (count == 0) return LAB_OK;
+  if (!coeffs || !base_seed) return fail(c, LAB_ERR_ARG, "lab_crs_expand_u64: null argument");
+  LAB_HIP(c, hipSetDevice(c->device));
+  int rc = ensure_scratch(c, Staging::need(coeffs, count * D * 8));
+  if (rc) return rc;
+  Carver cv(c->scratch);
+  Staging st(c, &cv);
+  uint64_t* d = st.out(coeffs, count * D);
+  LAB_HIP(c, launch_crs_expand(d, count, base_seed, offset_lo, offset_hi, c->q, c->stream));
+  return st.finish();
+}
+
+extern "C" int lab_crs_expand(lab_ctx* c, lab_vec* dst, size_t dst_off, size_t count, const uint8_t base_seed[32],
+                              uint64_t offset_lo, uint64_t offset_hi) {
+  if (!c) return LAB_ERR_ARG;
+  int rc = check_range(c, dst, dst_off, count, "lab_crs_expand");
+  if (rc) return rc;
+  if (!base_seed) return fail(c, LAB_ERR_ARG, "lab_crs_expand: null seed");
+  LAB_HIP(c, hipSetDevice(c->device));
+  const size_t chunk = 1u << 18;
+  if ((rc = ensure_scratch(c, (count < chunk ? count : chunk) * D * 8))) return rc;
+  uint64_t* stage = static_cast<uint64_t*>(c->scratch);
+  for (size_t done = 0; done < count; done += chunk) {
+    const size_t n = count - done < chunk ? count - done : chunk;
+    // offset advances by 64 seeds per polynomial
+    unsigned __int128 off = (((unsigned __int128)offset_hi << 64) | offset_lo) + (unsigned __int128)done * D;
+    HatView v = dst->view(dst_off + done);
+    LAB_HIP(c, launch_crs_expand(stage, n, base_seed, (uint64_t)off, (uint64_t)(off >> 64), c->q, c->stream));
+    LAB_HIP(c, launch_reduce_u64(stage, v, n, c->nlimbs, c->d_tabs, c->stream));
+    LAB_HIP(c, launch_ntt(true, v, v, n, c->nlimbs, c->d_tabs, 0, c->stream));
+  }
+  return LAB_OK;
+}
+
 // ------------------------------------------------------------- inner products / mat-vec
 extern "C" int lab_matvec_sum(lab_ctx* c, lab_vec* out, size_t out_off, const lab_vec* M, size_t m_off, size_t nmat,
                               size_t rows, size_t cols, const lab_vec* V, size_t v_off) {

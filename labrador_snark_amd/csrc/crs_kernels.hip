@@ -1,0 +1,98 @@
+// crs_kernels.hip — on-device expansion of the reference's CRS random oracle
+// (src/structs.rs:27-190): every coefficient is
+//     ChaCha20Rng::from_seed(base_seed + offset).gen_range(0..Q)      (src/structs.rs:167-171)
+// with a 256-bit big-endian seed incremented once per coefficient (:155-165).
+// One thread per coefficient: 256-bit seed add, ChaCha20 block(s) (RFC 7539
+// block function, 64-bit counter / zero stream as rand_chacha 0.3.1 lays it
+// out), rand 0.8.5's UniformInt<i128>::sample_single (u128 candidate from four
+// consecutive words, widening multiply by Q, accept if lo <= (Q << lz) - 1).
+// ~1 100 integer ops per coefficient: VALU-bound (≈3·10^10 coefficients/s).
+// gfx950 only.  SURVEY §8(f) row f1.
+#include "kernels.h"
+
+namespace lab {
+
+struct CrsSeed {
+  uint32_t limb[8];  // base seed as a 256-bit big-endian integer: limb[0] most significant
+};
+
+#define LAB_QR(a, b, c, d)                                        \
+  a += b; d ^= a; d = __builtin_rotateleft32(d, 16);              \
+  c += d; b ^= c; b = __builtin_rotateleft32(b, 12);              \
+  a += b; d ^= a; d = __builtin_rotateleft32(d, 8);               \
+  c += d; b ^= c; b = __builtin_rotateleft32(b, 7);
+
+__global__ void __launch_bounds__(256)
+k_crs_expand(uint64_t* __restrict__ out, size_t nwords, CrsSeed base, uint64_t off_lo, uint64_t off_hi, uint64_t q,
+             uint64_t zone_lo, uint64_t zone_hi) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < nwords; i += stride) {
+    // seed = base + offset + i  (256-bit big-endian arithmetic, wraps at 2^256 like increment_seed)
+    uint64_t add_lo = off_lo + (uint64_t)i;
+    uint64_t add_hi = off_hi + (add_lo < off_lo ? 1 : 0);
+    const uint32_t addw[4] = {(uint32_t)add_lo, (uint32_t)(add_lo >> 32), (uint32_t)add_hi, (uint32_t)(add_hi >> 32)};
+    uint32_t key[8];
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 7; w >= 0; w--) {
+      const uint64_t s = (uint64_t)base.limb[w] + (w >= 4 ? addw[7 - w] : 0u) + carry;
+      carry = (uint32_t)(s >> 32);
+      // the seed BYTES are the big-endian integer; ChaCha's key words are little-endian words of those bytes
+      key[w] = __builtin_bswap32((uint32_t)s);
+    }
+    uint64_t result = 0;
+    bool done = false;
+    for (uint32_t counter = 0; !done; counter++) {
+      uint32_t x0 = 0x61707865u, x1 = 0x3320646eu, x2 = 0x79622d32u, x3 = 0x6b206574u;
+      uint32_t x4 = key[0], x5 = key[1], x6 = key[2], x7 = key[3], x8 = key[4], x9 = key[5], x10 = key[6], x11 = key[7];
+      uint32_t x12 = counter, x13 = 0, x14 = 0, x15 = 0;
+#pragma unroll
+      for (int rnd = 0; rnd < 10; rnd++) {
+        LAB_QR(x0, x4, x8, x12) LAB_QR(x1, x5, x9, x13) LAB_QR(x2, x6, x10, x14) LAB_QR(x3, x7, x11, x15)
+        LAB_QR(x0, x5, x10, x15) LAB_QR(x1, x6, x11, x12) LAB_QR(x2, x7, x8, x13) LAB_QR(x3, x4, x9, x14)
+      }
+      const uint32_t blk[16] = {x0 + 0x61707865u, x1 + 0x3320646eu, x2 + 0x79622d32u, x3 + 0x6b206574u,
+                                x4 + key[0], x5 + key[1], x6 + key[2], x7 + key[3],
+                                x8 + key[4], x9 + key[5], x10 + key[6], x11 + key[7],
+                                x12 + counter, x13, x14, x15};
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        if (!done) {
+          const uint64_t x = (uint64_t)blk[4 * d] | ((uint64_t)blk[4 * d + 1] << 32);      // first next_u64()
+          const uint64_t y = (uint64_t)blk[4 * d + 2] | ((uint64_t)blk[4 * d + 3] << 32);  // second: high half
+          // (y*2^64 + x) * q as 256 bits; q < 2^40
+          const uint64_t a_lo = x * q, a_hi = __umul64hi(x, q);
+          const uint64_t b_lo = y * q, b_hi = __umul64hi(y, q);
+          const uint64_t t = a_hi + b_lo;
+          const uint64_t c = t < a_hi ? 1 : 0;
+          const uint64_t lo_lo = a_lo, lo_hi = t, hi = b_hi + c;
+          const bool ok = (lo_hi < zone_hi) || (lo_hi == zone_hi && lo_lo <= zone_lo);
+          if (ok) { result = hi; done = true; }
+        }
+      }
+    }
+    out[i] = result;
+  }
+}
+
+hipError_t launch_crs_expand(uint64_t* coeffs, size_t count, const uint8_t base_seed[32], uint64_t off_lo,
+                             uint64_t off_hi, uint64_t q, hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  CrsSeed base;
+  for (int w = 0; w < 8; w++)
+    base.limb[w] = ((uint32_t)base_seed[4 * w] << 24) | ((uint32_t)base_seed[4 * w + 1] << 16) |
+                   ((uint32_t)base_seed[4 * w + 2] << 8) | (uint32_t)base_seed[4 * w + 3];
+  // zone = (q << leading_zeros_128(q)) - 1
+  unsigned __int128 range = q;
+  int lz = 64 + __builtin_clzll(q);
+  unsigned __int128 zone = (range << lz) - 1;
+  size_t nwords = count * D;
+  unsigned blocks = (unsigned)((nwords + 255) / 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_crs_expand, dim3(blocks), dim3(256), 0, s, coeffs, nwords, base, off_lo, off_hi, q,
+                     (uint64_t)zone, (uint64_t)(zone >> 64));
+  return hipGetLastError();
+}
+
+}  // namespace lab

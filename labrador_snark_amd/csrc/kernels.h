@@ -86,4 +86,8 @@ hipError_t launch_jl_project(int64_t* proj, const int8_t* Pi, const uint64_t* S,
 hipError_t launch_phi_pi_part(uint64_t* W, const int8_t* Pi, const uint64_t* omega, size_t n, size_t r, uint64_t q,
                               hipStream_t s);
 
+// ---- crs_kernels.hip: CRS::random_oracle_gen on the device (src/structs.rs:35-45, 147-171)
+hipError_t launch_crs_expand(uint64_t* coeffs, size_t count, const uint8_t base_seed[32], uint64_t off_lo,
+                             uint64_t off_hi, uint64_t q, hipStream_t s);
+
 }  // namespace lab

@@ -75,6 +75,82 @@ class ResidentCRS:
             v.close()
 
 
+class CRS:
+    """The reference's seed-addressed CRS (src/structs.rs:27-190): `base_seed` is the 32-byte PRG seed, rows are
+    ChaCha20-expanded on the GPU (lab_crs_expand) instead of one coefficient at a time on the host.  fetch_* return
+    coefficient arrays like the reference's Vec<Rq>; materialize() builds the resident transform-domain matrices
+    lab_prove_core consumes.  Seed offsets are the reference's own, copied literally (including B matrices that
+    are spaced kappa1*kappa seeds apart although each consumes 64x that, and T_1 used for C's index)."""
+
+    def __init__(self, ctx, constants, base_seed):
+        if len(base_seed) != 32:
+            raise ValueError("base_seed must be 32 bytes")
+        self.ctx, self.constants, self.base_seed = ctx, constants, bytes(base_seed)
+
+    # ---- offsets in coefficient units
+    def _sum_pairs(self, i):
+        R = self.constants.R
+        return i * R - (i * (i - 1)) // 2 if i > 0 else 0
+
+    def offset_A(self, row):                                  # src/structs.rs:62
+        k = self.constants
+        return row * (k.N * D)
+
+    def offset_B(self, i, kk, row):                           # src/structs.rs:78-82
+        k = self.constants
+        return k.KAPPA * k.N * D + (i * k.T_1 + kk) * (k.KAPPA_1 * k.KAPPA) + row * (k.KAPPA * D)
+
+    def offset_C(self, i, j, kk):                             # src/structs.rs:94-108
+        k = self.constants
+        return (k.KAPPA * k.N * D + (k.R * k.T_1) * (k.KAPPA_1 * k.KAPPA) * D +
+                (kk + k.T_1 * (self._sum_pairs(i) + (j - i))) * (k.KAPPA_2 * D))
+
+    def offset_D(self, i, j, kk):                             # src/structs.rs:120-138
+        k = self.constants
+        return (k.KAPPA * k.N * D + (k.R * k.T_1) * (k.KAPPA_1 * k.KAPPA) * D + (k.R * (k.R + 1) // 2) * (k.KAPPA_2 * D) +
+                (kk + k.T_1 * (self._sum_pairs(i) + (j - i))) * (k.KAPPA_2 * D))
+
+    # ---- fetch_* as coefficient arrays [count][64]
+    def _fetch(self, offset, count):
+        out = np.empty((count, D), dtype=np.uint64)
+        self.ctx._check(self.ctx._lib.lab_crs_expand_u64(self.ctx._h, _ptr(out), count, self.base_seed,
+                                                         offset & ((1 << 64) - 1), offset >> 64))
+        return out
+
+    def fetch_A_row(self, row):
+        return self._fetch(self.offset_A(row), self.constants.N)
+
+    def fetch_B_ik_row(self, i, kk, row):
+        return self._fetch(self.offset_B(i, kk, row), self.constants.KAPPA)
+
+    def fetch_C_ijk(self, i, j, kk):
+        return self._fetch(self.offset_C(i, j, kk), self.constants.KAPPA_2)
+
+    def fetch_D_ijk(self, i, j, kk):
+        return self._fetch(self.offset_D(i, j, kk), self.constants.KAPPA_2)
+
+    def _expand_into(self, vec, dst_off, count, offset):
+        self.ctx._check(self.ctx._lib.lab_crs_expand(self.ctx._h, vec._h, dst_off, count, self.base_seed,
+                                                     offset & ((1 << 64) - 1), offset >> 64))
+
+    def materialize(self):
+        """Resident transform-domain A, B, C, D with exactly the rows the reference's fetch_* would return."""
+        k = self.constants
+        res = ResidentCRS(self.ctx, k)
+        self._expand_into(res.A, 0, k.KAPPA * k.N, self.offset_A(0))       # rows of A are consecutive in seed space
+        for i in range(k.R):
+            for kk in range(k.T_1):                                           # rows of one B_ik are consecutive too
+                self._expand_into(res.B, (i * k.T_1 + kk) * k.KAPPA_1 * k.KAPPA, k.KAPPA_1 * k.KAPPA, self.offset_B(i, kk, 0))
+        for i in range(k.R):
+            for j in range(i, k.R):
+                pair = self._sum_pairs(i) + (j - i)
+                for kk in range(k.T_2):
+                    self._expand_into(res.C, (pair * k.T_2 + kk) * k.KAPPA_2, k.KAPPA_2, self.offset_C(i, j, kk))
+                for kk in range(k.T_1):
+                    self._expand_into(res.Dm, (pair * k.T_1 + kk) * k.KAPPA_2, k.KAPPA_2, self.offset_D(i, j, kk))
+        return res
+
+
 class State:
     """The parts of src/structs.rs:269-286 the prover reads: phi_k[0], a_prime_k[0], b_prime_k[0]."""
 

@@ -102,6 +102,17 @@ def lib():
                                   C.POINTER(C.c_double)]
     L.orc_state_b.restype = None
     L.orc_state_b.argtypes = [C.c_uint64, C.c_size_t, C.c_size_t, u64p, u64p, u64p, u64p]
+    L.orc_chacha20_block.restype = None
+    L.orc_chacha20_block.argtypes = [np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS"),
+                                     np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")]
+    L.orc_crs_coeff.restype = C.c_uint64
+    L.orc_crs_coeff.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_int)]
+    L.orc_crs_fill.restype = None
+    L.orc_crs_fill.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_size_t, C.c_uint64, u64p]
+    L.orc_crs_offset.restype = None
+    L.orc_crs_offset.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int,
+                                 C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint64),
+                                 C.POINTER(C.c_uint64)]
     L.orc_bench_inner_product_faithful.restype = C.c_uint64
     L.orc_bench_inner_product_faithful.argtypes = [C.c_uint64, u64p, u64p, C.c_size_t, C.c_int]
     _lib = L
@@ -274,3 +285,24 @@ class ProverCase:
         s = C.c_double()
         rc = lib().orc_verify_core(C.byref(pin), C.byref(po), self.b_poly, int(bconst), float(beta_prime), C.byref(s))
         return rc, s.value
+
+
+def chacha20_block(state16):
+    st = np.ascontiguousarray(state16, dtype=np.uint32)
+    out = np.empty(16, dtype=np.uint32)
+    lib().orc_chacha20_block(st, out)
+    return out
+
+
+def crs_fill(base_seed, offset, count, q):
+    """count coefficients for seeds base_seed + offset + k (src/structs.rs:147-171)."""
+    out = np.empty(count, dtype=np.uint64)
+    lib().orc_crs_fill(bytes(base_seed), offset & ((1 << 64) - 1), offset >> 64, count, q, out)
+    return out
+
+
+def crs_offset(which, n, r, kappa, kappa1, kappa2, t1, i=0, j=0, k=0, row=0):
+    lo, hi = C.c_uint64(), C.c_uint64()
+    lib().orc_crs_offset({"A": 0, "B": 1, "C": 2, "D": 3}[which], n, r, kappa, kappa1, kappa2, t1, i, j, k, row,
+                         C.byref(lo), C.byref(hi))
+    return (hi.value << 64) | lo.value

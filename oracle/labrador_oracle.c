@@ -623,6 +623,100 @@ int orc_verify_core(const orc_prove_in *in, const orc_prove_out *pf, const uint6
   return fail;
 }
 
+/* ------------------------------------------------ CRS random oracle */
+
+#define ROTL32(x, n) (((x) << (n)) | ((x) >> (32 - (n))))
+#define QR(a, b, c, d) \
+  a += b; d ^= a; d = ROTL32(d, 16); c += d; b ^= c; b = ROTL32(b, 12); \
+  a += b; d ^= a; d = ROTL32(d, 8);  c += d; b ^= c; b = ROTL32(b, 7);
+
+void orc_chacha20_block(const uint32_t st[16], uint32_t out[16]) { /* RFC 7539 section 2.3 */
+  uint32_t x[16];
+  memcpy(x, st, sizeof x);
+  for (int i = 0; i < 10; i++) {
+    QR(x[0], x[4], x[8], x[12]) QR(x[1], x[5], x[9], x[13]) QR(x[2], x[6], x[10], x[14]) QR(x[3], x[7], x[11], x[15])
+    QR(x[0], x[5], x[10], x[15]) QR(x[1], x[6], x[11], x[12]) QR(x[2], x[7], x[8], x[13]) QR(x[3], x[4], x[9], x[14])
+  }
+  for (int i = 0; i < 16; i++) out[i] = x[i] + st[i];
+}
+
+static int clz128(u128 x) {
+  uint64_t hi = (uint64_t)(x >> 64), lo = (uint64_t)x;
+  if (hi) return __builtin_clzll(hi);
+  return 64 + (lo ? __builtin_clzll(lo) : 64);
+}
+
+/* src/structs.rs:167-171.  ChaCha20Rng::from_seed: key = the 32 seed bytes as little-endian words, 64-bit block
+ * counter from 0, 64-bit stream id 0.  gen_range(0..Q) on i128 -> UniformInt::sample_single_inclusive(0, Q-1):
+ *   range = Q; zone = (range << range.leading_zeros()) - 1;
+ *   loop { v = next_u64() | next_u64() << 64; (hi, lo) = v.wmul(range); if lo <= zone { return hi } } */
+uint64_t orc_crs_coeff(const uint8_t seed[32], uint64_t q, int *draws) {
+  uint32_t st[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+  for (int i = 0; i < 8; i++)
+    st[4 + i] = (uint32_t)seed[4 * i] | ((uint32_t)seed[4 * i + 1] << 8) | ((uint32_t)seed[4 * i + 2] << 16) | ((uint32_t)seed[4 * i + 3] << 24);
+  st[14] = st[15] = 0;
+  const u128 range = q;
+  const u128 zone = (range << clz128(range)) - 1;
+  uint32_t blk[16];
+  int nd = 0;
+  for (uint64_t counter = 0;; counter++) {
+    st[12] = (uint32_t)counter;
+    st[13] = (uint32_t)(counter >> 32);
+    orc_chacha20_block(st, blk);
+    for (int d = 0; d < 4; d++) { /* 4 u128 candidates per 16-word block */
+      uint64_t x = (uint64_t)blk[4 * d] | ((uint64_t)blk[4 * d + 1] << 32);
+      uint64_t y = (uint64_t)blk[4 * d + 2] | ((uint64_t)blk[4 * d + 3] << 32);
+      nd++;
+      /* 256-bit product (y*2^64 + x) * range, range < 2^64 */
+      u128 a = (u128)x * (uint64_t)range, b = (u128)y * (uint64_t)range;
+      u128 t = (a >> 64) + (uint64_t)b;
+      u128 lo = (t << 64) | (uint64_t)a;
+      u128 hi = (b >> 64) + (t >> 64);
+      if (lo <= zone) {
+        if (draws) *draws = nd;
+        return (uint64_t)hi;
+      }
+    }
+  }
+}
+
+/* 256-bit big-endian seed arithmetic: BigUint::from_bytes_be(base) + increment (src/structs.rs:59-68), then
+ * increment_seed per coefficient (:155-165; wraps silently at 2^256 like the byte loop does) */
+static void seed_add(uint8_t s[32], u128 inc) {
+  unsigned carry = 0;
+  for (int i = 31; i >= 0; i--) {
+    unsigned add = (i >= 16) ? (unsigned)((inc >> (8 * (31 - i))) & 0xff) : 0;
+    unsigned v = s[i] + add + carry;
+    s[i] = (uint8_t)v;
+    carry = v >> 8;
+  }
+}
+
+void orc_crs_fill(const uint8_t base_seed[32], uint64_t off_lo, uint64_t off_hi, size_t count, uint64_t q, uint64_t *out) {
+  uint8_t s[32];
+  memcpy(s, base_seed, 32);
+  seed_add(s, ((u128)off_hi << 64) | off_lo);
+  for (size_t k = 0; k < count; k++) {
+    out[k] = orc_crs_coeff(s, q, NULL);
+    seed_add(s, 1);
+  }
+}
+
+void orc_crs_offset(int which, size_t n, size_t r, size_t kappa, size_t kappa1, size_t kappa2, int t1,
+                    size_t i, size_t j, size_t k, size_t row, uint64_t *lo, uint64_t *hi) {
+  u128 N = n, R = r, K = kappa, K1 = kappa1, K2 = kappa2, T1 = (u128)t1, Dd = D;
+  u128 offset_A = K * N * Dd;                                   /* :78, :94, :120 */
+  u128 size_B = K1 * K;                                         /* :81 — in polynomials, not coefficients (sic) */
+  u128 sum_pairs = i > 0 ? (u128)i * R - ((u128)i * (i - 1)) / 2 : 0; /* :101-105 */
+  u128 inc = 0;
+  if (which == 0) inc = (u128)row * (N * Dd);                                                       /* :62 */
+  else if (which == 1) inc = offset_A + ((u128)i * T1 + k) * size_B + (u128)row * (K * Dd);          /* :82 */
+  else if (which == 2) inc = offset_A + (R * T1) * size_B * Dd + ((u128)k + T1 * (sum_pairs + (j - i))) * (K2 * Dd); /* :106-108 (T_1, sic) */
+  else inc = offset_A + (R * T1) * size_B * Dd + (R * (R + 1) / 2) * (K2 * Dd) + ((u128)k + T1 * (sum_pairs + (j - i))) * (K2 * Dd); /* :127-138 */
+  *lo = (uint64_t)inc;
+  *hi = (uint64_t)(inc >> 64);
+}
+
 /* ------------------------------------------------ timed baseline */
 
 uint64_t orc_bench_inner_product_faithful(uint64_t q, const uint64_t *v1, const uint64_t *v2, size_t len, int reps) {

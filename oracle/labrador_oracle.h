@@ -169,6 +169,23 @@ int orc_verify_core(const orc_prove_in *in, const orc_prove_out *proof, const ui
 void orc_state_b(uint64_t q, size_t n, size_t r, const uint64_t *S, const uint64_t *phi,
                  const uint64_t *a, uint64_t *b_out);
 
+/* ---- CRS random oracle (src/structs.rs:27-190) — SURVEY §8(f) row f1 ----------------
+ * Every coefficient is `ChaCha20Rng::from_seed(seed).gen_range(0..Q)` on i128 with a 256-bit big-endian seed
+ * that is incremented once per coefficient (src/structs.rs:35-45, 155-171).  The ChaCha20 block function is
+ * pinned by RFC 7539 / djb test vectors (tests/test_crs.py); the rand_chacha 0.3.1 word order and rand 0.8.5
+ * `UniformInt<i128>::sample_single` (Lemire widening multiply with the `(range << lz) - 1` zone) are restated
+ * from their published algorithms — those crates are not in the reference tree, so that part is PARITY UNPINNED. */
+void orc_chacha20_block(const uint32_t state[16], uint32_t out[16]);
+/* one coefficient from one 32-byte seed; *draws (optional) = number of u128 candidates consumed */
+uint64_t orc_crs_coeff(const uint8_t seed[32], uint64_t q, int *draws);
+/* out[k] = coefficient for seed = base_seed + offset + k  (offset = off_hi*2^64 + off_lo), k < count */
+void orc_crs_fill(const uint8_t base_seed[32], uint64_t off_lo, uint64_t off_hi, size_t count, uint64_t q, uint64_t *out);
+/* seed offsets, in coefficient units, of the reference's fetch_* (copied literally, including their
+ * inconsistent scaling): which = 0: fetch_A_row(row) :62 | 1: fetch_B_ik_row(i,k,row) :78-82 |
+ * 2: fetch_C_ijk(i,j,k) :94-108 | 3: fetch_D_ijk(i,j,k) :120-138.  Result as lo/hi of a u128. */
+void orc_crs_offset(int which, size_t n, size_t r, size_t kappa, size_t kappa1, size_t kappa2, int t1,
+                    size_t i, size_t j, size_t k, size_t row, uint64_t *lo, uint64_t *hi);
+
 /* ---- timed CPU baselines (bench.py cpu_baseline leg) ------------------ */
 /* B0: `count` reference-faithful inner-product terms (polymul_faithful + add);
  * returns a checksum so the work cannot be optimised away. */

@@ -329,3 +329,69 @@ def prove_core(R, p):
     out.update(t=t, G=G, H=H, u1=u1, u2=u2, proj_int=proj_int, proj=proj, bpp=bpp, z=z,
                jl_valid=jl_valid, bpp_ok=bpp_ok, phi_final=phif)
     return out
+
+
+# ---------------------------------------------------------------- CRS random oracle (src/structs.rs:27-190)
+# ChaCha20 block function: RFC 7539 section 2.3.  Word order / u128 assembly / gen_range: rand_chacha 0.3.1 and
+# rand 0.8.5 restated from their published algorithms (crates not in the reference tree -> parity unpinned).
+
+def _rotl(x, n):
+    return ((x << n) & 0xFFFFFFFF) | (x >> (32 - n))
+
+
+def _qr(s, a, b, c, d):
+    s[a] = (s[a] + s[b]) & 0xFFFFFFFF; s[d] = _rotl(s[d] ^ s[a], 16)
+    s[c] = (s[c] + s[d]) & 0xFFFFFFFF; s[b] = _rotl(s[b] ^ s[c], 12)
+    s[a] = (s[a] + s[b]) & 0xFFFFFFFF; s[d] = _rotl(s[d] ^ s[a], 8)
+    s[c] = (s[c] + s[d]) & 0xFFFFFFFF; s[b] = _rotl(s[b] ^ s[c], 7)
+
+
+def chacha20_block(state):
+    s = list(state)
+    for _ in range(10):
+        _qr(s, 0, 4, 8, 12); _qr(s, 1, 5, 9, 13); _qr(s, 2, 6, 10, 14); _qr(s, 3, 7, 11, 15)
+        _qr(s, 0, 5, 10, 15); _qr(s, 1, 6, 11, 12); _qr(s, 2, 7, 8, 13); _qr(s, 3, 4, 9, 14)
+    return [(a + b) & 0xFFFFFFFF for a, b in zip(s, state)]
+
+
+def crs_coeff(seed_int, q):
+    """generate_random_coeff (src/structs.rs:167-171) for the 256-bit big-endian seed value `seed_int`."""
+    seed = (seed_int % (1 << 256)).to_bytes(32, "big")
+    key = [int.from_bytes(seed[4 * i:4 * i + 4], "little") for i in range(8)]
+    rng_range = q
+    zone = ((rng_range << (128 - rng_range.bit_length())) - 1) & ((1 << 128) - 1)
+    counter = 0
+    while True:
+        blk = chacha20_block([0x61707865, 0x3320646E, 0x79622D32, 0x6B206574] + key +
+                             [counter & 0xFFFFFFFF, counter >> 32, 0, 0])
+        for d in range(4):
+            x = blk[4 * d] | (blk[4 * d + 1] << 32)
+            y = blk[4 * d + 2] | (blk[4 * d + 3] << 32)
+            v = x | (y << 64)
+            prod = v * rng_range
+            hi, lo = prod >> 128, prod & ((1 << 128) - 1)
+            if lo <= zone:
+                return hi
+        counter += 1
+
+
+def crs_fill(base_seed_bytes, offset, count, q):
+    base = int.from_bytes(base_seed_bytes, "big")
+    return [crs_coeff(base + offset + k, q) for k in range(count)]
+
+
+def crs_offsets(n, r, kappa, kappa1, kappa2, t1):
+    """The reference's seed offsets in coefficient units, copied literally (src/structs.rs:62, 78-82, 94-108, 120-138)."""
+    offset_A = kappa * n * D
+    size_B = kappa1 * kappa
+
+    def pairs(i):
+        return i * r - (i * (i - 1)) // 2 if i > 0 else 0
+
+    return {
+        "A": lambda row: row * (n * D),
+        "B": lambda i, k, row: offset_A + (i * t1 + k) * size_B + row * (kappa * D),
+        "C": lambda i, j, k: offset_A + (r * t1) * size_B * D + (k + t1 * (pairs(i) + (j - i))) * (kappa2 * D),
+        "D": lambda i, j, k: offset_A + (r * t1) * size_B * D + (r * (r + 1) // 2) * (kappa2 * D) +
+        (k + t1 * (pairs(i) + (j - i))) * (kappa2 * D),
+    }

@@ -1,0 +1,155 @@
+"""CRS random oracle (src/structs.rs:27-190).  CPU part: the ChaCha20 block function against
+the RFC 7539 / djb known-answer vectors and (when available) an independent OpenSSL keystream; the C and Python
+restatements of rand's seed handling + gen_range against each other; the literal seed-offset formulas.
+The rand_chacha/rand internals are restated from memory of their published algorithms: PARITY UNPINNED for
+those (documented in oracle/labrador_oracle.h)."""
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import Q_DEFAULT, Q_REF33, Q_DIRECT
+
+from oracle import coracle as co
+from oracle import pyref
+
+SIGMA = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574]
+D = 64
+
+
+def test_chacha20_block_known_answers():
+    # all-zero key/nonce, block counter 0 (djb's original vector; also rand_chacha's test_chacha_true_values_a)
+    want0 = bytes.fromhex("76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7"
+                          "da41597c5157488d7724e03fb8d84a376a43b8f41518a11cc387b669b2ee6586")
+    st = SIGMA + [0] * 12
+    assert struct.pack("<16I", *[int(x) for x in co.chacha20_block(st)]) == want0
+    assert struct.pack("<16I", *pyref.chacha20_block(st)) == want0
+    # RFC 7539 section 2.3.2: key 00..1f, counter 1, nonce 00:00:00:09:00:00:00:4a:00:00:00:00
+    want1 = bytes.fromhex("10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4e"
+                          "d2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e")
+    st = SIGMA + list(struct.unpack("<8I", bytes(range(32)))) + [1, 0x09000000, 0x4A000000, 0]
+    assert struct.pack("<16I", *[int(x) for x in co.chacha20_block(st)]) == want1
+    assert struct.pack("<16I", *pyref.chacha20_block(st)) == want1
+
+
+@pytest.mark.skipif(shutil.which("openssl") is None, reason="openssl CLI not available")
+def test_chacha20_block_matches_openssl_keystream():
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        key = bytes(int(x) for x in rng.integers(0, 256, 32))
+        # OpenSSL's 16-byte IV = 32-bit LE counter || 96-bit nonce; all zero = rand_chacha's counter 0, stream 0
+        ks = subprocess.run(["openssl", "enc", "-chacha20", "-K", key.hex(), "-iv", "00" * 16],
+                            input=bytes(128), capture_output=True, check=True).stdout
+        for counter in (0, 1):
+            st = SIGMA + list(struct.unpack("<8I", key)) + [counter, 0, 0, 0]
+            assert struct.pack("<16I", *[int(x) for x in co.chacha20_block(st)]) == ks[64 * counter:64 * counter + 64]
+
+
+@pytest.mark.parametrize("q", [Q_DEFAULT, Q_REF33, Q_DIRECT])
+def test_crs_fill_twins_agree_and_are_uniform_enough(q):
+    base = bytes(range(100, 132))
+    got = co.crs_fill(base, 12345, 300, q)
+    want = pyref.crs_fill(base, 12345, 300, q)
+    assert [int(x) for x in got] == want
+    assert all(0 <= x < q for x in want)
+    # consecutive offsets continue the same stream (fetch_next_n, src/structs.rs:147-153)
+    assert np.array_equal(co.crs_fill(base, 12345 + 100, 50, q), got[100:150])
+
+
+def test_seed_addition_carries_across_the_256_bit_seed():
+    q = Q_DEFAULT
+    base = bytes([0] * 15 + [0xFF] * 17)             # low 136 bits all ones: +1 carries into byte 14
+    a = co.crs_fill(base, 0, 3, q)
+    b = pyref.crs_fill(base, 0, 3, q)
+    assert [int(x) for x in a] == b
+    big = (1 << 100) + 77                             # offsets beyond 64 bits (reference kappa puts B offsets near 2^45..)
+    assert [int(x) for x in co.crs_fill(base, big, 2, q)] == pyref.crs_fill(base, big, 2, q)
+
+
+def test_rejection_sampling_is_exercised_at_33_bit_q():
+    # at Q = 2^32+15 the zone is ~2^127: about half of the u128 candidates are rejected
+    import ctypes as C
+    draws = []
+    for k in range(200):
+        d = C.c_int()
+        seed = (k * 7919 + 3).to_bytes(32, "big")
+        co.lib().orc_crs_coeff(seed, Q_REF33, C.byref(d))
+        draws.append(d.value)
+    assert max(draws) >= 3 and 1.6 < sum(draws) / len(draws) < 2.6
+
+
+def test_offsets_copied_literally():
+    n, r, kappa, kappa1, kappa2, t1 = 2, 2, 128, 128, 128, 4      # RuntimeConstants::new(2,2) at Q = 8191
+    off = pyref.crs_offsets(n, r, kappa, kappa1, kappa2, t1)
+    assert co.crs_offset("A", n, r, kappa, kappa1, kappa2, t1, row=5) == off["A"](5) == 5 * n * D
+    for (i, k, row) in ((0, 0, 0), (1, 3, 7), (1, 0, 127)):
+        assert co.crs_offset("B", n, r, kappa, kappa1, kappa2, t1, i=i, k=k, row=row) == off["B"](i, k, row)
+    for (i, j, k) in ((0, 0, 0), (0, 1, 1), (1, 1, 1)):
+        assert co.crs_offset("C", n, r, kappa, kappa1, kappa2, t1, i=i, j=j, k=k) == off["C"](i, j, k)
+        assert co.crs_offset("D", n, r, kappa, kappa1, kappa2, t1, i=i, j=j, k=k) == off["D"](i, j, k)
+    # the B matrices are spaced kappa1*kappa apart although each consumes kappa1*kappa*64 seeds (sic, :81)
+    assert off["B"](0, 1, 0) - off["B"](0, 0, 0) == kappa1 * kappa
+
+
+# ------------------------------------------------------------------ GPU side
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", [Q_DEFAULT, Q_REF33, Q_DIRECT])
+def test_gpu_crs_expand_matches_oracle(contexts, q):
+    import labrador_snark_amd as lab
+    ctx = contexts(q)
+    base = bytes(range(7, 39))
+    k = lab.RuntimeConstants(q, 2, 2, 4, 3, 3)
+    crs = lab.CRS(ctx, k, base)
+    # coefficient-form fetches vs the oracle at the same literal offsets
+    row = crs.fetch_A_row(3)
+    assert np.array_equal(row.ravel(), co.crs_fill(base, co.crs_offset("A", 2, 2, 4, 3, 3, k.T_1, row=3), 2 * D, q))
+    b = crs.fetch_B_ik_row(1, 2, 1)
+    assert np.array_equal(b.ravel(), co.crs_fill(base, co.crs_offset("B", 2, 2, 4, 3, 3, k.T_1, i=1, k=2, row=1), 4 * D, q))
+    c = crs.fetch_C_ijk(0, 1, 1)
+    assert np.array_equal(c.ravel(), co.crs_fill(base, co.crs_offset("C", 2, 2, 4, 3, 3, k.T_1, i=0, j=1, k=1), 3 * D, q))
+    d = crs.fetch_D_ijk(1, 1, 0)
+    assert np.array_equal(d.ravel(), co.crs_fill(base, co.crs_offset("D", 2, 2, 4, 3, 3, k.T_1, i=1, j=1, k=0), 3 * D, q))
+    # a longer stream with a carry-heavy seed and an offset beyond 64 bits
+    base2 = bytes([0] * 15 + [0xFF] * 17)
+    crs2 = lab.CRS(ctx, k, base2)
+    big = (1 << 70) + 12345
+    got = crs2._fetch(big, 40)
+    assert np.array_equal(got.ravel(), co.crs_fill(base2, big, 40 * D, q))
+
+
+@pytest.mark.gpu
+def test_gpu_prove_on_seed_addressed_crs_matches_oracle(contexts):
+    # the reference's own flow: CRS::new(seed) -> proof_gen fetches rows from the seed (src/main.rs:82-97)
+    import labrador_snark_amd as lab
+    import cases
+    q, n, r, kappa, kappa1 = Q_REF33, 2, 2, 5, 4
+    ctx = contexts(q)
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, kappa1)
+    base = bytes((i * 37 + 11) % 256 for i in range(32))
+    crs = lab.CRS(ctx, k, base)
+    S, phi, a, tape = cases.make_inputs(p, seed=41)
+    # oracle side: expand the same matrices with the oracle's CRS restatement at the reference's offsets
+    off = lambda which, **kw: co.crs_offset(which, n, r, kappa, kappa1, kappa1, p.t1, **kw)
+    A = np.stack([co.crs_fill(base, off("A", row=rho), n * D, q).reshape(n, D) for rho in range(kappa)])
+    B = np.stack([np.stack([co.crs_fill(base, off("B", i=m // p.t1, k=m % p.t1, row=rho), kappa * D, q).reshape(kappa, D)
+                            for rho in range(kappa1)]) for m in range(r * p.t1)])
+    pairs = [(i, j) for i in range(r) for j in range(i, r)]
+    C = np.stack([co.crs_fill(base, off("C", i=i, j=j, k=kk), kappa1 * D, q).reshape(kappa1, D)
+                  for (i, j) in pairs for kk in range(p.t2)])
+    Dm = np.stack([co.crs_fill(base, off("D", i=i, j=j, k=kk), kappa1 * D, q).reshape(kappa1, D)
+                   for (i, j) in pairs for kk in range(p.t1)])
+    case = co.ProverCase(q, n, r, kappa, kappa1, kappa1, p.b1, p.t1, p.b2, p.t2, p.beta_bound, S, phi, a, A, B, C, Dm,
+                         tape["Pi"], tape["psi"], tape["omega"], tape["alpha"], tape["beta"], tape["c"])
+    want = case.prove()
+    assert want["jl_valid"] and want["bpp_ok"]
+    res = crs.materialize()
+    assert np.array_equal(res.A.store().reshape(kappa, n, D), A)
+    assert np.array_equal(res.B.store().reshape(B.shape), B)
+    T = lab.prove_core(ctx, k, S, lab.State(phi, a, case.b_prime), res, tape)
+    res.close()
+    assert np.array_equal(T.u_1, want["u1"]) and np.array_equal(T.u_2, want["u2"])
+    assert np.array_equal(T.t_i_all, want["t"]) and np.array_equal(T.z, want["z"])
+    assert np.array_equal(T.h_mat, want["H"]) and np.array_equal(T.g_mat, want["G"])
