@@ -248,6 +248,17 @@ typedef struct {
  * LAB_ERR_BPP_CHECK when verify_b_prime_prime's assertion would fire (src/verification.rs:550). */
 int lab_prove_core(lab_ctx *ctx, const lab_prove_input *in, lab_transcript *out);
 
+/* ---- Verifier::verify (src/verification.rs:25-438) on the same kernels — SURVEY §8(f) row f3 ----
+ * `in` carries the state, the tape stored in the transcript (pi_i_all as int8, psi, omega, alpha, beta, c) and the
+ * resident CRS exactly as for lab_prove_core (S is not read and may be NULL); `proof` the computed transcript fields
+ * (u_1, projection, b_prime_prime, u_2, z, t_i_all, g_mat, h_mat; projection_int is not read).
+ * b_poly = st.b_k[0] ([64]); bconst = RuntimeConstants::B; beta_prime = RuntimeConstants::BETA_PRIME.
+ * On LAB_OK, *failed_line is 0 when every check passes, otherwise the number (8..20) of the first failing
+ * protocol line in the reference's order; *line14_sum receives the f64 norm sum of line 14, folded in the
+ * reference's order (src/verification.rs:231-255). */
+int lab_verify_core(lab_ctx *ctx, const lab_prove_input *in, const lab_transcript *proof, const uint64_t *b_poly,
+                    int64_t bconst, double beta_prime, int *failed_line, double *line14_sum);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,6 +115,8 @@ SIGNATURES = {
     "lab_sigma_inv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "lab_jl_project": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     "lab_prove_core": (C.c_int, [C.c_void_p, C.POINTER(lab_prove_input), C.POINTER(lab_transcript)]),
+    "lab_verify_core": (C.c_int, [C.c_void_p, C.POINTER(lab_prove_input), C.POINTER(lab_transcript), C.c_void_p,
+                                  C.c_int64, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
 }
 
 _lib = None

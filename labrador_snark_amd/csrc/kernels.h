@@ -85,6 +85,10 @@ hipError_t launch_symmetrize_half(uint64_t* H, const uint64_t* X, size_t r, uint
 hipError_t launch_jl_project(int64_t* proj, const int8_t* Pi, const uint64_t* S, size_t n, size_t r, hipStream_t s);
 hipError_t launch_phi_pi_part(uint64_t* W, const int8_t* Pi, const uint64_t* omega, size_t n, size_t r, uint64_t q,
                               hipStream_t s);
+hipError_t launch_compare_u64(unsigned int* flag, const uint64_t* a, const uint64_t* b, size_t nwords, hipStream_t s);
+hipError_t launch_symmetry_u64(unsigned int* flag, const uint64_t* X, size_t r, hipStream_t s);
+hipError_t launch_check18(uint64_t* res, const uint64_t* s1, const uint64_t* H, const uint64_t* b, size_t r, uint64_t q,
+                          hipStream_t s);
 
 // ---- crs_kernels.hip: CRS::random_oracle_gen on the device (src/structs.rs:35-45, 147-171)
 hipError_t launch_crs_expand(uint64_t* coeffs, size_t count, const uint8_t base_seed[32], uint64_t off_lo,

@@ -277,3 +277,59 @@ hipError_t launch_phi_pi_part(uint64_t* W, const int8_t* Pi, const uint64_t* ome
 }
 
 }  // namespace lab
+
+namespace lab {
+
+// ---- small helpers for the verifier (src/verification.rs:157-178, 291, 312, 332, 350, 413, 433)
+// flag[0] += number of mismatching words (0 = equal)
+__global__ void __launch_bounds__(256)
+k_compare_u64(unsigned int* __restrict__ flag, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, size_t nwords) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  unsigned int bad = 0;
+  for (; i < nwords; i += stride) bad += a[i] != b[i] ? 1u : 0u;
+  if (bad) atomicAdd(flag, bad);
+}
+
+hipError_t launch_compare_u64(unsigned int* flag, const uint64_t* a, const uint64_t* b, size_t nwords, hipStream_t s) {
+  if (nwords == 0) return hipSuccess;
+  unsigned blocks = (unsigned)((nwords + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_compare_u64, dim3(blocks), dim3(256), 0, s, flag, a, b, nwords);
+  return hipGetLastError();
+}
+
+// X[i][j] == X[j][i] for an [r][r][64] array (checks 8 and 9)
+__global__ void __launch_bounds__(256)
+k_symmetry_u64(unsigned int* __restrict__ flag, const uint64_t* __restrict__ X, unsigned r) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)r * r * D;
+  if (idx >= n) return;
+  const unsigned c = idx % D, e = idx / D, i = e / r, j = e % r;
+  if (X[idx] != X[((size_t)j * r + i) * D + c]) atomicAdd(flag, 1u);
+}
+
+hipError_t launch_symmetry_u64(unsigned int* flag, const uint64_t* X, size_t r, hipStream_t s) {
+  if (r == 0) return hipSuccess;
+  size_t n = r * r * D;
+  hipLaunchKernelGGL(k_symmetry_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, flag, X, (unsigned)r);
+  return hipGetLastError();
+}
+
+// check 18 (src/verification.rs:340-352): res = s1 + sum_i H[i][i] - b  (one polynomial, mod q)
+__global__ void k_check18(uint64_t* __restrict__ res, const uint64_t* __restrict__ s1, const uint64_t* __restrict__ H,
+                          const uint64_t* __restrict__ b, unsigned r, uint64_t q) {
+  const unsigned c = threadIdx.x;
+  if (c >= D) return;
+  uint64_t acc = s1[c];
+  for (unsigned i = 0; i < r; i++) acc = addmod(acc, H[((size_t)i * r + i) * D + c], q);
+  res[c] = submod(acc, b[c], q);
+}
+
+hipError_t launch_check18(uint64_t* res, const uint64_t* s1, const uint64_t* H, const uint64_t* b, size_t r, uint64_t q,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(k_check18, dim3(1), dim3(64), 0, s, res, s1, H, b, (unsigned)r, q);
+  return hipGetLastError();
+}
+
+}  // namespace lab

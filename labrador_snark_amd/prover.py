@@ -226,3 +226,59 @@ def prove_core(ctx, k, witness, st, crs, tape, device_outputs=False):
     ctx._check(ctx._lib.lab_prove_core(ctx._h, C.byref(pin), C.byref(tr)))
     T.tape = tape
     return T
+
+
+def verify_core(ctx, k, st, b_poly, crs, T, tape=None):
+    """Verifier::verify (src/verification.rs:25-438) on the GPU via lab_verify_core.
+    Returns (failed_line, line14_sum): failed_line == 0 means the reference would return true, otherwise it is
+    the number of the first failing protocol line.  `T` is a Transcript (or any object with its fields)."""
+    tape = tape if tape is not None else T.tape
+    n, r = k.N, k.R
+    pin = _lib.lab_prove_input()
+    pin.n, pin.r, pin.kappa, pin.kappa1, pin.kappa2 = n, r, k.KAPPA, k.KAPPA_1, k.KAPPA_2
+    pin.b1, pin.b2, pin.t1, pin.t2, pin.beta_bound = k.B_1, k.B_2, k.T_1, k.T_2, k.BETA_BOUND
+    keep = []
+
+    def p64(a):
+        a = _as_u64(a)
+        keep.append(a)
+        return _ptr(a)
+
+    pin.S = None
+    pin.phi, pin.a = p64(st.phi), p64(st.a)
+    pin.b_prime = st.b_prime
+    pin.A, pin.B, pin.C, pin.Dm = crs.A._h, crs.B._h, crs.C._h, crs.Dm._h
+    pin.a_off = pin.b_off = pin.c_off = pin.d_off = 0
+    Pi = tape["Pi"]
+    if isinstance(Pi, np.ndarray):
+        Pi = np.ascontiguousarray(Pi, dtype=np.int8)
+    keep.append(Pi)
+    pin.Pi = _ptr(Pi)
+    pin.psi = int(tape["psi"])
+    pin.omega, pin.alpha, pin.beta, pin.c = p64(tape["omega"]), p64(tape["alpha"]), p64(tape["beta"]), p64(tape["c"])
+    tr = _lib.lab_transcript()
+    for name in ("u_1", "projection", "b_prime_prime", "u_2", "z", "t_i_all", "g_mat", "h_mat"):
+        setattr(tr, name, p64(getattr(T, name)))
+    tr.projection_int = None
+    line, s14 = C.c_int(-1), C.c_double()
+    ctx._check(ctx._lib.lab_verify_core(ctx._h, C.byref(pin), C.byref(tr), p64(b_poly), int(k.B), float(k.BETA_PRIME),
+                                        C.byref(line), C.byref(s14)))
+    return line.value, s14.value
+
+
+class Verifier:
+    """Mirror of src/verification.rs:12-23: `Verifier::new(b_prime_k, &constants)`; verify() runs on the GPU.
+    The challenge samplers stay host-side objects supplied by the caller (they are the interactive verifier)."""
+
+    def __init__(self, b_prime_k, constants, ctx):
+        self.b_prime, self.constants, self.ctx = b_prime_k, constants, ctx
+
+    def verify(self, st, b_poly, proof, crs, beta_prime=None):
+        """-> bool, like Verifier::verify(&self, &State, &Transcript, &mut CRS)."""
+        k = self.constants
+        if beta_prime is not None:
+            import copy
+            k = copy.copy(k)
+            k.BETA_PRIME = beta_prime
+        line, _ = verify_core(self.ctx, k, st, b_poly, crs, proof)
+        return line == 0

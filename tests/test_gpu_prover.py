@@ -99,3 +99,43 @@ def test_prover_class_mirrors_reference_call_shape(contexts):
     want = case.prove()
     assert np.array_equal(T.u_1, want["u1"]) and np.array_equal(T.u_2, want["u2"]) and np.array_equal(T.z, want["z"])
     crs.close()
+
+
+@pytest.mark.parametrize("q,n,r,kappa,kappa1", [(Q_DEFAULT, 2, 2, 4, 3), (Q_REF33, 2, 2, 5, 4), (Q_REF33, 4, 3, 6, 5),
+                                               (Q_DIRECT, 3, 2, 7, 4), (Q_REF33, 16, 8, 24, 16)])
+def test_verify_core_matches_oracle_verifier(contexts, q, n, r, kappa, kappa1):
+    # Verifier::verify (src/verification.rs:25-438) on the GPU: same verdict, same failing line and the same
+    # f64 line-14 norm sum (bit-for-bit: the exact integer norms are folded in the reference's order) as the oracle
+    import copy
+    import labrador_snark_amd as lab
+    ctx = contexts(q)
+    p = cases.Params(q, n, r, kappa, kappa1)
+    case, (S, phi, a, tape) = cases.oracle_case(p, seed=21)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
+    crs = lab.ResidentCRS(ctx, k).fill_synthetic(1000)
+    st = lab.State(phi, a, case.b_prime)
+    T = lab.prove_core(ctx, k, S, st, crs, tape)
+    proof = dict(t=T.t_i_all, G=T.g_mat, H=T.h_mat, u1=T.u_1, u2=T.u_2, proj_int=T.projection_int, proj=T.projection,
+                 bpp=T.b_prime_prime, z=T.z)
+    kinf = copy.copy(k); kinf.BETA_PRIME = float("inf")
+    line, s14 = lab.verify_core(ctx, kinf, st, case.b_poly, crs, T)
+    orc_line, orc_s14 = case.verify(proof, k.B, float("inf"))
+    assert (line, s14) == (orc_line, orc_s14) == (0, orc_s14)
+    # line 14 with a bound just below / at the sum
+    ktight = copy.copy(k); ktight.BETA_PRIME = s14
+    assert lab.verify_core(ctx, ktight, st, case.b_poly, crs, T)[0] == 0
+    ktight.BETA_PRIME = float(np.nextafter(s14, 0.0))
+    assert lab.verify_core(ctx, ktight, st, case.b_poly, crs, T)[0] == 14
+    # tampering: the GPU verifier reports the same first failing line as the oracle
+    for field, okey, idx in (("z", "z", (0, 0)), ("u_1", "u1", (0, 3)), ("u_2", "u2", (1, 0)), ("t_i_all", "t", (0, 0, 0)),
+                             ("g_mat", "G", (0, 1, 2)), ("h_mat", "H", (1, 0, 5)), ("b_prime_prime", "bpp", (7,))):
+        T2 = copy.copy(T)
+        arr = getattr(T, field).copy()
+        arr[idx] = (int(arr[idx]) + 1) % q
+        setattr(T2, field, arr)
+        bad = dict(proof); bad[okey] = arr
+        got = lab.verify_core(ctx, kinf, st, case.b_poly, crs, T2)[0]
+        want = case.verify(bad, k.B, float("inf"))[0]
+        assert got == want != 0, (field, got, want)
+    assert lab.Verifier([case.b_prime], k, ctx).verify(st, case.b_poly, T, crs, beta_prime=float("inf")) is True
+    crs.close()
