@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--kappa", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-compact-crs", action="store_true", help="keep B, C, D in the main RNS basis (12 B/coefficient at the 33-bit q)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -141,7 +142,8 @@ def main():
     dtape = dict(Pi=torch.from_numpy(tape["Pi"]).to(dev), psi=tape["psi"], omega=dev64(tape["omega"]),
                  alpha=dev64(tape["alpha"]), beta=dev64(tape["beta"]), c=dev64(tape["c"]))
     st = lab.State(dphi, da, b_prime)
-    crs = lab.ResidentCRS(ctx, k).fill_synthetic(1000 + 10 * rank)
+    # B, C, D are only ever multiplied by decomposition digits: keep them in the digit basis (u16 small limb)
+    crs = lab.ResidentCRS(ctx, k, compact=not args.no_compact_crs).fill_synthetic(1000 + 10 * rank)
     torch.cuda.synchronize()
 
     def step():

@@ -101,6 +101,24 @@ int lab_ctx_synchronize(lab_ctx *ctx);
 int lab_ctx_profile_begin(lab_ctx *ctx);
 int lab_ctx_profile_end(lab_ctx *ctx, double *kernel_ms, uint64_t *launches, double *algorithmic_bytes);
 
+/* Digit basis (no reference counterpart; a storage/bandwidth optimisation).  The outer commitments multiply CRS
+ * matrices by decomposition DIGITS (< b_1, b_2 ~ 2^11, src/util.rs:389-442), so their exact integer results need
+ * far fewer CRT bits than products of two canonical elements.  After this call the context also owns a second,
+ * smaller RNS basis — a prefix of the main limb primes plus, when it saves space, one NTT prime below 2^16 —
+ * that is exact for up to `max_terms` products of a canonical element with a value < digit_bound.
+ * lab_vec_create_digit() makes vectors in that basis; with compact = 1 the small limb is stored as u16
+ * (e.g. 4+4+2 = 10 bytes per coefficient instead of 12 at q = 2^32+15).  Digit-basis vectors are accepted by
+ * lab_vec_load_u64 / _store_u64 / _fill_synthetic, lab_crs_expand, lab_pointwise, lab_matvec_sum and
+ * lab_axpy_commit (compact only as their streamed matrix M / C; the caller guarantees V / G hold digits below
+ * digit_bound) and by lab_prove_core / lab_verify_core for B, C, D.  Fails with LAB_ERR_RANGE when no smaller
+ * basis exists (e.g. q is its own NTT prime). */
+int lab_ctx_enable_digit_basis(lab_ctx *ctx, uint64_t max_terms, uint64_t digit_bound);
+/* nlimbs/primes of the digit basis; max_len = max_terms; device = 1 when the last limb is a u16-storable prime */
+int lab_ctx_digit_info(const lab_ctx *ctx, lab_info *out);
+int lab_vec_create_digit(lab_ctx *ctx, size_t count, int compact, lab_vec **out);
+/* bit 0: digit basis, bit 1: compact */
+int lab_vec_basis(const lab_vec *v);
+
 /* ---- the reference's operator seam -------------------------------------
  * (*PLAN).negacyclic_polymul(&mut prod, &lhs, &rhs) + transform_slice_u64_to_zq
  * (src/algebraic.rs:396-397; raw form benches/ntt_speed.rs:17-19), batched:

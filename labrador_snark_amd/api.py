@@ -87,6 +87,20 @@ class Context:
         import torch
         self._check(self._lib.lab_ctx_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
+    def enable_digit_basis(self, max_terms, digit_bound):
+        """Second, smaller RNS basis for reductions whose vector operand is a decomposition digit (< digit_bound):
+        see lab_ctx_enable_digit_basis.  Returns (primes, last_limb_is_u16, bytes_per_coefficient)."""
+        self._check(self._lib.lab_ctx_enable_digit_basis(self._h, int(max_terms), int(digit_bound)))
+        return self.digit_info()
+
+    def digit_info(self):
+        info = _lib.lab_info()
+        self._check(self._lib.lab_ctx_digit_info(self._h, C.byref(info)))
+        primes = [int(info.primes[i]) for i in range(int(info.nlimbs))]
+        small = bool(info.device)
+        self.digit_primes, self.digit_small = primes, small
+        return primes, small, (4 * (len(primes) - 1) + 2 if small else 4 * len(primes))
+
     def profile_begin(self):
         """Start bracketing every launch of the streaming mat-vec kernel with HIP events on the context's stream."""
         self._check(self._lib.lab_ctx_profile_begin(self._h))
@@ -120,8 +134,8 @@ class Context:
         self._check(self._lib.lab_ntt_inverse(self._h, _ptr(residues), batch))
 
     # ---- hat vectors
-    def vec(self, count):
-        return HatVec(self, count)
+    def vec(self, count, digit=False, compact=False):
+        return HatVec(self, count, digit=digit, compact=compact)
 
     def vec_from(self, coeffs):
         coeffs = _as_u64(coeffs)
@@ -133,12 +147,16 @@ class Context:
 class HatVec:
     """Device-resident ring elements in the transform domain (lab_vec)."""
 
-    def __init__(self, ctx, count):
+    def __init__(self, ctx, count, digit=False, compact=False):
         self.ctx = ctx
         h = C.c_void_p()
-        ctx._check(ctx._lib.lab_vec_create(ctx._h, int(count), C.byref(h)))
+        if digit or compact:
+            ctx._check(ctx._lib.lab_vec_create_digit(ctx._h, int(count), 1 if compact else 0, C.byref(h)))
+        else:
+            ctx._check(ctx._lib.lab_vec_create(ctx._h, int(count), C.byref(h)))
         self._h = h
         self.count = int(count)
+        self.digit, self.compact = bool(digit or compact), bool(compact)
 
     def close(self):
         if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
@@ -191,7 +209,7 @@ def polynomial_vec_inner_product(ctx, v1, v2, off1=0, off2=0, length=None, out=N
 def matvec_sum(ctx, M, V, nmat, rows, cols, m_off=0, v_off=0, out=None, out_off=0):
     """out[rho] = sum_m <M[m][rho,:], V[m][:]> — src/proofgen.rs:41-49 (nmat=1) and :101-132 (nmat=r*t1)."""
     if out is None:
-        out = HatVec(ctx, rows)
+        out = HatVec(ctx, rows, digit=M.digit)
     ctx._check(ctx._lib.lab_matvec_sum(ctx._h, out._h, out_off, M._h, m_off, nmat, rows, cols, V._h, v_off))
     return out
 
@@ -215,7 +233,7 @@ def gram(ctx, P, S, n, r, p_off=0, s_off=0, out=None, out_off=0):
 def axpy_commit(ctx, G, Cm, nterms, length, g_off=0, c_off=0, out=None, out_off=0):
     """out[rho] = sum_m G[m] * C[m][rho] (src/proofgen.rs:137-148, 364-378)."""
     if out is None:
-        out = HatVec(ctx, length)
+        out = HatVec(ctx, length, digit=Cm.digit)
     ctx._check(ctx._lib.lab_axpy_commit(ctx._h, out._h, out_off, G._h, g_off, Cm._h, c_off, nterms, length))
     return out
 

@@ -132,26 +132,26 @@ static bool build_limb_table(uint32_t p, LimbTable* t) {
   return true;
 }
 
-static void build_crt_table(const lab_ctx* c, CrtTable* t) {
+static void build_crt_table(uint64_t q, int nlimbs, const uint32_t* primes, CrtTable* t) {
   memset(t, 0, sizeof *t);
-  t->q = c->q;
-  t->nlimbs = c->nlimbs;
+  t->q = q;
+  t->nlimbs = nlimbs;
   u128 M = 1;
-  for (int a = 0; a < c->nlimbs; a++) {
-    t->p[a] = c->primes[a];
-    t->prefix_mod_q[a] = (uint64_t)(M % c->q);
-    M *= c->primes[a];
+  for (int a = 0; a < nlimbs; a++) {
+    t->p[a] = primes[a];
+    t->prefix_mod_q[a] = (uint64_t)(M % q);
+    M *= primes[a];
     for (int b = 0; b < a; b++) {
-      uint32_t g = (uint32_t)invmod_prime(c->primes[b] % c->primes[a], c->primes[a]);
+      uint32_t g = (uint32_t)invmod_prime(primes[b] % primes[a], primes[a]);
       t->ginv[a][b][0] = g;
-      t->ginv[a][b][1] = shoup(g, c->primes[a]);
+      t->ginv[a][b][1] = shoup(g, primes[a]);
     }
   }
-  t->m_mod_q = (uint64_t)(M % c->q);
+  t->m_mod_q = (uint64_t)(M % q);
   u128 h = (M - 1) / 2;
-  for (int a = 0; a < c->nlimbs; a++) {
-    t->half_digits[a] = (uint32_t)(h % c->primes[a]);
-    h /= c->primes[a];
+  for (int a = 0; a < nlimbs; a++) {
+    t->half_digits[a] = (uint32_t)(h % primes[a]);
+    h /= primes[a];
   }
 }
 
@@ -192,7 +192,7 @@ extern "C" int lab_ctx_create(uint64_t q, int device, uint64_t max_len, lab_ctx*
   }
   for (int l = 0; l < c->nlimbs; l++)
     if (!build_limb_table(c->primes[l], &c->h_tabs[l])) { delete c; return LAB_ERR_ARG; }
-  build_crt_table(c, &c->h_crt);
+  build_crt_table(c->q, c->nlimbs, c->primes, &c->h_crt);
 
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -216,6 +216,8 @@ extern "C" void lab_ctx_destroy(lab_ctx* c) {
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->d_tabs) (void)hipFree(c->d_tabs);
   if (c->d_crt) (void)hipFree(c->d_crt);
+  if (c->dg_tabs) (void)hipFree(c->dg_tabs);
+  if (c->dg_crt) (void)hipFree(c->dg_crt);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -227,6 +229,67 @@ extern "C" int lab_ctx_info(const lab_ctx* c, lab_info* out) {
   for (int l = 0; l < 4; l++) out->primes[l] = l < c->nlimbs ? c->primes[l] : 0;
   out->max_len = c->max_len;
   out->device = c->device;
+  return LAB_OK;
+}
+
+// candidates for the compact last limb: NTT-friendly primes below 2^16 (p == 1 mod 128), ascending
+static std::vector<uint32_t> small_ntt_primes() {
+  std::vector<uint32_t> v;
+  for (uint32_t p = 2 * D + 1; p < 65536; p += 2 * D)
+    if (is_prime_u64(p)) v.push_back(p);
+  return v;
+}
+
+extern "C" int lab_ctx_enable_digit_basis(lab_ctx* c, uint64_t max_terms, uint64_t digit_bound) {
+  if (!c) return LAB_ERR_ARG;
+  if (max_terms == 0 || digit_bound < 2 || digit_bound > c->q) return fail(c, LAB_ERR_ARG, "lab_ctx_enable_digit_basis: bad bounds");
+  if (c->direct) return fail(c, LAB_ERR_ARG, "lab_ctx_enable_digit_basis: q is its own NTT prime; the main basis is already minimal");
+  if (c->dg_nlimbs) return fail(c, LAB_ERR_ARG, "lab_ctx_enable_digit_basis: already enabled");
+  // smallest storage (4 B per full limb + 2 B for a small one) with M/2 >= max_terms*64*(q-1)*(digit_bound-1)
+  const u128 need = (u128)max_terms * D * (u128)(c->q - 1) * (u128)(digit_bound - 1);
+  const std::vector<uint32_t> small_primes = small_ntt_primes();
+  int best_bytes = 1 << 30, best_full = -1;
+  uint32_t best_small = 0;
+  for (int nfull = 0; nfull <= c->nlimbs; nfull++) {
+    u128 M = 1;
+    for (int l = 0; l < nfull; l++) M *= c->primes[l];
+    if ((M - 1) / 2 >= need) {
+      if (nfull > 0 && 4 * nfull < best_bytes) { best_bytes = 4 * nfull; best_full = nfull; best_small = 0; }
+      continue;
+    }
+    if (nfull == MAX_LIMBS) break;
+    for (uint32_t sp : small_primes)
+      if ((M * sp - 1) / 2 >= need) {
+        if (4 * nfull + 2 < best_bytes) { best_bytes = 4 * nfull + 2; best_full = nfull; best_small = sp; }
+        break;
+      }
+  }
+  if (best_full < 0 || best_bytes >= 4 * c->nlimbs)
+    return fail(c, LAB_ERR_RANGE, "lab_ctx_enable_digit_basis: no digit basis smaller than the main basis for these bounds");
+  c->dg_nlimbs = best_full + (best_small ? 1 : 0);
+  c->dg_small = best_small != 0;
+  for (int l = 0; l < best_full; l++) c->dg_primes[l] = c->primes[l];
+  if (best_small) c->dg_primes[best_full] = best_small;
+  c->dg_terms = max_terms;
+  c->dg_vmax = digit_bound - 1;
+  for (int l = 0; l < c->dg_nlimbs; l++)
+    if (!build_limb_table(c->dg_primes[l], &c->dg_h_tabs[l])) { c->dg_nlimbs = 0; return fail(c, LAB_ERR_ARG, "digit basis: no root of unity"); }
+  build_crt_table(c->q, c->dg_nlimbs, c->dg_primes, &c->dg_h_crt);
+  LAB_HIP(c, hipSetDevice(c->device));
+  LAB_HIP(c, hipMalloc(&c->dg_tabs, sizeof(LimbTable) * c->dg_nlimbs));
+  LAB_HIP(c, hipMalloc(&c->dg_crt, sizeof(CrtTable)));
+  LAB_HIP(c, hipMemcpy(c->dg_tabs, c->dg_h_tabs, sizeof(LimbTable) * c->dg_nlimbs, hipMemcpyHostToDevice));
+  LAB_HIP(c, hipMemcpy(c->dg_crt, &c->dg_h_crt, sizeof(CrtTable), hipMemcpyHostToDevice));
+  return LAB_OK;
+}
+
+extern "C" int lab_ctx_digit_info(const lab_ctx* c, lab_info* out) {
+  if (!c || !out) return LAB_ERR_ARG;
+  out->q = c->q;
+  out->nlimbs = c->dg_nlimbs;
+  for (int l = 0; l < 4; l++) out->primes[l] = l < c->dg_nlimbs ? c->dg_primes[l] : 0;
+  out->max_len = c->dg_terms;
+  out->device = c->dg_small ? 1 : 0;  // reused field: 1 = last limb is a u16-storable prime
   return LAB_OK;
 }
 
@@ -273,9 +336,11 @@ extern "C" int lab_ctx_profile_end(lab_ctx* c, double* kernel_ms, uint64_t* laun
   return LAB_OK;
 }
 
-int lab::matvec_partial_timed(lab_ctx* c, HatView partial, ConstHatView M, ConstHatView V, size_t nmat, size_t rows, size_t cols) {
+int lab::matvec_partial_timed(lab_ctx* c, HatView partial, ConstHatView M, ConstHatView V, size_t nmat, size_t rows, size_t cols,
+                              int nlimbs, const LimbTable* tabs) {
+  if (nlimbs <= 0) { nlimbs = c->nlimbs; tabs = c->d_tabs; }
   if (!c->prof_on) {
-    LAB_HIP(c, launch_matvec_partial(partial, M, V, nmat, rows, cols, c->nlimbs, c->d_tabs, c->stream));
+    LAB_HIP(c, launch_matvec_partial(partial, M, V, nmat, rows, cols, nlimbs, tabs, c->stream));
     return LAB_OK;
   }
   if (c->prof_used == c->prof_events.size()) {
@@ -286,9 +351,9 @@ int lab::matvec_partial_timed(lab_ctx* c, HatView partial, ConstHatView M, Const
   }
   auto& ev = c->prof_events[c->prof_used++];
   LAB_HIP(c, hipEventRecord(ev.first, c->stream));
-  LAB_HIP(c, launch_matvec_partial(partial, M, V, nmat, rows, cols, c->nlimbs, c->d_tabs, c->stream));
+  LAB_HIP(c, launch_matvec_partial(partial, M, V, nmat, rows, cols, nlimbs, tabs, c->stream));
   LAB_HIP(c, hipEventRecord(ev.second, c->stream));
-  c->prof_bytes += (double)c->nlimbs * 256.0 * ((double)nmat * rows * cols + (double)nmat * cols + (double)nmat * rows);
+  c->prof_bytes += (double)nlimbs * 256.0 * ((double)nmat * rows * cols + (double)nmat * cols + (double)nmat * rows);
   return LAB_OK;
 }
 
@@ -352,21 +417,37 @@ extern "C" int lab_ntt_forward(lab_ctx* c, uint32_t* dev, size_t batch) { return
 extern "C" int lab_ntt_inverse(lab_ctx* c, uint32_t* dev, size_t batch) { return ntt_inplace(c, dev, batch, false); }
 
 // ------------------------------------------------------------- vectors
-extern "C" int lab_vec_create(lab_ctx* c, size_t count, lab_vec** out) {
+static int vec_create(lab_ctx* c, size_t count, int basis, bool compact, lab_vec** out) {
   if (!c || !out || count == 0) return fail(c, LAB_ERR_ARG, "lab_vec_create: bad argument");
   *out = nullptr;
+  if (basis && !c->dg_nlimbs) return fail(c, LAB_ERR_ARG, "lab_vec_create_digit: call lab_ctx_enable_digit_basis first");
+  if (compact && !(basis && c->dg_small)) return fail(c, LAB_ERR_ARG, "lab_vec_create_digit: this digit basis has no u16 limb");
   LAB_HIP(c, hipSetDevice(c->device));
   lab_vec* v = new lab_vec();
   v->ctx = c;
   v->count = count;
-  hipError_t e = hipMalloc(&v->d, (size_t)c->nlimbs * count * D * sizeof(uint32_t));
+  v->basis = basis;
+  v->compact = compact;
+  // one allocation: the u32 planes, then (compact) the u16 plane
+  const size_t b32 = (size_t)v->planes32() * count * D * sizeof(uint32_t);
+  const size_t b16 = compact ? count * D * sizeof(uint16_t) : 0;
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, b32 + b16 + 256);
   if (e != hipSuccess) {
     delete v;
-    return fail(c, LAB_ERR_HIP, "hipMalloc(%zu elements x %d limbs): %s", count, c->nlimbs, hipGetErrorString(e));
+    return fail(c, LAB_ERR_HIP, "hipMalloc(%zu elements, %zu bytes): %s", count, b32 + b16, hipGetErrorString(e));
   }
+  v->d = static_cast<uint32_t*>(p);
+  v->d16 = compact ? reinterpret_cast<uint16_t*>(static_cast<char*>(p) + b32) : nullptr;
   *out = v;
   return LAB_OK;
 }
+
+extern "C" int lab_vec_create(lab_ctx* c, size_t count, lab_vec** out) { return vec_create(c, count, 0, false, out); }
+extern "C" int lab_vec_create_digit(lab_ctx* c, size_t count, int compact, lab_vec** out) {
+  return vec_create(c, count, 1, compact != 0, out);
+}
+extern "C" int lab_vec_basis(const lab_vec* v) { return v ? (v->basis | (v->compact ? 2 : 0)) : -1; }
 
 extern "C" void lab_vec_destroy(lab_vec* v) {
   if (!v) return;
@@ -377,6 +458,14 @@ extern "C" void lab_vec_destroy(lab_vec* v) {
 
 extern "C" size_t lab_vec_count(const lab_vec* v) { return v ? v->count : 0; }
 
+// operands of the transform-domain ops must be plain u32 vectors of one basis (only the streamed matrix of
+// lab_matvec_sum / lab_axpy_commit may be compact)
+static int check_plain(lab_ctx* c, const lab_vec* v, int basis, const char* what) {
+  if (v->compact) return fail(c, LAB_ERR_ARG, "%s: a compact (u16-limb) vector is only valid as the matrix of lab_matvec_sum / lab_axpy_commit", what);
+  if (v->basis != basis) return fail(c, LAB_ERR_ARG, "%s: operands live in different RNS bases", what);
+  return LAB_OK;
+}
+
 int lab::check_range(lab_ctx* c, const lab_vec* v, size_t off, size_t n, const char* what) {
   if (!v) return fail(c, LAB_ERR_ARG, "%s: null vector", what);
   if (v->ctx != c) return fail(c, LAB_ERR_ARG, "%s: vector belongs to another context", what);
@@ -385,16 +474,44 @@ int lab::check_range(lab_ctx* c, const lab_vec* v, size_t off, size_t n, const c
   return LAB_OK;
 }
 
-int lab::from_hat(lab_ctx* c, ConstHatView src, size_t count, uint32_t* tmp, uint64_t* dcoeffs) {
+int lab::from_hat(lab_ctx* c, ConstHatView src, size_t count, uint32_t* tmp, uint64_t* dcoeffs, int basis) {
   HatView t{tmp, count * D};
-  LAB_HIP(c, launch_ntt(false, src, t, count, c->nlimbs, c->d_tabs, 0, c->stream));
-  LAB_HIP(c, launch_crt_to_u64(t, dcoeffs, count, c->d_crt, c->stream));
+  LAB_HIP(c, launch_ntt(false, src, t, count, basis_nlimbs(c, basis), basis_tabs(c, basis), 0, c->stream));
+  LAB_HIP(c, launch_crt_to_u64(t, dcoeffs, count, basis_crt(c, basis), c->stream));
   return LAB_OK;
 }
 
-int lab::to_hat(lab_ctx* c, const uint64_t* dcoeffs, HatView dst, size_t count) {
-  LAB_HIP(c, launch_reduce_u64(dcoeffs, dst, count, c->nlimbs, c->d_tabs, c->stream));
-  LAB_HIP(c, launch_ntt(true, dst, dst, count, c->nlimbs, c->d_tabs, 0, c->stream));
+int lab::to_hat(lab_ctx* c, const uint64_t* dcoeffs, HatView dst, size_t count, int basis) {
+  LAB_HIP(c, launch_reduce_u64(dcoeffs, dst, count, basis_nlimbs(c, basis), basis_tabs(c, basis), c->stream));
+  LAB_HIP(c, launch_ntt(true, dst, dst, count, basis_nlimbs(c, basis), basis_tabs(c, basis), 0, c->stream));
+  return LAB_OK;
+}
+
+// coefficients (device) -> `dst` elements [dst_off, dst_off+count) in dst's basis; compact vectors go through a
+// u32 staging area (`stage32`, dst->nlimbs() * count * 64 words) and get their last plane packed to u16
+static int store_hat_from_coeffs(lab_ctx* c, const uint64_t* dcoeffs, lab_vec* dst, size_t dst_off, size_t count,
+                                 uint32_t* stage32) {
+  if (!dst->compact) return to_hat(c, dcoeffs, dst->view(dst_off), count, dst->basis);
+  HatView t{stage32, count * D};
+  int rc = to_hat(c, dcoeffs, t, count, dst->basis);
+  if (rc) return rc;
+  const int nfull = dst->planes32();
+  for (int l = 0; l < nfull; l++)
+    LAB_HIP(c, hipMemcpyAsync(dst->d + (size_t)l * dst->count * D + dst_off * D, stage32 + (size_t)l * count * D,
+                              count * D * 4, hipMemcpyDeviceToDevice, c->stream));
+  LAB_HIP(c, launch_pack_u16(dst->d16 + dst_off * D, stage32 + (size_t)nfull * count * D, count, false, nullptr, c->stream));
+  return LAB_OK;
+}
+
+int lab::matvec_partial_any(lab_ctx* c, HatView partial, const lab_vec* M, size_t m_off, ConstHatView V, size_t nmat,
+                            size_t rows, size_t cols) {
+  const int nfull = M->planes32();
+  int rc = LAB_OK;
+  if (nfull > 0 && (rc = matvec_partial_timed(c, partial, M->view(m_off), V, nmat, rows, cols, nfull, M->tabs()))) return rc;
+  if (M->compact)
+    LAB_HIP(c, launch_matvec_partial_u16(partial.base + (size_t)nfull * partial.plane_stride, M->d16 + m_off * D,
+                                         V.base + (size_t)nfull * V.plane_stride, nmat, rows, cols, M->tabs() + nfull,
+                                         c->stream));
   return LAB_OK;
 }
 
@@ -406,14 +523,17 @@ extern "C" int lab_vec_load_u64(lab_ctx* c, lab_vec* dst, size_t dst_off, const 
   if (!coeffs) return fail(c, LAB_ERR_ARG, "lab_vec_load_u64: null coefficients");
   LAB_HIP(c, hipSetDevice(c->device));
   const void* dsrc = coeffs;
-  if (!is_device_pointer(coeffs)) {
-    if ((rc = ensure_scratch(c, count * D * 8))) return rc;
-    if ((rc = stage_in(c, coeffs, c->scratch, count * D * 8, &dsrc))) return rc;
+  const bool host = !is_device_pointer(coeffs);
+  const size_t stage_bytes = dst->compact ? Carver::padded((size_t)dst->nlimbs() * count * D * 4) : 0;
+  if ((rc = ensure_scratch(c, stage_bytes + (host ? count * D * 8 : 0)))) return rc;
+  Carver cv(c->scratch);
+  uint32_t* stage32 = dst->compact ? cv.take<uint32_t>((size_t)dst->nlimbs() * count * D) : nullptr;
+  if (host) {
+    uint64_t* hs = cv.take<uint64_t>(count * D);
+    if ((rc = stage_in(c, coeffs, hs, count * D * 8, &dsrc))) return rc;
   }
-  HatView v = dst->view(dst_off);
-  LAB_HIP(c, launch_reduce_u64((const uint64_t*)dsrc, v, count, c->nlimbs, c->d_tabs, c->stream));
-  LAB_HIP(c, launch_ntt(true, v, v, count, c->nlimbs, c->d_tabs, 0, c->stream));
-  if (dsrc != coeffs) LAB_HIP(c, hipStreamSynchronize(c->stream));  // the staged host buffer may be reused by the caller
+  if ((rc = store_hat_from_coeffs(c, (const uint64_t*)dsrc, dst, dst_off, count, stage32))) return rc;
+  if (host) LAB_HIP(c, hipStreamSynchronize(c->stream));  // the staged host buffer may be reused by the caller
   return LAB_OK;
 }
 
@@ -424,15 +544,25 @@ extern "C" int lab_vec_store_u64(lab_ctx* c, const lab_vec* src, size_t src_off,
   if (count == 0) return LAB_OK;
   if (!coeffs) return fail(c, LAB_ERR_ARG, "lab_vec_store_u64: null output");
   LAB_HIP(c, hipSetDevice(c->device));
-  const size_t words = count * D, L = c->nlimbs;
+  const size_t words = count * D, L = src->nlimbs();
   const bool out_dev = is_device_pointer(coeffs);
-  if ((rc = ensure_scratch(c, Carver::padded(L * words * 4) + Carver::padded(words * 8)))) return rc;
+  if ((rc = ensure_scratch(c, 2 * Carver::padded(L * words * 4) + Carver::padded(words * 8)))) return rc;
   Carver cv(c->scratch);
   uint32_t* tmp = cv.take<uint32_t>(L * words);
+  uint32_t* unp = cv.take<uint32_t>(L * words);
   uint64_t* so = cv.take<uint64_t>(words);
   HatView t{tmp, words};
-  LAB_HIP(c, launch_ntt(false, src->view(src_off), t, count, c->nlimbs, c->d_tabs, 0, c->stream));
-  LAB_HIP(c, launch_crt_to_u64(t, out_dev ? coeffs : so, count, c->d_crt, c->stream));
+  ConstHatView sv = src->view(src_off);
+  if (src->compact) {  // rebuild dense u32 planes first
+    const int nfull = src->planes32();
+    for (int l = 0; l < nfull; l++)
+      LAB_HIP(c, hipMemcpyAsync(unp + (size_t)l * words, src->d + (size_t)l * src->count * D + src_off * D, words * 4,
+                                hipMemcpyDeviceToDevice, c->stream));
+    LAB_HIP(c, launch_pack_u16(const_cast<uint16_t*>(src->d16) + src_off * D, nullptr, count, true, unp + (size_t)nfull * words, c->stream));
+    sv = ConstHatView(unp, words);
+  }
+  LAB_HIP(c, launch_ntt(false, sv, t, count, (int)L, src->tabs(), 0, c->stream));
+  LAB_HIP(c, launch_crt_to_u64(t, out_dev ? coeffs : so, count, src->crt(), c->stream));
   if (!out_dev) {
     LAB_HIP(c, hipMemcpyAsync(coeffs, so, words * 8, hipMemcpyDeviceToHost, c->stream));
     LAB_HIP(c, hipStreamSynchronize(c->stream));
@@ -449,14 +579,15 @@ extern "C" int lab_vec_fill_synthetic(lab_ctx* c, lab_vec* dst, size_t dst_off, 
   LAB_HIP(c, hipSetDevice(c->device));
   // generate coefficient-domain residues in chunks, then transform in place
   const size_t chunk = 1u << 18;  // 128 MiB of u64 staging at most
-  if ((rc = ensure_scratch(c, (count < chunk ? count : chunk) * D * 8))) return rc;
-  uint64_t* stage = static_cast<uint64_t*>(c->scratch);
+  const size_t cn = count < chunk ? count : chunk;
+  if ((rc = ensure_scratch(c, Carver::padded(cn * D * 8) + (dst->compact ? (size_t)dst->nlimbs() * cn * D * 4 : 0)))) return rc;
+  Carver cv(c->scratch);
+  uint64_t* stage = cv.take<uint64_t>(cn * D);
+  uint32_t* stage32 = dst->compact ? cv.take<uint32_t>((size_t)dst->nlimbs() * cn * D) : nullptr;
   for (size_t done = 0; done < count; done += chunk) {
     size_t n = count - done < chunk ? count - done : chunk;
-    HatView v = dst->view(dst_off + done);
     LAB_HIP(c, launch_synth_fill_u64(stage, n, seed, first_elem + done, bound, c->stream));
-    LAB_HIP(c, launch_reduce_u64(stage, v, n, c->nlimbs, c->d_tabs, c->stream));
-    LAB_HIP(c, launch_ntt(true, v, v, n, c->nlimbs, c->d_tabs, 0, c->stream));
+    if ((rc = store_hat_from_coeffs(c, stage, dst, dst_off + done, n, stage32))) return rc;
   }
   return LAB_OK;
 }
@@ -485,16 +616,17 @@ extern "C" int lab_crs_expand(lab_ctx* c, lab_vec* dst, size_t dst_off, size_t c
   if (!base_seed) return fail(c, LAB_ERR_ARG, "lab_crs_expand: null seed");
   LAB_HIP(c, hipSetDevice(c->device));
   const size_t chunk = 1u << 18;
-  if ((rc = ensure_scratch(c, (count < chunk ? count : chunk) * D * 8))) return rc;
-  uint64_t* stage = static_cast<uint64_t*>(c->scratch);
+  const size_t cn = count < chunk ? count : chunk;
+  if ((rc = ensure_scratch(c, Carver::padded(cn * D * 8) + (dst->compact ? (size_t)dst->nlimbs() * cn * D * 4 : 0)))) return rc;
+  Carver cv(c->scratch);
+  uint64_t* stage = cv.take<uint64_t>(cn * D);
+  uint32_t* stage32 = dst->compact ? cv.take<uint32_t>((size_t)dst->nlimbs() * cn * D) : nullptr;
   for (size_t done = 0; done < count; done += chunk) {
     const size_t n = count - done < chunk ? count - done : chunk;
     // offset advances by 64 seeds per polynomial
     unsigned __int128 off = (((unsigned __int128)offset_hi << 64) | offset_lo) + (unsigned __int128)done * D;
-    HatView v = dst->view(dst_off + done);
     LAB_HIP(c, launch_crs_expand(stage, n, base_seed, (uint64_t)off, (uint64_t)(off >> 64), c->q, c->stream));
-    LAB_HIP(c, launch_reduce_u64(stage, v, n, c->nlimbs, c->d_tabs, c->stream));
-    LAB_HIP(c, launch_ntt(true, v, v, n, c->nlimbs, c->d_tabs, 0, c->stream));
+    if ((rc = store_hat_from_coeffs(c, stage, dst, dst_off + done, n, stage32))) return rc;
   }
   return LAB_OK;
 }
@@ -509,17 +641,22 @@ extern "C" int lab_matvec_sum(lab_ctx* c, lab_vec* out, size_t out_off, const la
   if ((rc = check_range(c, M, m_off, nmat * rows * cols, "lab_matvec_sum(M)"))) return rc;
   if ((rc = check_range(c, V, v_off, nmat * cols, "lab_matvec_sum(V)"))) return rc;
   if (nmat == 0 || rows == 0 || cols == 0) return fail(c, LAB_ERR_ARG, "lab_matvec_sum: empty dimension");
-  if ((u128)nmat * cols > c->max_len)
-    return fail(c, LAB_ERR_RANGE, "lab_matvec_sum: reduction length %zu exceeds the exactness bound %llu of this context",
-                nmat * cols, (unsigned long long)c->max_len);
+  const int basis = M->basis;
+  if ((rc = check_plain(c, V, basis, "lab_matvec_sum(V)")) || (rc = check_plain(c, out, basis, "lab_matvec_sum(out)"))) return rc;
+  // main basis: exact for canonical operands up to max_len terms; digit basis: exact for up to dg_terms terms
+  // provided the entries of V are digits below the bound given to lab_ctx_enable_digit_basis (caller's contract)
+  const uint64_t limit = basis ? c->dg_terms : c->max_len;
+  if ((u128)nmat * cols > limit)
+    return fail(c, LAB_ERR_RANGE, "lab_matvec_sum: reduction length %zu exceeds the exactness bound %llu of this basis",
+                nmat * cols, (unsigned long long)limit);
   if (rows > 0x7fffffffu || cols > 0x7fffffffu / 64 || nmat > 65535) return fail(c, LAB_ERR_ARG, "lab_matvec_sum: dimension too large");
   LAB_HIP(c, hipSetDevice(c->device));
-  if (nmat == 1) return matvec_partial_timed(c, out->view(out_off), M->view(m_off), V->view(v_off), 1, rows, cols);
+  if (nmat == 1) return matvec_partial_any(c, out->view(out_off), M, m_off, V->view(v_off), 1, rows, cols);
   const size_t pw = nmat * rows * D;
-  if ((rc = ensure_scratch(c, (size_t)c->nlimbs * pw * 4))) return rc;
+  if ((rc = ensure_scratch(c, (size_t)M->nlimbs() * pw * 4))) return rc;
   HatView partial{static_cast<uint32_t*>(c->scratch), pw};
-  if ((rc = matvec_partial_timed(c, partial, M->view(m_off), V->view(v_off), nmat, rows, cols))) return rc;
-  LAB_HIP(c, launch_sum_terms(out->view(out_off), partial, nmat, rows, c->nlimbs, c->d_tabs, c->stream));
+  if ((rc = matvec_partial_any(c, partial, M, m_off, V->view(v_off), nmat, rows, cols))) return rc;
+  LAB_HIP(c, launch_sum_terms(out->view(out_off), partial, nmat, rows, M->nlimbs(), M->tabs(), c->stream));
   return LAB_OK;
 }
 
@@ -551,6 +688,8 @@ extern "C" int lab_inner_product(lab_ctx* c, lab_vec* out, size_t out_off, const
   if ((rc = check_range(c, v1, off1, len, "lab_inner_product(v1)"))) return rc;
   if ((rc = check_range(c, v2, off2, len, "lab_inner_product(v2)"))) return rc;
   if (len == 0) return fail(c, LAB_ERR_ARG, "lab_inner_product: empty vectors");
+  if ((rc = check_plain(c, v1, 0, "lab_inner_product")) || (rc = check_plain(c, v2, 0, "lab_inner_product")) ||
+      (rc = check_plain(c, out, 0, "lab_inner_product"))) return rc;
   if (len > c->max_len) return fail(c, LAB_ERR_RANGE, "lab_inner_product: length %zu exceeds the exactness bound %llu of this context", len, (unsigned long long)c->max_len);
   if (len > 0x7fffffffu / 64) return fail(c, LAB_ERR_ARG, "lab_inner_product: length too large");
   LAB_HIP(c, hipSetDevice(c->device));
@@ -569,6 +708,8 @@ extern "C" int lab_ajtai_commit(lab_ctx* c, lab_vec* out, size_t out_off, const 
   if ((rc = check_range(c, out, out_off, rows * ncols, "lab_ajtai_commit(out)"))) return rc;
   if ((rc = check_range(c, A, a_off, rows * inner, "lab_ajtai_commit(A)"))) return rc;
   if ((rc = check_range(c, S, s_off, inner * ncols, "lab_ajtai_commit(S)"))) return rc;
+  if ((rc = check_plain(c, A, 0, "lab_ajtai_commit")) || (rc = check_plain(c, S, 0, "lab_ajtai_commit")) ||
+      (rc = check_plain(c, out, 0, "lab_ajtai_commit"))) return rc;
   if (inner > c->max_len) return fail(c, LAB_ERR_RANGE, "lab_ajtai_commit: reduction length %zu exceeds the exactness bound %llu", inner, (unsigned long long)c->max_len);
   LAB_HIP(c, hipSetDevice(c->device));
   LAB_HIP(c, launch_matmul_t(out->view(out_off), A->view(a_off), S->view(s_off), rows, inner, ncols, c->nlimbs, c->d_tabs, c->stream));
@@ -583,9 +724,23 @@ extern "C" int lab_gram(lab_ctx* c, lab_vec* out, size_t out_off, const lab_vec*
   if ((rc = check_range(c, out, out_off, r * r, "lab_gram(out)"))) return rc;
   if ((rc = check_range(c, P, p_off, n * r, "lab_gram(P)"))) return rc;
   if ((rc = check_range(c, S, s_off, n * r, "lab_gram(S)"))) return rc;
+  if ((rc = check_plain(c, P, 0, "lab_gram")) || (rc = check_plain(c, S, 0, "lab_gram")) || (rc = check_plain(c, out, 0, "lab_gram"))) return rc;
   if (n > c->max_len) return fail(c, LAB_ERR_RANGE, "lab_gram: reduction length %zu exceeds the exactness bound %llu", n, (unsigned long long)c->max_len);
   LAB_HIP(c, hipSetDevice(c->device));
-  LAB_HIP(c, launch_gram(out->view(out_off), P->view(p_off), S->view(s_off), n, r, c->nlimbs, c->d_tabs, c->stream));
+  const size_t chunks = gram_num_chunks(n);
+  if ((rc = ensure_scratch(c, (size_t)c->nlimbs * chunks * r * r * D * 4))) return rc;
+  return gram_impl(c, out->view(out_off), P->view(p_off), S->view(s_off), n, r,
+                   HatView{static_cast<uint32_t*>(c->scratch), chunks * r * r * D});
+}
+
+int lab::gram_impl(lab_ctx* c, HatView out, ConstHatView P, ConstHatView S, size_t n, size_t r, HatView partial) {
+  const size_t chunks = gram_num_chunks(n);
+  if (chunks == 1) {
+    LAB_HIP(c, launch_gram_tiled(out, P, S, n, r, c->nlimbs, c->d_tabs, c->stream));
+    return LAB_OK;
+  }
+  LAB_HIP(c, launch_gram_tiled(partial, P, S, n, r, c->nlimbs, c->d_tabs, c->stream));
+  LAB_HIP(c, launch_sum_terms(out, partial, chunks, r * r, c->nlimbs, c->d_tabs, c->stream));
   return LAB_OK;
 }
 
@@ -603,6 +758,19 @@ int axpy_commit_impl(lab_ctx* c, HatView out, ConstHatView G, ConstHatView C, si
 }
 }  // namespace lab
 
+int lab::axpy_commit_any(lab_ctx* c, HatView out, ConstHatView G, const lab_vec* Cm, size_t c_off, size_t nterms, size_t len,
+                         HatView partial) {
+  const size_t chunks = axpy_num_chunks(nterms);
+  HatView target = chunks == 1 ? out : partial;
+  const int nfull = Cm->planes32();
+  if (nfull > 0) LAB_HIP(c, launch_axpy_partial(target, G, Cm->view(c_off), nterms, len, nfull, Cm->tabs(), c->stream));
+  if (Cm->compact)
+    LAB_HIP(c, launch_axpy_partial_u16(target.base + (size_t)nfull * target.plane_stride, G.base + (size_t)nfull * G.plane_stride,
+                                       Cm->d16 + c_off * D, nterms, len, Cm->tabs() + nfull, c->stream));
+  if (chunks > 1) LAB_HIP(c, launch_sum_terms(out, partial, chunks, len, Cm->nlimbs(), Cm->tabs(), c->stream));
+  return LAB_OK;
+}
+
 extern "C" int lab_axpy_commit(lab_ctx* c, lab_vec* out, size_t out_off, const lab_vec* G, size_t g_off,
                                const lab_vec* Cm, size_t c_off, size_t nterms, size_t len) {
   if (!c) return LAB_ERR_ARG;
@@ -611,12 +779,15 @@ extern "C" int lab_axpy_commit(lab_ctx* c, lab_vec* out, size_t out_off, const l
   if ((rc = check_range(c, out, out_off, len, "lab_axpy_commit(out)"))) return rc;
   if ((rc = check_range(c, G, g_off, nterms, "lab_axpy_commit(G)"))) return rc;
   if ((rc = check_range(c, Cm, c_off, nterms * len, "lab_axpy_commit(C)"))) return rc;
-  if (nterms > c->max_len) return fail(c, LAB_ERR_RANGE, "lab_axpy_commit: %zu terms exceed the exactness bound %llu", nterms, (unsigned long long)c->max_len);
+  const int basis = Cm->basis;
+  if ((rc = check_plain(c, G, basis, "lab_axpy_commit(G)")) || (rc = check_plain(c, out, basis, "lab_axpy_commit(out)"))) return rc;
+  const uint64_t limit = basis ? c->dg_terms : c->max_len;
+  if (nterms > limit) return fail(c, LAB_ERR_RANGE, "lab_axpy_commit: %zu terms exceed the exactness bound %llu of this basis", nterms, (unsigned long long)limit);
   LAB_HIP(c, hipSetDevice(c->device));
   const size_t chunks = axpy_num_chunks(nterms);
-  if ((rc = ensure_scratch(c, (size_t)c->nlimbs * chunks * len * D * 4))) return rc;
-  return axpy_commit_impl(c, out->view(out_off), G->view(g_off), Cm->view(c_off), nterms, len,
-                          HatView{static_cast<uint32_t*>(c->scratch), chunks * len * D});
+  if ((rc = ensure_scratch(c, (size_t)Cm->nlimbs() * chunks * len * D * 4))) return rc;
+  return axpy_commit_any(c, out->view(out_off), G->view(g_off), Cm, c_off, nterms, len,
+                         HatView{static_cast<uint32_t*>(c->scratch), chunks * len * D});
 }
 
 extern "C" int lab_amortize_z(lab_ctx* c, lab_vec* out, size_t out_off, const lab_vec* S, size_t s_off, size_t n,
@@ -639,8 +810,10 @@ extern "C" int lab_pointwise(lab_ctx* c, lab_op op, lab_vec* out, size_t out_off
     case LAB_OP_SUB: k = PW_SUB; break;
     default: return fail(c, LAB_ERR_ARG, "lab_pointwise: unknown op %d", (int)op);
   }
+  if ((rc = check_plain(c, b, a->basis, "lab_pointwise")) || (rc = check_plain(c, out, a->basis, "lab_pointwise")) ||
+      (rc = check_plain(c, a, a->basis, "lab_pointwise"))) return rc;
   LAB_HIP(c, hipSetDevice(c->device));
-  LAB_HIP(c, launch_pointwise(k, out->view(out_off), a->view(a_off), b->view(b_off), count, c->nlimbs, c->d_tabs, c->stream));
+  LAB_HIP(c, launch_pointwise(k, out->view(out_off), a->view(a_off), b->view(b_off), count, a->nlimbs(), a->tabs(), c->stream));
   return LAB_OK;
 }
 
@@ -651,6 +824,8 @@ extern "C" int lab_poly_by_poly_vec(lab_ctx* c, lab_vec* out, size_t out_off, co
   if ((rc = check_range(c, out, out_off, len, "lab_poly_by_poly_vec(out)"))) return rc;
   if ((rc = check_range(c, p, p_off, 1, "lab_poly_by_poly_vec(p)"))) return rc;
   if ((rc = check_range(c, v, v_off, len, "lab_poly_by_poly_vec(v)"))) return rc;
+  if ((rc = check_plain(c, p, 0, "lab_poly_by_poly_vec")) || (rc = check_plain(c, v, 0, "lab_poly_by_poly_vec")) ||
+      (rc = check_plain(c, out, 0, "lab_poly_by_poly_vec"))) return rc;
   LAB_HIP(c, hipSetDevice(c->device));
   LAB_HIP(c, launch_poly_by_vec(out->view(out_off), p->view(p_off), v->view(v_off), len, c->nlimbs, c->d_tabs, c->stream));
   return LAB_OK;

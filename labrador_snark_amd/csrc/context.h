@@ -27,6 +27,17 @@ struct lab_ctx {
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
   mutable std::string err;
+  // digit basis (lab_ctx_enable_digit_basis): RNS basis for reductions whose vector operand is a decomposition
+  // digit (< dg_vmax): dg_nlimbs limbs = a prefix of the main primes plus, when dg_small, one prime < 2^16 whose
+  // matrix residues can be stored as u16 ("compact" vectors)
+  int dg_nlimbs = 0;
+  bool dg_small = false;
+  uint32_t dg_primes[lab::MAX_LIMBS] = {0, 0, 0, 0};
+  uint64_t dg_terms = 0, dg_vmax = 0;
+  lab::LimbTable* dg_tabs = nullptr;
+  lab::CrtTable* dg_crt = nullptr;
+  lab::LimbTable dg_h_tabs[lab::MAX_LIMBS];
+  lab::CrtTable dg_h_crt;
   // measurement hook (lab_ctx_profile_begin/end): HIP events around the mat-vec kernel
   bool prof_on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -37,7 +48,14 @@ struct lab_ctx {
 struct lab_vec {
   lab_ctx* ctx = nullptr;
   size_t count = 0;
-  uint32_t* d = nullptr;  // [nlimbs][count][64]
+  int basis = 0;           // 0 = main basis, 1 = digit basis
+  bool compact = false;    // digit basis only: the small last limb is stored as u16 in d16
+  uint32_t* d = nullptr;   // [planes32][count][64]
+  uint16_t* d16 = nullptr; // [count][64] when compact
+  int nlimbs() const { return basis ? ctx->dg_nlimbs : ctx->nlimbs; }
+  int planes32() const { return nlimbs() - (compact ? 1 : 0); }
+  const lab::LimbTable* tabs() const { return basis ? ctx->dg_tabs : ctx->d_tabs; }
+  const lab::CrtTable* crt() const { return basis ? ctx->dg_crt : ctx->d_crt; }
   lab::HatView view(size_t off) const { return lab::HatView{d + off * lab::D, count * lab::D}; }
 };
 
@@ -107,11 +125,22 @@ struct Staging {
   }
 };
 
+// out[i*r+k] = sum_x P[x*r+i]*S[x*r+k]; `partial` must hold gram_num_chunks(n)*r*r elements (unused when 1 chunk)
+int gram_impl(lab_ctx* c, HatView out, ConstHatView P, ConstHatView S, size_t n, size_t r, HatView partial);
 int check_range(lab_ctx* c, const lab_vec* v, size_t off, size_t n, const char* what);
 // launch_matvec_partial wrapped in the profiling events when the hook is active
-int matvec_partial_timed(lab_ctx* c, HatView partial, ConstHatView M, ConstHatView V, size_t nmat, size_t rows, size_t cols);
+int matvec_partial_timed(lab_ctx* c, HatView partial, ConstHatView M, ConstHatView V, size_t nmat, size_t rows, size_t cols,
+                         int nlimbs = 0, const LimbTable* tabs = nullptr);
 // hat -> coefficient conversion of `count` elements of `src` into device memory `dcoeffs`, using `tmp` (>= count elements of hat scratch)
-int from_hat(lab_ctx* c, ConstHatView src, size_t count, uint32_t* tmp, uint64_t* dcoeffs);
-int to_hat(lab_ctx* c, const uint64_t* dcoeffs, HatView dst, size_t count);
+int from_hat(lab_ctx* c, ConstHatView src, size_t count, uint32_t* tmp, uint64_t* dcoeffs, int basis = 0);
+int to_hat(lab_ctx* c, const uint64_t* dcoeffs, HatView dst, size_t count, int basis = 0);
+inline int basis_nlimbs(const lab_ctx* c, int basis) { return basis ? c->dg_nlimbs : c->nlimbs; }
+inline const LimbTable* basis_tabs(const lab_ctx* c, int basis) { return basis ? c->dg_tabs : c->d_tabs; }
+inline const CrtTable* basis_crt(const lab_ctx* c, int basis) { return basis ? c->dg_crt : c->d_crt; }
+// sum_m <M[m][rho,:], V[m]> partials with M possibly compact: all limbs of the matrix's basis
+int matvec_partial_any(lab_ctx* c, HatView partial, const lab_vec* M, size_t m_off, ConstHatView V, size_t nmat,
+                       size_t rows, size_t cols);
+int axpy_commit_any(lab_ctx* c, HatView out, ConstHatView G, const lab_vec* Cm, size_t c_off, size_t nterms, size_t len,
+                    HatView partial);
 
 }  // namespace lab

@@ -59,12 +59,24 @@ hipError_t launch_matvec_partial(HatView partial, ConstHatView M, ConstHatView V
 hipError_t launch_sum_terms(HatView out, ConstHatView partial, size_t nterms, size_t rows, int nlimbs,
                             const LimbTable* tabs, hipStream_t s);
 const char* matvec_kernel_name();
+// single-limb variants whose matrix residues are stored as u16 (compact last limb of the digit basis)
+hipError_t launch_matvec_partial_u16(uint32_t* partial_plane, const uint16_t* M, const uint32_t* V_plane, size_t nmat,
+                                     size_t rows, size_t cols, const LimbTable* tab, hipStream_t s);
+hipError_t launch_axpy_partial_u16(uint32_t* partial_plane, const uint32_t* G_plane, const uint16_t* C, size_t nterms,
+                                   size_t len, const LimbTable* tab, hipStream_t s);
+// pack (unpack = false: dst16 <- src32) or unpack (unpack = true: udst32 <- dst16) one limb plane of `count` elements
+hipError_t launch_pack_u16(uint16_t* dst16, const uint32_t* src32, size_t count, bool unpack, uint32_t* udst32,
+                           hipStream_t s);
 // out[i*rows + rho] = <A[rho,:], S[:,i]>   A: [rows][inner], S: [inner][ncols]
 hipError_t launch_matmul_t(HatView out, ConstHatView A, ConstHatView S, size_t rows, size_t inner, size_t ncols,
                            int nlimbs, const LimbTable* tabs, hipStream_t s);
 // out[i*r + k] = sum_x P[x*r+i] * S[x*r+k]
 hipError_t launch_gram(HatView out, ConstHatView P, ConstHatView S, size_t n, size_t r, int nlimbs,
                        const LimbTable* tabs, hipStream_t s);
+// tiled Gram: partial[chunk][i][k], gram_num_chunks(n) chunks, to be summed with launch_sum_terms(rows = r*r)
+size_t gram_num_chunks(size_t n);
+hipError_t launch_gram_tiled(HatView partial, ConstHatView P, ConstHatView S, size_t n, size_t r, int nlimbs,
+                             const LimbTable* tabs, hipStream_t s);
 // partial[chunk*len + rho] = sum_{m in chunk} G[m] * C[m*len + rho]; axpy_num_chunks(nterms) chunks
 size_t axpy_num_chunks(size_t nterms);
 hipError_t launch_axpy_partial(HatView partial, ConstHatView G, ConstHatView C, size_t nterms, size_t len, int nlimbs,
@@ -85,6 +97,9 @@ hipError_t launch_symmetrize_half(uint64_t* H, const uint64_t* X, size_t r, uint
 hipError_t launch_jl_project(int64_t* proj, const int8_t* Pi, const uint64_t* S, size_t n, size_t r, hipStream_t s);
 hipError_t launch_phi_pi_part(uint64_t* W, const int8_t* Pi, const uint64_t* omega, size_t n, size_t r, uint64_t q,
                               hipStream_t s);
+// JL projection and the Pi part of phi'' in one pass over Pi (proj must be zeroed)
+hipError_t launch_pi_fused(int64_t* proj, uint64_t* W, const int8_t* Pi, const uint64_t* S, const uint64_t* omega,
+                           size_t n, size_t r, uint64_t q, hipStream_t s);
 hipError_t launch_compare_u64(unsigned int* flag, const uint64_t* a, const uint64_t* b, size_t nwords, hipStream_t s);
 hipError_t launch_symmetry_u64(unsigned int* flag, const uint64_t* X, size_t r, hipStream_t s);
 hipError_t launch_check18(uint64_t* res, const uint64_t* s1, const uint64_t* H, const uint64_t* b, size_t r, uint64_t q,

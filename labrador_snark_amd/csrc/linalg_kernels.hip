@@ -80,10 +80,27 @@ hipError_t launch_pointwise(PointwiseOp op, HatView out, ConstHatView a, ConstHa
 constexpr int MV_ROWS = 4;
 constexpr int MV_WAVES = 4;
 
+// four consecutive NTT slots of a matrix polynomial: 16 B when residues are u32, 8 B when the limb is a
+// small prime stored as u16 (the compact third limb of the digit basis)
+template <typename MT> struct Quad;
+template <> struct Quad<uint32_t> {
+  typedef uint4 raw;
+  static __device__ __forceinline__ uint4 load(const raw* p) { return *p; }
+};
+template <> struct Quad<uint16_t> {
+  typedef uint2 raw;
+  static __device__ __forceinline__ uint4 load(const raw* p) {
+    const uint2 v = *p;
+    return make_uint4(v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16);
+  }
+};
+
+template <typename MT>
 __global__ void __launch_bounds__(64 * MV_WAVES)
-k_matvec_partial(uint32_t* __restrict__ partial, size_t partial_ps, const uint32_t* __restrict__ M, size_t m_ps,
+k_matvec_partial(uint32_t* __restrict__ partial, size_t partial_ps, const MT* __restrict__ M, size_t m_ps,
                  const uint32_t* __restrict__ V, size_t v_ps, unsigned rows, unsigned cols,
                  const LimbTable* __restrict__ tabs) {
+  typedef typename Quad<MT>::raw mraw;
   __shared__ uint32_t red[MV_WAVES][MV_ROWS][D];
   const int limb = blockIdx.z;
   const unsigned mat = blockIdx.y;
@@ -94,11 +111,11 @@ k_matvec_partial(uint32_t* __restrict__ partial, size_t partial_ps, const uint32
   const int jq = lane & 15;           // slots 4*jq .. 4*jq+3
 
   const uint4* Vp = reinterpret_cast<const uint4*>(V + (size_t)limb * v_ps + (size_t)mat * cols * D);
-  const uint4* Mp[MV_ROWS];
+  const mraw* Mp[MV_ROWS];
 #pragma unroll
   for (int r = 0; r < MV_ROWS; r++) {
     unsigned row = min(row0 + r, rows - 1);  // clamp: out-of-range rows recompute the last row and are not stored
-    Mp[r] = reinterpret_cast<const uint4*>(M + (size_t)limb * m_ps + ((size_t)mat * rows + row) * cols * D);
+    Mp[r] = reinterpret_cast<const mraw*>(M + (size_t)limb * m_ps + ((size_t)mat * rows + row) * cols * D);
   }
 
   uint64_t acc[MV_ROWS][4];
@@ -121,7 +138,7 @@ k_matvec_partial(uint32_t* __restrict__ partial, size_t partial_ps, const uint32
         const size_t off = (size_t)((ch + u * MV_WAVES) * 4 + sub) * 16 + jq;  // uint4 index of (poly, 4 slots)
         v[u] = Vp[off];
 #pragma unroll
-        for (int r = 0; r < MV_ROWS; r++) m[u][r] = Mp[r][off];
+        for (int r = 0; r < MV_ROWS; r++) m[u][r] = Quad<MT>::load(Mp[r] + off);
       }
 #pragma unroll
       for (int u = 0; u < 4; u++)
@@ -147,7 +164,7 @@ k_matvec_partial(uint32_t* __restrict__ partial, size_t partial_ps, const uint32
       const uint4 v = Vp[off];
 #pragma unroll
       for (int r = 0; r < MV_ROWS; r++) {
-        const uint4 m = Mp[r][off];
+        const uint4 m = Quad<MT>::load(Mp[r] + off);
         acc[r][0] += (uint64_t)m.x * v.x;
         acc[r][1] += (uint64_t)m.y * v.y;
         acc[r][2] += (uint64_t)m.z * v.z;
@@ -193,8 +210,18 @@ hipError_t launch_matvec_partial(HatView partial, ConstHatView M, ConstHatView V
                                  size_t cols, int nlimbs, const LimbTable* tabs, hipStream_t s) {
   if (nmat == 0 || rows == 0) return hipSuccess;
   dim3 grid((unsigned)((rows + MV_ROWS - 1) / MV_ROWS), (unsigned)nmat, (unsigned)nlimbs);
-  hipLaunchKernelGGL(k_matvec_partial, grid, dim3(64 * MV_WAVES), 0, s, partial.base, partial.plane_stride, M.base,
-                     M.plane_stride, V.base, V.plane_stride, (unsigned)rows, (unsigned)cols, tabs);
+  hipLaunchKernelGGL(k_matvec_partial<uint32_t>, grid, dim3(64 * MV_WAVES), 0, s, partial.base, partial.plane_stride,
+                     M.base, M.plane_stride, V.base, V.plane_stride, (unsigned)rows, (unsigned)cols, tabs);
+  return hipGetLastError();
+}
+
+// one limb whose matrix residues are stored as u16 (`tab` = that limb's table; partial/V already offset to its plane)
+hipError_t launch_matvec_partial_u16(uint32_t* partial_plane, const uint16_t* M, const uint32_t* V_plane, size_t nmat,
+                                     size_t rows, size_t cols, const LimbTable* tab, hipStream_t s) {
+  if (nmat == 0 || rows == 0) return hipSuccess;
+  dim3 grid((unsigned)((rows + MV_ROWS - 1) / MV_ROWS), (unsigned)nmat, 1);
+  hipLaunchKernelGGL(k_matvec_partial<uint16_t>, grid, dim3(64 * MV_WAVES), 0, s, partial_plane, (size_t)0, M,
+                     (size_t)0, V_plane, (size_t)0, (unsigned)rows, (unsigned)cols, tab);
   return hipGetLastError();
 }
 
@@ -209,7 +236,15 @@ k_sum_terms(uint32_t* __restrict__ out, size_t out_ps, const uint32_t* __restric
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < row_words; i += stride) {
     uint64_t acc = 0;
-    for (unsigned m = 0; m < nterms; m++) acc += P[(size_t)m * row_words + i];
+    unsigned m = 0;
+    for (; m + 8 <= nterms; m += 8) {  // 8 independent loads in flight
+      uint32_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = P[(size_t)(m + u) * row_words + i];
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc += v[u];
+    }
+    for (; m < nterms; m++) acc += P[(size_t)m * row_words + i];
     out[(size_t)limb * out_ps + i] = (uint32_t)(acc % p);
   }
 }
@@ -241,7 +276,7 @@ namespace lab {
 constexpr int MM_RT = 4;
 constexpr int MM_CT = 8;
 
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3)))
 k_matmul_t(uint32_t* __restrict__ out, size_t out_ps, const uint32_t* __restrict__ A, size_t a_ps,
            const uint32_t* __restrict__ S, size_t s_ps, unsigned rows, unsigned inner, unsigned ncols,
            const LimbTable* __restrict__ tabs) {
@@ -268,24 +303,47 @@ k_matmul_t(uint32_t* __restrict__ out, size_t out_ps, const uint32_t* __restrict
     for (int c = 0; c < MM_CT; c++) acc[r][c] = 0;
 
   unsigned x = 0;
-  while (x < inner) {
-    const unsigned xe = min(x + 8, inner);
-    for (; x < xe; x++) {
-      uint32_t a[MM_RT], s[MM_CT];
+  // main loop: 8 terms per accumulator fold, in four groups of 2 whose 24 loads are all issued before their
+  // multiply-adds (a plain per-x loop waits on every load and runs latency-bound)
+  for (; x + 8 <= inner; x += 8) {
 #pragma unroll
-      for (int r = 0; r < MM_RT; r++) a[r] = Ap[arow[r] + (size_t)x * D];
+    for (int half = 0; half < 4; half++) {
+      uint32_t a[2][MM_RT], s[2][MM_CT];
 #pragma unroll
-      for (int c = 0; c < MM_CT; c++) s[c] = Sp[(size_t)x * ncols * D + scol[c]];
+      for (int u = 0; u < 2; u++) {
+        const size_t xx = x + half * 2 + u;
 #pragma unroll
-      for (int r = 0; r < MM_RT; r++)
+        for (int r = 0; r < MM_RT; r++) a[u][r] = Ap[arow[r] + xx * D];
 #pragma unroll
-        for (int c = 0; c < MM_CT; c++) acc[r][c] += (uint64_t)a[r] * s[c];
+        for (int c = 0; c < MM_CT; c++) s[u][c] = Sp[xx * ncols * D + scol[c]];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int r = 0; r < MM_RT; r++)
+#pragma unroll
+          for (int c = 0; c < MM_CT; c++) acc[r][c] += (uint64_t)a[u][r] * s[u][c];
     }
 #pragma unroll
     for (int r = 0; r < MM_RT; r++)
 #pragma unroll
       for (int c = 0; c < MM_CT; c++) acc[r][c] = acc_fold(acc[r][c], p, p2);
   }
+  for (; x < inner; x++) {  // fewer than 8 terms left
+    uint32_t a[MM_RT], s[MM_CT];
+#pragma unroll
+    for (int r = 0; r < MM_RT; r++) a[r] = Ap[arow[r] + (size_t)x * D];
+#pragma unroll
+    for (int c = 0; c < MM_CT; c++) s[c] = Sp[(size_t)x * ncols * D + scol[c]];
+#pragma unroll
+    for (int r = 0; r < MM_RT; r++)
+#pragma unroll
+      for (int c = 0; c < MM_CT; c++) acc[r][c] += (uint64_t)a[r] * s[c];
+  }
+#pragma unroll
+  for (int r = 0; r < MM_RT; r++)
+#pragma unroll
+    for (int c = 0; c < MM_CT; c++) acc[r][c] = acc_fold(acc[r][c], p, p2);
 #pragma unroll
   for (int r = 0; r < MM_RT; r++)
 #pragma unroll
@@ -301,7 +359,7 @@ hipError_t launch_matmul_t(HatView out, ConstHatView A, ConstHatView S, size_t r
                            int nlimbs, const LimbTable* tabs, hipStream_t s) {
   if (rows == 0 || ncols == 0) return hipSuccess;
   unsigned col_groups = (unsigned)((ncols + MM_CT - 1) / MM_CT);
-  unsigned wy = col_groups < 16 ? col_groups : 16;
+  unsigned wy = col_groups < 4 ? col_groups : 4;
   dim3 block(64, wy);
   dim3 grid((unsigned)((rows + MM_RT - 1) / MM_RT), (col_groups + wy - 1) / wy, (unsigned)nlimbs);
   hipLaunchKernelGGL(k_matmul_t, grid, block, 0, s, out.base, out.plane_stride, A.base, A.plane_stride, S.base,
@@ -358,10 +416,12 @@ hipError_t launch_gram(HatView out, ConstHatView P, ConstHatView S, size_t n, si
 // instruction covers 4 consecutive rho (1 KiB contiguous).
 constexpr int AX_CHUNK = 64;
 
+template <typename MT>
 __global__ void __launch_bounds__(256)
 k_axpy_partial(uint32_t* __restrict__ partial, size_t partial_ps, const uint32_t* __restrict__ G, size_t g_ps,
-               const uint32_t* __restrict__ C, size_t c_ps, unsigned nterms, unsigned len,
+               const MT* __restrict__ C, size_t c_ps, unsigned nterms, unsigned len,
                const LimbTable* __restrict__ tabs) {
+  typedef typename Quad<MT>::raw mraw;
   const int limb = blockIdx.z;
   const uint32_t p = tabs[limb].p, p2 = tabs[limb].p2, pinv = tabs[limb].pinv, r2 = tabs[limb].r2;
   const unsigned rho = blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -369,14 +429,14 @@ k_axpy_partial(uint32_t* __restrict__ partial, size_t partial_ps, const uint32_t
   const unsigned m0 = blockIdx.y * AX_CHUNK, m1 = min(m0 + AX_CHUNK, nterms);
   if (rho >= len) return;
   const uint4* Gp = reinterpret_cast<const uint4*>(G + (size_t)limb * g_ps) + jq;
-  const uint4* Cp = reinterpret_cast<const uint4*>(C + (size_t)limb * c_ps) + (size_t)rho * 16 + jq;
+  const mraw* Cp = reinterpret_cast<const mraw*>(C + (size_t)limb * c_ps) + (size_t)rho * 16 + jq;
   uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
   unsigned m = m0;
   while (m < m1) {
     const unsigned me = min(m + 8, m1);
     for (; m < me; m++) {
       const uint4 g = Gp[(size_t)m * 16];
-      const uint4 c = Cp[(size_t)m * len * 16];
+      const uint4 c = Quad<MT>::load(Cp + (size_t)m * len * 16);
       a0 += (uint64_t)g.x * c.x; a1 += (uint64_t)g.y * c.y; a2 += (uint64_t)g.z * c.z; a3 += (uint64_t)g.w * c.w;
     }
     a0 = acc_fold(a0, p, p2); a1 = acc_fold(a1, p, p2); a2 = acc_fold(a2, p, p2); a3 = acc_fold(a3, p, p2);
@@ -395,8 +455,48 @@ hipError_t launch_axpy_partial(HatView partial, ConstHatView G, ConstHatView C, 
                                const LimbTable* tabs, hipStream_t s) {
   if (nterms == 0 || len == 0) return hipSuccess;
   dim3 grid((unsigned)((len + 15) / 16), (unsigned)axpy_num_chunks(nterms), (unsigned)nlimbs);
-  hipLaunchKernelGGL(k_axpy_partial, grid, dim3(256), 0, s, partial.base, partial.plane_stride, G.base,
+  hipLaunchKernelGGL(k_axpy_partial<uint32_t>, grid, dim3(256), 0, s, partial.base, partial.plane_stride, G.base,
                      G.plane_stride, C.base, C.plane_stride, (unsigned)nterms, (unsigned)len, tabs);
+  return hipGetLastError();
+}
+
+hipError_t launch_axpy_partial_u16(uint32_t* partial_plane, const uint32_t* G_plane, const uint16_t* C, size_t nterms,
+                                   size_t len, const LimbTable* tab, hipStream_t s) {
+  if (nterms == 0 || len == 0) return hipSuccess;
+  dim3 grid((unsigned)((len + 15) / 16), (unsigned)axpy_num_chunks(nterms), 1);
+  hipLaunchKernelGGL(k_axpy_partial<uint16_t>, grid, dim3(256), 0, s, partial_plane, (size_t)0, G_plane, (size_t)0, C,
+                     (size_t)0, (unsigned)nterms, (unsigned)len, tab);
+  return hipGetLastError();
+}
+
+// u32 residues of one limb plane -> u16 (the limb prime is < 2^16)
+__global__ void __launch_bounds__(256)
+k_pack_u16(uint16_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t nquads) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < nquads; i += stride) {
+    const uint4 v = reinterpret_cast<const uint4*>(src)[i];
+    reinterpret_cast<uint2*>(dst)[i] = make_uint2(v.x | (v.y << 16), v.z | (v.w << 16));
+  }
+}
+__global__ void __launch_bounds__(256)
+k_unpack_u16(uint32_t* __restrict__ dst, const uint16_t* __restrict__ src, size_t nquads) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < nquads; i += stride) {
+    const uint2 v = reinterpret_cast<const uint2*>(src)[i];
+    reinterpret_cast<uint4*>(dst)[i] = make_uint4(v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16);
+  }
+}
+
+hipError_t launch_pack_u16(uint16_t* dst, const uint32_t* src, size_t count, bool unpack, uint32_t* udst,
+                           hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  size_t nquads = count * D / 4;
+  unsigned blocks = (unsigned)((nquads + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (!unpack) hipLaunchKernelGGL(k_pack_u16, dim3(blocks), dim3(256), 0, s, dst, src, nquads);
+  else hipLaunchKernelGGL(k_unpack_u16, dim3(blocks), dim3(256), 0, s, udst, (const uint16_t*)dst, nquads);
   return hipGetLastError();
 }
 
@@ -430,6 +530,103 @@ hipError_t launch_poly_by_vec(HatView out, ConstHatView poly, ConstHatView v, si
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(k_poly_by_vec, dim3(blocks, (unsigned)nlimbs), dim3(256), 0, s, out.base, out.plane_stride,
                      poly.base, poly.plane_stride, v.base, v.plane_stride, nquads, tabs);
+  return hipGetLastError();
+}
+
+}  // namespace lab
+
+namespace lab {
+
+// ------------------------------------------------ tiled Gram product with split reduction
+// partial[chunk][i][k][j] = sum_{x in chunk} P[x][i][j] * S[x][k][j]
+// Same register tile as k_matmul_t (lane = slot, 4 x 8 accumulators) so each loaded value feeds 8 (P) or 4 (S)
+// multiply-adds; the reduction over x is cut into GR_CHUNK-long pieces for parallelism and summed by k_sum_terms.
+constexpr int GR_CHUNK = 64;
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3)))
+k_gram_tiled(uint32_t* __restrict__ partial, size_t partial_ps, const uint32_t* __restrict__ P, size_t p_ps,
+             const uint32_t* __restrict__ S, size_t s_ps, unsigned n, unsigned r, unsigned nchunks,
+             const LimbTable* __restrict__ tabs) {
+  const unsigned limb = blockIdx.z / nchunks, chunk = blockIdx.z % nchunks;
+  const uint32_t p = tabs[limb].p, p2 = tabs[limb].p2, pinv = tabs[limb].pinv, r2 = tabs[limb].r2;
+  const int j = threadIdx.x;
+  const unsigned i0 = blockIdx.x * MM_RT;
+  const unsigned k0 = (blockIdx.y * blockDim.y + threadIdx.y) * MM_CT;
+  if (k0 >= r) return;
+  const uint32_t* Pp = P + (size_t)limb * p_ps + j;
+  const uint32_t* Sp = S + (size_t)limb * s_ps + j;
+  unsigned pi[MM_RT], sk[MM_CT];
+#pragma unroll
+  for (int a = 0; a < MM_RT; a++) pi[a] = min(i0 + a, r - 1) * D;
+#pragma unroll
+  for (int b = 0; b < MM_CT; b++) sk[b] = min(k0 + b, r - 1) * D;
+  uint64_t acc[MM_RT][MM_CT];
+#pragma unroll
+  for (int a = 0; a < MM_RT; a++)
+#pragma unroll
+    for (int b = 0; b < MM_CT; b++) acc[a][b] = 0;
+  unsigned x = chunk * GR_CHUNK;
+  const unsigned xend = min(x + GR_CHUNK, n);
+  for (; x + 8 <= xend; x += 8) {
+#pragma unroll
+    for (int half = 0; half < 4; half++) {
+      uint32_t pv[2][MM_RT], sv[2][MM_CT];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const size_t base = (size_t)(x + half * 2 + u) * r * D;
+#pragma unroll
+        for (int a = 0; a < MM_RT; a++) pv[u][a] = Pp[base + pi[a]];
+#pragma unroll
+        for (int b = 0; b < MM_CT; b++) sv[u][b] = Sp[base + sk[b]];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int a = 0; a < MM_RT; a++)
+#pragma unroll
+          for (int b = 0; b < MM_CT; b++) acc[a][b] += (uint64_t)pv[u][a] * sv[u][b];
+    }
+#pragma unroll
+    for (int a = 0; a < MM_RT; a++)
+#pragma unroll
+      for (int b = 0; b < MM_CT; b++) acc[a][b] = acc_fold(acc[a][b], p, p2);
+  }
+  for (; x < xend; x++) {  // fewer than 8 terms left
+    const size_t base = (size_t)x * r * D;
+    uint32_t pv[MM_RT], sv[MM_CT];
+#pragma unroll
+    for (int a = 0; a < MM_RT; a++) pv[a] = Pp[base + pi[a]];
+#pragma unroll
+    for (int b = 0; b < MM_CT; b++) sv[b] = Sp[base + sk[b]];
+#pragma unroll
+    for (int a = 0; a < MM_RT; a++)
+#pragma unroll
+      for (int b = 0; b < MM_CT; b++) acc[a][b] += (uint64_t)pv[a] * sv[b];
+  }
+#pragma unroll
+  for (int a = 0; a < MM_RT; a++)
+#pragma unroll
+    for (int b = 0; b < MM_CT; b++) acc[a][b] = acc_fold(acc[a][b], p, p2);
+#pragma unroll
+  for (int a = 0; a < MM_RT; a++)
+#pragma unroll
+    for (int b = 0; b < MM_CT; b++)
+      if (i0 + a < r && k0 + b < r)
+        partial[(size_t)limb * partial_ps + (((size_t)chunk * r + i0 + a) * r + k0 + b) * D + j] =
+            mont_mul(redc64(acc[a][b], p, pinv), r2, p, pinv);
+}
+
+size_t gram_num_chunks(size_t n) { return (n + GR_CHUNK - 1) / GR_CHUNK; }
+
+hipError_t launch_gram_tiled(HatView partial, ConstHatView P, ConstHatView S, size_t n, size_t r, int nlimbs,
+                             const LimbTable* tabs, hipStream_t s) {
+  if (r == 0 || n == 0) return hipSuccess;
+  const unsigned nchunks = (unsigned)gram_num_chunks(n);
+  unsigned kgroups = (unsigned)((r + MM_CT - 1) / MM_CT);
+  unsigned wy = kgroups < 4 ? kgroups : 4;
+  dim3 grid((unsigned)((r + MM_RT - 1) / MM_RT), (kgroups + wy - 1) / wy, (unsigned)nlimbs * nchunks);
+  hipLaunchKernelGGL(k_gram_tiled, grid, dim3(64, wy), 0, s, partial.base, partial.plane_stride, P.base,
+                     P.plane_stride, S.base, S.plane_stride, (unsigned)n, (unsigned)r, nchunks, tabs);
   return hipGetLastError();
 }
 

@@ -333,3 +333,82 @@ hipError_t launch_check18(uint64_t* res, const uint64_t* s1, const uint64_t* H, 
 }
 
 }  // namespace lab
+
+namespace lab {
+
+// ---- one pass over Pi for both of its uses (src/proofgen.rs:429-456 and :244-253):
+//   proj[m]    += sum_col Pi_i[m][col] * s_i[col]                       (JL projection, integers)
+//   W[x][i][.]  = sum_m omega[m] * sigma_inv(poly(Pi_i[m][64x..]))      (Pi part of phi'')
+// A block owns witness column i and a 4096-column chunk and walks all 256 rows: a thread keeps 16
+// witness coefficients and 16+16 column accumulators in registers, loads 16 B of Pi per row, reduces
+// the row sum with wave shuffles.  Pi (1 byte per entry) is read exactly once.
+__global__ void __launch_bounds__(256)
+k_pi_fused(unsigned long long* __restrict__ proj, uint64_t* __restrict__ W, const int8_t* __restrict__ Pi,
+           const uint64_t* __restrict__ S, const uint64_t* __restrict__ omega, unsigned n, unsigned r, uint64_t q) {
+  __shared__ uint64_t om[256];
+  __shared__ long long rowsum[4][256];
+  om[threadIdx.x] = omega[threadIdx.x];
+  __syncthreads();
+  const size_t cols = (size_t)n * D;
+  const unsigned i = blockIdx.y;
+  const size_t col0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+  const bool active = col0 < cols;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long long s[16];
+  uint64_t pos[16], neg[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) { s[c] = 0; pos[c] = 0; neg[c] = 0; }
+  if (active) {
+    const uint64_t* sp = S + ((col0 / D) * r + i) * D + (col0 % D);
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) {
+      const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(sp + c);
+      s[c] = (long long)v.x; s[c + 1] = (long long)v.y;
+    }
+  }
+  const int8_t* pp = Pi + (size_t)i * 256 * cols + (active ? col0 : 0);
+#pragma unroll 2
+  for (int m = 0; m < 256; m++) {
+    uint4 w = make_uint4(0, 0, 0, 0);
+    if (active) w = *reinterpret_cast<const uint4*>(pp + (size_t)m * cols);
+    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+    const uint64_t o = om[m];
+    long long a = 0;
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+      const int8_t e = (int8_t)(ww[c >> 2] >> ((c & 3) * 8));
+      a += e > 0 ? s[c] : (e < 0 ? -s[c] : 0);
+      pos[c] += e > 0 ? o : 0;
+      neg[c] += e < 0 ? o : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+    if (lane == 0) rowsum[wave][m] = a;
+  }
+  __syncthreads();
+  {
+    const int m = threadIdx.x;
+    const long long t = rowsum[0][m] + rowsum[1][m] + rowsum[2][m] + rowsum[3][m];
+    if (t != 0) atomicAdd(&proj[m], (unsigned long long)t);
+  }
+  if (active) {
+    const size_t x = col0 / D, k0 = col0 % D;
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+      const uint64_t u = submod(pos[c] % q, neg[c] % q, q);
+      const size_t k = k0 + c;
+      W[(x * r + i) * D + (k == 0 ? 0 : D - k)] = k == 0 ? u : (u == 0 ? 0 : q - u);
+    }
+  }
+}
+
+hipError_t launch_pi_fused(int64_t* proj /*zeroed*/, uint64_t* W, const int8_t* Pi, const uint64_t* S,
+                           const uint64_t* omega, size_t n, size_t r, uint64_t q, hipStream_t s) {
+  if (n == 0 || r == 0) return hipSuccess;
+  const size_t cols = n * D;
+  hipLaunchKernelGGL(k_pi_fused, dim3((unsigned)((cols + 4095) / 4096), (unsigned)r), dim3(256), 0, s,
+                     reinterpret_cast<unsigned long long*>(proj), W, Pi, S, omega, (unsigned)n, (unsigned)r, q);
+  return hipGetLastError();
+}
+
+}  // namespace lab

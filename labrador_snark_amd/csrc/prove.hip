@@ -63,40 +63,57 @@ extern "C" int lab_prove_core(lab_ctx* c, const lab_prove_input* in, lab_transcr
   if ((rc = check_range(c, in->B, in->b_off, r * (size_t)t1 * k1 * kappa, "lab_prove_core(B)"))) return rc;
   if ((rc = check_range(c, in->C, in->c_off, pairs * (size_t)t2 * k2, "lab_prove_core(C)"))) return rc;
   if ((rc = check_range(c, in->Dm, in->d_off, pairs * (size_t)t1 * k2, "lab_prove_core(D)"))) return rc;
+  // B, C, D may live in the context's digit basis (lab_ctx_enable_digit_basis): steps 3, 4, 9 then run in it
+  const int bdig = in->B->basis;
+  if (in->C->basis != bdig || in->Dm->basis != bdig) return fail(c, LAB_ERR_ARG, "lab_prove_core: B, C, D must share one RNS basis");
+  if (in->A->basis != 0 || in->A->compact) return fail(c, LAB_ERR_ARG, "lab_prove_core: A must be a main-basis vector");
   // exactness of every transform-domain reduction (see header comment)
   const u128 qm1 = c->q - 1;
   const u128 bmax = (u128)(in->b1 > in->b2 ? in->b1 : in->b2);
-  if (!exact_ok(c, n, qm1) || !exact_ok(c, rr + nr, qm1) || !exact_ok(c, r, qm1) ||
-      !exact_ok(c, (u128)r * t1 * kappa + (u128)pairs * t2, bmax) || !exact_ok(c, (u128)pairs * t1, (u128)in->b1))
+  if (!exact_ok(c, n, qm1) || !exact_ok(c, rr + nr, qm1) || !exact_ok(c, r, qm1))
     return fail(c, LAB_ERR_RANGE, "lab_prove_core: a reduction exceeds the CRT range of this context; create it with a larger max_len");
+  if (bdig) {
+    if ((u128)r * t1 * kappa + (u128)pairs * t2 > c->dg_terms || (u128)pairs * t1 > c->dg_terms || bmax - 1 > c->dg_vmax)
+      return fail(c, LAB_ERR_RANGE, "lab_prove_core: outer commitments exceed the digit basis bounds (max_terms %llu, digit_bound %llu)",
+                  (unsigned long long)c->dg_terms, (unsigned long long)(c->dg_vmax + 1));
+  } else if (!exact_ok(c, (u128)r * t1 * kappa + (u128)pairs * t2, bmax) || !exact_ok(c, (u128)pairs * t1, (u128)in->b1)) {
+    return fail(c, LAB_ERR_RANGE, "lab_prove_core: a reduction exceeds the CRT range of this context; create it with a larger max_len");
+  }
   if ((u128)r * n * D * qm1 >= ((u128)1 << 63)) return fail(c, LAB_ERR_RANGE, "lab_prove_core: JL projection does not fit 64 bits");
   LAB_HIP(c, hipSetDevice(c->device));
 
   // ---------------- workspace plan
   const int L = c->nlimbs;
   HatArena ha;
-  const size_t hS = ha.take(nr), hphi = ha.take(nr), hT = ha.take(rk), hTdec = ha.take(rk * t1), hG = ha.take(rr),
-               hGdec = ha.take(pairs * t2), hlhs = ha.take(k1), hrhs = ha.take(k1), hphipp = ha.take(nr),
+  const size_t hS = ha.take(nr), hphi = ha.take(nr), hT = ha.take(rk), hG = ha.take(rr), hphipp = ha.take(nr),
                happ = ha.take(rr), hGc = ha.take(rr), hbpp = ha.take(2), hphif = ha.take(nr), hbphi = ha.take(nr),
-               hX = ha.take(rr), hHdec = ha.take(pairs * t1), hu2 = ha.take(k2), hc = ha.take(r), hz = ha.take(n),
-               hab = ha.take(2);
+               hX = ha.take(rr), hc = ha.take(r), hz = ha.take(n), hab = ha.take(2);
+  // second arena, in the basis of B/C/D, for the digit-operand reductions (steps 3, 4, 9)
+  HatArena hd;
+  const size_t hTdec = hd.take(rk * t1), hGdec = hd.take(pairs * t2), hlhs = hd.take(k1), hrhs = hd.take(k1),
+               hHdec = hd.take(pairs * t1), hu2 = hd.take(k2);
+  const int Ld = basis_nlimbs(c, bdig);
+  const LimbTable* tabsd = basis_tabs(c, bdig);
   size_t tmp_elems = rk;
   if (nr > tmp_elems) tmp_elems = nr;
   if (k1 > tmp_elems) tmp_elems = k1;
   if (rr > tmp_elems) tmp_elems = rr;
-  size_t part_elems = r * (size_t)t1 * k1;
-  if (part_elems < 512) part_elems = 512;  // inner_product_impl splits a long inner product into <= 512 partials
-  const size_t ax_chunks_c = axpy_num_chunks(pairs * t2), ax_chunks_d = axpy_num_chunks(pairs * t1);
-  if (ax_chunks_c * k2 > part_elems) part_elems = ax_chunks_c * k2;
-  if (ax_chunks_d * k2 > part_elems) part_elems = ax_chunks_d * k2;
+  size_t part_elems = 512;  // inner_product_impl splits a long inner product into <= 512 partials
+  if (gram_num_chunks(n) * rr > part_elems) part_elems = gram_num_chunks(n) * rr;
   const size_t hpart = ha.take(part_elems);
-  const size_t hat_words = ha.total * D;
+  size_t partd_elems = r * (size_t)t1 * k1;
+  const size_t ax_chunks_c = axpy_num_chunks(pairs * t2), ax_chunks_d = axpy_num_chunks(pairs * t1);
+  if (ax_chunks_c * k2 > partd_elems) partd_elems = ax_chunks_c * k2;
+  if (ax_chunks_d * k2 > partd_elems) partd_elems = ax_chunks_d * k2;
+  const size_t hpartd = hd.take(partd_elems);
+  const size_t hat_words = ha.total * D, hatd_words = hd.total * D;
 
   const size_t coef_elems = rk /*cT*/ + rk * t1 /*cTdec*/ + rr /*cG*/ + pairs /*cGup*/ + pairs * t2 /*cGdec*/ +
                             nr /*cW*/ + nr /*cphipp*/ + rr /*capp*/ + nr /*cphif*/ + rr /*cX*/ + rr /*cH*/ +
                             pairs /*cHup*/ + pairs * t1 /*cHdec*/ + k1 /*cu1*/ + k2 /*cu2*/ + n /*cz*/ + 1 /*cbpp*/ +
                             2 /*cab*/;
-  size_t bytes = Carver::padded((size_t)L * hat_words * 4) + Carver::padded((size_t)L * tmp_elems * D * 4) +
+  size_t bytes = Carver::padded((size_t)L * hat_words * 4) + Carver::padded((size_t)Ld * hatd_words * 4) +
+                 Carver::padded((size_t)L * tmp_elems * D * 4) +
                  coef_elems * (D * 8) + 32 * 256 /*alignment padding of the carves*/ + 3 * 4096 /*proj*/;
   bytes += Staging::need(in->S, nr * D * 8) + Staging::need(in->phi, nr * D * 8) + Staging::need(in->a, rr * D * 8) +
            Staging::need(in->Pi, r * 256 * n * D) + Staging::need(in->omega, 256 * 8) +
@@ -104,7 +121,9 @@ extern "C" int lab_prove_core(lab_ctx* c, const lab_prove_input* in, lab_transcr
   if ((rc = ensure_scratch(c, bytes + (1 << 16)))) return rc;
   Carver cv(c->scratch);
   uint32_t* hat_base = cv.take<uint32_t>((size_t)L * hat_words);
+  uint32_t* hatd_base = cv.take<uint32_t>((size_t)Ld * hatd_words);
   auto HV = [&](size_t off) { return HatView{hat_base + off * D, hat_words}; };
+  auto HD = [&](size_t off) { return HatView{hatd_base + off * D, hatd_words}; };
   auto CO = [&](size_t elems) { return cv.take<uint64_t>(elems * D); };
   uint64_t *cT = CO(rk), *cTdec = CO(rk * t1), *cG = CO(rr), *cGup = CO(pairs), *cGdec = CO(pairs * t2), *cW = CO(nr),
            *cphipp = CO(nr), *capp = CO(rr), *cphif = CO(nr), *cX = CO(rr), *cH = CO(rr), *cHup = CO(pairs),
@@ -141,32 +160,32 @@ extern "C" int lab_prove_core(lab_ctx* c, const lab_prove_input* in, lab_transcr
   if ((rc = from_hat(c, HV(hT), rk, dense_tmp, cT))) return rc;
 
   // ---------------- step 2 (:59-70): G = S^T S
-  LAB_HIP(c, launch_gram(HV(hG), HV(hS), HV(hS), n, r, L, tabs, s));
+  if ((rc = gram_impl(c, HV(hG), HV(hS), HV(hS), n, r, HV(hpart)))) return rc;
   if ((rc = from_hat(c, HV(hG), rr, dense_tmp, cG))) return rc;
 
   // ---------------- step 3 (:101-132): lhs = sum_{i,k} B_ik t_i^(k)
   LAB_HIP(c, launch_decompose(cTdec, cT, rk, q, (uint64_t)in->b1, t1, kappa, s));  // [i][k][rho]
-  if ((rc = to_hat(c, cTdec, HV(hTdec), rk * t1))) return rc;
-  if ((rc = matvec_partial_timed(c, HV(hpart), in->B->view(in->b_off), HV(hTdec), r * (size_t)t1, k1, kappa))) return rc;
-  LAB_HIP(c, launch_sum_terms(HV(hlhs), HV(hpart), r * (size_t)t1, k1, L, tabs, s));
+  if ((rc = to_hat(c, cTdec, HD(hTdec), rk * t1, bdig))) return rc;
+  if ((rc = matvec_partial_any(c, HD(hpartd), in->B, in->b_off, HD(hTdec), r * (size_t)t1, k1, kappa))) return rc;
+  LAB_HIP(c, launch_sum_terms(HD(hlhs), HD(hpartd), r * (size_t)t1, k1, Ld, tabsd, s));
 
   // ---------------- step 4 (:137-148): rhs = sum_{i<=j,k} g_ij^(k) C_ijk ; u_1 = lhs + rhs (:153)
   LAB_HIP(c, launch_gather_upper(cGup, cG, r, s));
   LAB_HIP(c, launch_decompose(cGdec, cGup, pairs, q, (uint64_t)in->b2, t2, 1, s));  // [pair][k]
-  if ((rc = to_hat(c, cGdec, HV(hGdec), pairs * t2))) return rc;
-  if ((rc = axpy_commit_impl(c, HV(hrhs), HV(hGdec), in->C->view(in->c_off), pairs * t2, k2, HV(hpart)))) return rc;
-  LAB_HIP(c, launch_pointwise(PW_ADD, HV(hlhs), HV(hlhs), HV(hrhs), k1, L, tabs, s));
-  if ((rc = from_hat(c, HV(hlhs), k1, dense_tmp, cu1))) return rc;
+  if ((rc = to_hat(c, cGdec, HD(hGdec), pairs * t2, bdig))) return rc;
+  if ((rc = axpy_commit_any(c, HD(hrhs), HD(hGdec), in->C, in->c_off, pairs * t2, k2, HD(hpartd)))) return rc;
+  LAB_HIP(c, launch_pointwise(PW_ADD, HD(hlhs), HD(hlhs), HD(hrhs), k1, Ld, tabsd, s));
+  if ((rc = from_hat(c, HD(hlhs), k1, dense_tmp, cu1, bdig))) return rc;
 
   // ---------------- step 5 (:161-186, 429-456): JL projection over the integers
+  // (one pass over Pi also produces W, the Pi part of phi'' used in step 6)
   LAB_HIP(c, hipMemsetAsync(dproj_int, 0, 256 * 8, s));
-  LAB_HIP(c, launch_jl_project(dproj_int, dPi, dS, n, r, s));
+  LAB_HIP(c, launch_pi_fused(dproj_int, cW, dPi, dS, domega, n, r, q, s));
   LAB_HIP(c, launch_lift_i64(dproj, dproj_int, 256, q, s));
 
   // ---------------- step 6 (:205-289): a'' = psi a', phi'' = psi phi' + sum_m omega_m sigma_inv(pi^(m)), b''
   const uint64_t psi = in->psi % q;
   LAB_HIP(c, launch_coef_elementwise(capp, da, nullptr, rr, q, psi, 0, s));
-  LAB_HIP(c, launch_phi_pi_part(cW, dPi, domega, n, r, q, s));
   LAB_HIP(c, launch_coef_elementwise(cphipp, dphi, cW, nr, q, psi, 1, s));
   if ((rc = to_hat(c, capp, HV(happ), rr))) return rc;
   if ((rc = to_hat(c, cphipp, HV(hphipp), nr))) return rc;
@@ -186,16 +205,16 @@ extern "C" int lab_prove_core(lab_ctx* c, const lab_prove_input* in, lab_transcr
   }
 
   // ---------------- step 8 (:320-358): H = 2^-1 (Phi^T S + S^T Phi)
-  LAB_HIP(c, launch_gram(HV(hX), HV(hphif), HV(hS), n, r, L, tabs, s));
+  if ((rc = gram_impl(c, HV(hX), HV(hphif), HV(hS), n, r, HV(hpart)))) return rc;
   if ((rc = from_hat(c, HV(hX), rr, dense_tmp, cX))) return rc;
   LAB_HIP(c, launch_symmetrize_half(cH, cX, r, q, inv2_mod(q), s));
 
   // ---------------- step 9 (:364-378): u_2 = sum_{i<=j,k} h_ij^(k) D_ijk
   LAB_HIP(c, launch_gather_upper(cHup, cH, r, s));
   LAB_HIP(c, launch_decompose(cHdec, cHup, pairs, q, (uint64_t)in->b1, t1, 1, s));
-  if ((rc = to_hat(c, cHdec, HV(hHdec), pairs * t1))) return rc;
-  if ((rc = axpy_commit_impl(c, HV(hu2), HV(hHdec), in->Dm->view(in->d_off), pairs * t1, k2, HV(hpart)))) return rc;
-  if ((rc = from_hat(c, HV(hu2), k2, dense_tmp, cu2))) return rc;
+  if ((rc = to_hat(c, cHdec, HD(hHdec), pairs * t1, bdig))) return rc;
+  if ((rc = axpy_commit_any(c, HD(hu2), HD(hHdec), in->Dm, in->d_off, pairs * t1, k2, HD(hpartd)))) return rc;
+  if ((rc = from_hat(c, HD(hu2), k2, dense_tmp, cu2, bdig))) return rc;
 
   // ---------------- step 10 (:380-399): z = sum_i c_i s_i
   LAB_HIP(c, launch_matvec_partial(HV(hz), HV(hS), HV(hc), 1, n, r, L, tabs, s));

@@ -40,6 +40,14 @@ extern "C" int lab_verify_core(lab_ctx* c, const lab_prove_input* in, const lab_
   if ((rc = check_range(c, in->B, in->b_off, r * (size_t)t1 * k1 * kappa, "lab_verify_core(B)"))) return rc;
   if ((rc = check_range(c, in->C, in->c_off, pairs * (size_t)t2 * k2, "lab_verify_core(C)"))) return rc;
   if ((rc = check_range(c, in->Dm, in->d_off, pairs * (size_t)t1 * k2, "lab_verify_core(D)"))) return rc;
+  const int bdig = in->B->basis;
+  if (in->C->basis != bdig || in->Dm->basis != bdig) return fail(c, LAB_ERR_ARG, "lab_verify_core: B, C, D must share one RNS basis");
+  if (in->A->basis != 0 || in->A->compact) return fail(c, LAB_ERR_ARG, "lab_verify_core: A must be a main-basis vector");
+  if (bdig) {
+    const uint64_t bm = (uint64_t)(in->b1 > in->b2 ? in->b1 : in->b2);
+    if ((u128)r * t1 * kappa + (u128)pairs * t2 > c->dg_terms || (u128)pairs * t1 > c->dg_terms || bm - 1 > c->dg_vmax)
+      return fail(c, LAB_ERR_RANGE, "lab_verify_core: outer commitments exceed the digit basis bounds");
+  }
   if (!c->direct) {
     u128 M = 1;
     for (int l = 0; l < c->nlimbs; l++) M *= c->primes[l];
@@ -48,7 +56,7 @@ extern "C" int lab_verify_core(lab_ctx* c, const lab_prove_input* in, const lab_
     size_t longest = n > nr + rr ? n : nr + rr;
     if (kappa > longest) longest = kappa;
     if ((u128)longest > half / (per * (u128)(c->q - 1)) ||
-        (u128)r * t1 * kappa + (u128)pairs * t2 > half / (per * bmax))
+        (!bdig && (u128)r * t1 * kappa + (u128)pairs * t2 > half / (per * bmax)))
       return fail(c, LAB_ERR_RANGE, "lab_verify_core: a reduction exceeds the CRT range of this context");
   }
   LAB_HIP(c, hipSetDevice(c->device));
@@ -62,12 +70,18 @@ extern "C" int lab_verify_core(lab_ctx* c, const lab_prove_input* in, const lab_
   auto HT = [&](size_t cnt) { size_t o = hat_total; hat_total += cnt; return o; };
   const size_t hphi = HT(nr), hab = HT(2), hc = HT(r), hz = HT(n), ht = HT(rk), hG = HT(rr), hH = HT(rr), happ = HT(rr),
                ha = HT(rr), haa = HT(rr), htmp = HT(rr), hphipp = HT(nr), hphif = HT(nr), hbphi = HT(nr), hbb = HT(2),
-               hb = HT(2), h15l = HT(kappa), h15r = HT(kappa), hv = HT(r), hone = HT(4), htdec = HT(rk * t1),
-               hGd = HT(pairs * t2), hHd = HT(pairs * t1), hlhs = HT(k1), hrhs = HT(k1), hu2 = HT(k2);
-  size_t part_elems = r * (size_t)t1 * k1;
-  if (part_elems < 512) part_elems = 512;
-  if (axpy_num_chunks(pairs * t2) * k2 > part_elems) part_elems = axpy_num_chunks(pairs * t2) * k2;
-  if (axpy_num_chunks(pairs * t1) * k2 > part_elems) part_elems = axpy_num_chunks(pairs * t1) * k2;
+               hb = HT(2), h15l = HT(kappa), h15r = HT(kappa), hv = HT(r), hone = HT(4);
+  size_t hatd_total = 0;
+  auto HDT = [&](size_t cnt) { size_t o = hatd_total; hatd_total += cnt; return o; };
+  const size_t htdec = HDT(rk * t1), hGd = HDT(pairs * t2), hHd = HDT(pairs * t1), hlhs = HDT(k1), hrhs = HDT(k1), hu2 = HDT(k2);
+  size_t partd_elems = r * (size_t)t1 * k1;
+  if (axpy_num_chunks(pairs * t2) * k2 > partd_elems) partd_elems = axpy_num_chunks(pairs * t2) * k2;
+  if (axpy_num_chunks(pairs * t1) * k2 > partd_elems) partd_elems = axpy_num_chunks(pairs * t1) * k2;
+  const size_t hpartd = HDT(partd_elems);
+  const size_t hatd_words = hatd_total * D;
+  const int Ld = basis_nlimbs(c, bdig);
+  const LimbTable* tabsd = basis_tabs(c, bdig);
+  size_t part_elems = 512;
   if (axpy_num_chunks(n) * r > part_elems) part_elems = axpy_num_chunks(n) * r;
   if (axpy_num_chunks(r) * (kappa > r ? kappa : r) > part_elems) part_elems = axpy_num_chunks(r) * (kappa > r ? kappa : r);
   const size_t hpart = HT(part_elems);
@@ -79,7 +93,8 @@ extern "C" int lab_verify_core(lab_ctx* c, const lab_prove_input* in, const lab_
   const size_t npoly_norm = 2 * n + rk * t1 + rr * t2 + rr * t1;
   const size_t coef_elems = rr + nr + nr + rr + nr + 1 + 2 * n + rk * t1 + rr * t2 + rr * t1 + pairs + pairs * t2 + pairs +
                             pairs * t1 + 2 * kappa + r + r + 8 + k1 + k2 + 4;
-  size_t bytes = Carver::padded((size_t)L * hat_words * 4) + Carver::padded((size_t)L * tmp_elems * D * 4) +
+  size_t bytes = Carver::padded((size_t)L * hat_words * 4) + Carver::padded((size_t)Ld * hatd_words * 4) +
+                 Carver::padded((size_t)L * tmp_elems * D * 4) +
                  coef_elems * D * 8 + 2 * Carver::padded(npoly_norm * 8) + 64 * 256 + (1 << 16);
   bytes += Staging::need(in->phi, nr * D * 8) + Staging::need(in->a, rr * D * 8) + Staging::need(in->Pi, r * 256 * n * D) +
            Staging::need(in->omega, 256 * 8) + Staging::need(in->alpha, D * 8) + Staging::need(in->beta, D * 8) +
@@ -90,7 +105,9 @@ extern "C" int lab_verify_core(lab_ctx* c, const lab_prove_input* in, const lab_
   Carver cv(c->scratch);
   uint32_t* hat_base = cv.take<uint32_t>((size_t)L * hat_words);
   uint32_t* dense_tmp = cv.take<uint32_t>((size_t)L * tmp_elems * D);
+  uint32_t* hatd_base = cv.take<uint32_t>((size_t)Ld * hatd_words);
   auto HV = [&](size_t off) { return HatView{hat_base + off * D, hat_words}; };
+  auto HD = [&](size_t off) { return HatView{hatd_base + off * D, hatd_words}; };
   auto CO = [&](size_t elems) { return cv.take<uint64_t>(elems * D); };
   uint64_t *capp = CO(rr), *cW = CO(nr), *cphipp = CO(nr), *caa = CO(rr), *cphif = CO(nr), *cb = CO(1), *czdec = CO(2 * n),
            *ctdec = CO(rk * t1), *cGdec = CO(rr * t2), *cHdec = CO(rr * t1), *cGup = CO(pairs), *cGupd = CO(pairs * t2),
@@ -210,23 +227,23 @@ extern "C" int lab_verify_core(lab_ctx* c, const lab_prove_input* in, const lab_
   LAB_HIP(c, launch_compare_u64(flags + F18, csc + 5 * D, csc + 6 * D, D, s));
 
   // check 19 (:372-415): recompute u_1 from t and g
-  if ((rc = to_hat(c, ctdec, HV(htdec), rk * t1))) return rc;
-  LAB_HIP(c, launch_matvec_partial(HV(hpart), in->B->view(in->b_off), HV(htdec), r * (size_t)t1, k1, kappa, L, tabs, s));
-  LAB_HIP(c, launch_sum_terms(HV(hlhs), HV(hpart), r * (size_t)t1, k1, L, tabs, s));
+  if ((rc = to_hat(c, ctdec, HD(htdec), rk * t1, bdig))) return rc;
+  if ((rc = matvec_partial_any(c, HD(hpartd), in->B, in->b_off, HD(htdec), r * (size_t)t1, k1, kappa))) return rc;
+  LAB_HIP(c, launch_sum_terms(HD(hlhs), HD(hpartd), r * (size_t)t1, k1, Ld, tabsd, s));
   LAB_HIP(c, launch_gather_upper(cGup, dG, r, s));
   LAB_HIP(c, launch_decompose(cGupd, cGup, pairs, q, (uint64_t)in->b2, t2, 1, s));
-  if ((rc = to_hat(c, cGupd, HV(hGd), pairs * t2))) return rc;
-  if ((rc = axpy_commit_impl(c, HV(hrhs), HV(hGd), in->C->view(in->c_off), pairs * t2, k2, HV(hpart)))) return rc;
-  LAB_HIP(c, launch_pointwise(PW_ADD, HV(hlhs), HV(hlhs), HV(hrhs), k1, L, tabs, s));
-  if ((rc = from_hat(c, HV(hlhs), k1, dense_tmp, cu1c))) return rc;
+  if ((rc = to_hat(c, cGupd, HD(hGd), pairs * t2, bdig))) return rc;
+  if ((rc = axpy_commit_any(c, HD(hrhs), HD(hGd), in->C, in->c_off, pairs * t2, k2, HD(hpartd)))) return rc;
+  LAB_HIP(c, launch_pointwise(PW_ADD, HD(hlhs), HD(hlhs), HD(hrhs), k1, Ld, tabsd, s));
+  if ((rc = from_hat(c, HD(hlhs), k1, dense_tmp, cu1c, bdig))) return rc;
   LAB_HIP(c, launch_compare_u64(flags + F19, cu1c, du1, k1 * D, s));
 
   // check 20 (:421-435): recompute u_2 from h
   LAB_HIP(c, launch_gather_upper(cHup, dH, r, s));
   LAB_HIP(c, launch_decompose(cHupd, cHup, pairs, q, (uint64_t)in->b1, t1, 1, s));
-  if ((rc = to_hat(c, cHupd, HV(hHd), pairs * t1))) return rc;
-  if ((rc = axpy_commit_impl(c, HV(hu2), HV(hHd), in->Dm->view(in->d_off), pairs * t1, k2, HV(hpart)))) return rc;
-  if ((rc = from_hat(c, HV(hu2), k2, dense_tmp, cu2c))) return rc;
+  if ((rc = to_hat(c, cHupd, HD(hHd), pairs * t1, bdig))) return rc;
+  if ((rc = axpy_commit_any(c, HD(hu2), HD(hHd), in->Dm, in->d_off, pairs * t1, k2, HD(hpartd)))) return rc;
+  if ((rc = from_hat(c, HD(hu2), k2, dense_tmp, cu2c, bdig))) return rc;
   LAB_HIP(c, launch_compare_u64(flags + F20, cu2c, du2, k2 * D, s));
 
   // ---------------- results

@@ -49,14 +49,26 @@ class RuntimeConstants:
 class ResidentCRS:
     """A, B_ik, C_ijk, D_ijk as transform-domain device matrices (stand-in for CRS::fetch_*, src/structs.rs:55-144)."""
 
-    def __init__(self, ctx, constants):
+    def __init__(self, ctx, constants, compact=False):
+        """compact=True keeps B, C, D in the context's digit basis with the small limb as u16 (they are only ever
+        multiplied by decomposition digits < B_1, B_2): fewer bytes per coefficient on the HBM-bound kernel.
+        Falls back to the main basis when no smaller basis exists (q its own NTT prime)."""
         k = constants
         pairs = k.R * (k.R + 1) // 2
         self.ctx, self.constants = ctx, k
+        self.compact = False
+        if compact and ctx.nlimbs > 1:
+            if not getattr(ctx, "digit_primes", None):
+                try:
+                    ctx.enable_digit_basis(k.R * k.T_1 * k.KAPPA + pairs * max(k.T_1, k.T_2), max(k.B_1, k.B_2))
+                except _lib.LabradorError:
+                    pass
+            self.compact = bool(getattr(ctx, "digit_primes", None))
+        dg = dict(digit=self.compact, compact=self.compact and ctx.digit_small)
         self.A = HatVec(ctx, k.KAPPA * k.N)
-        self.B = HatVec(ctx, k.R * k.T_1 * k.KAPPA_1 * k.KAPPA)
-        self.C = HatVec(ctx, pairs * k.T_2 * k.KAPPA_2)
-        self.Dm = HatVec(ctx, pairs * k.T_1 * k.KAPPA_2)
+        self.B = HatVec(ctx, k.R * k.T_1 * k.KAPPA_1 * k.KAPPA, **dg)
+        self.C = HatVec(ctx, pairs * k.T_2 * k.KAPPA_2, **dg)
+        self.Dm = HatVec(ctx, pairs * k.T_1 * k.KAPPA_2, **dg)
 
     def fill_synthetic(self, seed):
         """Uniform residues in [0,q) from the shared splitmix64 streams seed..seed+3 (oracle: orc_synth_fill)."""
@@ -133,10 +145,10 @@ class CRS:
         self.ctx._check(self.ctx._lib.lab_crs_expand(self.ctx._h, vec._h, dst_off, count, self.base_seed,
                                                      offset & ((1 << 64) - 1), offset >> 64))
 
-    def materialize(self):
+    def materialize(self, compact=False):
         """Resident transform-domain A, B, C, D with exactly the rows the reference's fetch_* would return."""
         k = self.constants
-        res = ResidentCRS(self.ctx, k)
+        res = ResidentCRS(self.ctx, k, compact=compact)
         self._expand_into(res.A, 0, k.KAPPA * k.N, self.offset_A(0))       # rows of A are consecutive in seed space
         for i in range(k.R):
             for kk in range(k.T_1):                                           # rows of one B_ik are consecutive too

@@ -3,7 +3,7 @@ Bit-exact integer work; every call goes through the C ABI."""
 import numpy as np
 import pytest
 
-from conftest import ALL_Q, Q_DEFAULT, Q_REF33
+from conftest import ALL_Q, Q_DEFAULT, Q_REF33, Q_DIRECT
 
 pytestmark = pytest.mark.gpu
 D = 64
@@ -150,3 +150,56 @@ def test_device_resident_io(contexts):
     dec = lab.decompose_polynomial_vec(ctx, da, 1625, 3)
     ctx.synchronize()
     assert np.array_equal(dec.cpu().numpy().view(np.uint64), co.decompose_vec(q, a, 1625, 3))
+
+
+@pytest.mark.parametrize("q", [Q_DEFAULT, Q_REF33])
+@pytest.mark.parametrize("compact", [False, True])
+def test_digit_basis_matvec_and_axpy(q, compact):
+    # matrices times decomposition DIGITS in the smaller RNS basis (u16 last limb when compact): same exact result
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    ctx = lab.Context(q, 0)
+    bound = 1625
+    nmat, rows, cols = 3, 9, 40
+    primes, small, nbytes = ctx.enable_digit_basis(5000, bound)
+    assert nbytes < 4 * ctx.nlimbs and small
+    rng = np.random.default_rng(3)
+    M = rp(rng, q, nmat, rows, cols)
+    V = rng.integers(0, bound, size=(nmat, cols, D), dtype=np.uint64)
+    hM = ctx.vec(nmat * rows * cols, digit=True, compact=compact).load(M)
+    hV = ctx.vec(nmat * cols, digit=True).load(V)
+    assert np.array_equal(hM.store(), M.reshape(-1, D)) and np.array_equal(hV.store(), V.reshape(-1, D))
+    got = lab.matvec_sum(ctx, hM, hV, nmat, rows, cols).store()
+    want = np.zeros((rows, D), np.uint64)
+    for m in range(nmat):
+        for r_ in range(rows):
+            want[r_] = co.poly_add(q, want[r_], co.inner_product(q, M[m, r_], V[m]))
+    assert np.array_equal(got, want)
+    nterms, length = 130, 21
+    G = rng.integers(0, bound, size=(nterms, D), dtype=np.uint64)
+    Cm = rp(rng, q, nterms, length)
+    hC = ctx.vec(nterms * length, digit=True, compact=compact).load(Cm)
+    got = lab.axpy_commit(ctx, ctx.vec(nterms, digit=True).load(G), hC, nterms, length).store()
+    want = np.zeros((length, D), np.uint64)
+    for m in range(nterms):
+        prod = co.poly_by_poly_vec(q, G[m], Cm[m])
+        for rho in range(length):
+            want[rho] = co.poly_add(q, want[rho], prod[rho])
+    assert np.array_equal(got, want)
+    # synthetic fill lands on the same coefficients in either storage
+    f = ctx.vec(70, digit=True, compact=compact).fill_synthetic(9)
+    assert np.array_equal(f.store(), co.synth_fill(9, 0, 70 * D, q).reshape(70, D))
+    # misuse is refused: compact vectors are not general operands, bases do not mix, lengths are bounded
+    with pytest.raises(lab.LabradorError):
+        lab.pointwise(ctx, "add", hM, hM) if compact else lab.matvec_sum(ctx, hM, ctx.vec_from(V), nmat, rows, cols)
+    with pytest.raises(lab.LabradorError):
+        lab.matvec_sum(ctx, ctx.vec(2 * 6000, digit=True), ctx.vec(6000, digit=True), 1, 2, 6000)
+    ctx.close()
+
+
+def test_digit_basis_not_offered_for_direct_modulus(contexts):
+    import labrador_snark_amd as lab
+    ctx = lab.Context(Q_DIRECT, 0)
+    with pytest.raises(lab.LabradorError):
+        ctx.enable_digit_basis(1000, 1625)
+    ctx.close()

@@ -139,3 +139,38 @@ def test_verify_core_matches_oracle_verifier(contexts, q, n, r, kappa, kappa1):
         assert got == want != 0, (field, got, want)
     assert lab.Verifier([case.b_prime], k, ctx).verify(st, case.b_poly, T, crs, beta_prime=float("inf")) is True
     crs.close()
+
+
+@pytest.mark.parametrize("q,n,r,kappa,kappa1", [(Q_DEFAULT, 2, 2, 4, 3), (Q_REF33, 4, 3, 6, 5), (Q_REF33, 16, 8, 24, 16),
+                                               (Q_REF33, 4, 8, 64, 4)])   # the last one needs the u16 limb
+def test_prove_and_verify_with_compact_crs(q, n, r, kappa, kappa1):
+    # B, C, D in the digit basis with a u16 limb (10 instead of 12 bytes per coefficient at the 33-bit Q): the
+    # transcript is bit-identical to the oracle's and to the main-basis run, and the GPU verifier accepts it
+    import copy
+    import labrador_snark_amd as lab
+    ctx = lab.Context(q, 0)
+    p = cases.Params(q, n, r, kappa, kappa1)
+    case, (S, phi, a, tape) = cases.oracle_case(p, seed=21)
+    want = case.prove()
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
+    crs = lab.ResidentCRS(ctx, k, compact=True).fill_synthetic(1000)
+    assert crs.compact and crs.B.digit        # digit basis; the u16 limb appears once the bounds need it
+    assert crs.B.compact == ctx.digit_small
+    if kappa == 64:
+        assert ctx.digit_small and len(ctx.digit_primes) == 3
+    st = lab.State(phi, a, case.b_prime)
+    T = lab.prove_core(ctx, k, S, st, crs, tape)
+    for f, o in (("t_i_all", "t"), ("g_mat", "G"), ("h_mat", "H"), ("u_1", "u1"), ("u_2", "u2"), ("z", "z"), ("b_prime_prime", "bpp")):
+        assert np.array_equal(getattr(T, f), want[o]), f
+    kinf = copy.copy(k); kinf.BETA_PRIME = float("inf")
+    assert lab.verify_core(ctx, kinf, st, case.b_poly, crs, T)[0] == 0
+    T2 = copy.copy(T); T2.u_1 = T.u_1.copy(); T2.u_1[0, 0] = (int(T2.u_1[0, 0]) + 1) % q
+    assert lab.verify_core(ctx, kinf, st, case.b_poly, crs, T2)[0] == 19
+    # seed-addressed CRS expands into the compact form as well
+    base = bytes(range(32))
+    res = lab.CRS(ctx, k, base).materialize(compact=True)
+    ref = lab.CRS(ctx, k, base).materialize(compact=False)
+    assert np.array_equal(res.B.store(), ref.B.store()) and np.array_equal(res.Dm.store(), ref.Dm.store())
+    for v in (crs, res, ref):
+        v.close()
+    ctx.close()
