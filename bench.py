@@ -180,11 +180,15 @@ def main():
         value = proofs / elapsed
         per_launch_s = (kernel_ms / 1e3) / max(launches, 1)
         achieved = (alg_bytes / max(launches, 1)) / per_launch_s / 1e9 if launches else 0.0
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE, gfx950 corrections applied) — only when they were taken on this very workload
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc))
+                if rec.get("workload_key") == [q, n, r, kappa, ctx.nlimbs, bool(crs.compact)]:
+                    traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         counts = ring_products_per_proof(n, r, kappa, kappa, kappa, k.T_1, k.T_2)
@@ -196,11 +200,14 @@ def main():
             "config": {"workload": "full Prover::proof_gen n=%d r=%d d=64, kappa=kappa1=kappa2=%d, q=%d (%d RNS limbs), "
                                    "CRS resident in transform domain, CRS expansion excluded" % (n, r, kappa, q, ctx.nlimbs),
                        "q": q, "n": n, "r": r, "kappa": kappa, "t1": k.T_1, "t2": k.T_2, "b1": k.B_1, "b2": k.B_2,
-                       "nlimbs": ctx.nlimbs, "instances_per_gpu": 1, "parallelism": "instance-per-gpu x%d" % world},
+                       "nlimbs": ctx.nlimbs, "crs_basis": ("digit basis %s, u16 last limb" % getattr(ctx, "digit_primes", None))
+                       if crs.compact else "main basis", "instances_per_gpu": 1, "parallelism": "instance-per-gpu x%d" % world},
             "proofs_per_s": value, "witness_Rq_elems_per_s": value * n * r,
             "ring_products_per_proof": sum(counts.values()),
             "checksum_u1_u2": int(chk.item()),
-            "roofline": {"bound": "hbm", "kernel": "k_matvec_partial (outer commitment sum_ik B_ik t_i^(k), src/proofgen.rs:101-132)",
+            "roofline": {"bound": "hbm", "kernel": "lab::k_matvec_partial<unsigned int> — the u32 limbs of the outer commitment "
+                                                   "sum_ik B_ik t_i^(k) (src/proofgen.rs:101-132); its u16 limb runs as a second, "
+                                                   "4x smaller launch of the same kernel template",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "launches": launches, "avg_launch_ms": per_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1),

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 outputs under gpurun_out/prof/ (kernel trace + two PMC passes of bench.py) into the small
+summaries committed under profiles/ (round tag as argv[1], default r01)."""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+P = "gpurun_out/prof/"
+DOM = "k_matvec_partial<unsigned int>"
+
+shutil.copy(glob.glob(P + "trace/*/*_kernel_stats.csv")[0], "profiles/%s_rocprofv3_kernel_stats.csv" % tag)
+shutil.copy(P + "bench_n1.json", "profiles/%s_bench_n1.json" % tag)
+bench = json.load(open(P + "pmc_fetch_bench.json"))
+cfg = bench["config"]
+
+
+def biggest(kind, name):
+    f = glob.glob(P + "pmc_%s/*/*_counter_collection.csv" % kind)[0]
+    best = None
+    for r in csv.DictReader(open(f)):
+        if DOM in r["Kernel_Name"] and r["Counter_Name"] == name:
+            v = float(r["Counter_Value"])
+            if best is None or v > best[0]:
+                best = (v, int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return best
+
+
+fs, ws = biggest("fetch", "FETCH_SIZE"), biggest("write", "WRITE_SIZE")
+alg = bench["roofline"]["algorithmic_bytes_per_launch"]
+fetch_bytes, write_bytes = fs[0] * 1024 * 2, ws[0] * 1024
+out = {"kernel": "lab::" + DOM + " (step-3 launch of bench.py: nmat=96, rows=1024, cols=1024, the u32 limbs)",
+       "workload_key": [cfg["q"], cfg["n"], cfg["r"], cfg["kappa"], cfg["nlimbs"], cfg["crs_basis"] != "main basis"],
+       "FETCH_SIZE_KB_raw": fs[0], "WRITE_SIZE_KB_raw": ws[0],
+       "correction": "FETCH_SIZE x2 on gfx950 for 16-B/lane coalesced streaming loads (MI355X_MICROARCH.md 'HBM'); "
+                     "WRITE_SIZE exact; FETCH and WRITE collected in separate --pmc passes",
+       "fetch_bytes": fetch_bytes, "write_bytes": write_bytes, "hbm_bytes_per_launch": fetch_bytes + write_bytes,
+       "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (fetch_bytes + write_bytes) / alg,
+       "kernel_ns_under_pmc": fs[1],
+       "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --no-cpu-baseline "
+                  "--no-extras --steps 2 --warmup 1"}
+json.dump(out, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
+
+tr = list(csv.DictReader(open(glob.glob(P + "trace/*/*_kernel_trace.csv")[0])))
+big = [i for i, r in enumerate(tr) if DOM in r["Kernel_Name"] and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 3e6]
+tb = json.load(open(P + "trace_bench.json"))
+lines = ["# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras  (%s)" % tag,
+         "# workload: " + tb["config"]["workload"] + " | CRS: " + tb["config"]["crs_basis"],
+         "# bench line under the profiler: " + json.dumps({k: tb[k] for k in ("value", "ms_per_step", "roofline")}),
+         "# kernels of ONE timed step (between two consecutive step-3 mat-vec launches), from the kernel trace:"]
+seg = tr[big[-2]:big[-1]]
+agg = collections.OrderedDict()
+for r in seg:
+    k = r["Kernel_Name"].split("(")[0]
+    a = agg.setdefault(k, [0, 0])
+    a[0] += 1
+    a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+tot = sum(v[1] for v in agg.values())
+lines.append("# kernels=%d  busy=%.3f ms  wall=%.3f ms" % (len(seg), tot / 1e6,
+             (int(seg[-1]["End_Timestamp"]) - int(seg[0]["Start_Timestamp"])) / 1e6))
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    lines.append("%-52s launches=%3d  %10.1f us  %5.1f%%" % (k, v[0], v[1] / 1e3, 100 * v[1] / tot))
+durs = [(int(tr[i]["End_Timestamp"]) - int(tr[i]["Start_Timestamp"])) / 1e6 for i in big]
+lines.append("# step-3 %s launch durations (ms): " % DOM + ", ".join("%.3f" % d for d in durs) + "  avg=%.3f" % (sum(durs) / len(durs)))
+open("profiles/%s_step_breakdown.txt" % tag, "w").write("\n".join(lines) + "\n")
+print("\n".join(lines[3:]))
+print(json.dumps({k: out[k] for k in ("hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "traffic_over_algorithmic")}))
+print(json.dumps({k: v for k, v in json.load(open(P + "bench_n1.json")).items() if k in ("value", "ms_per_step", "roofline", "cpu_baseline")})[:1500])
