@@ -1,0 +1,127 @@
+"""BASELINE.json configurations at their full sizes, checked through size-independent properties (round trips,
+linearity, the verifier's identities) plus oracle spot checks on a few outputs — the oracle cannot redo whole
+full-size results in seconds.  All bit-exact; everything goes through the C ABI."""
+import copy
+
+import numpy as np
+import pytest
+
+from conftest import Q_REF33, Q_DIRECT
+
+import cases
+
+pytestmark = pytest.mark.gpu
+D = 64
+
+
+@pytest.mark.parametrize("q", [Q_REF33, Q_DIRECT])
+def test_config2_batch_4096_forward_inverse_and_convolution(contexts, q):
+    # configs[1]: 4096 d=64 forward+inverse NTTs: identity round trip; INTT(NTT a . NTT b) == oracle product
+    import torch
+    from oracle import coracle as co
+    ctx = contexts(q)
+    batch = 4096
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, q, size=(batch, D), dtype=np.uint64)
+    b = rng.integers(0, q, size=(batch, D), dtype=np.uint64)
+    va = ctx.vec_from(a)
+    assert np.array_equal(va.store(), a)
+    prod = ctx.negacyclic_polymul(a, b)
+    idx = rng.integers(0, batch, size=64)
+    assert np.array_equal(prod[idx], co.polymul_batch(q, a[idx], b[idx]))
+    planes = torch.stack([torch.from_numpy((a % np.uint64(p)).astype(np.int64)).to(torch.int32) for p in ctx.primes]).cuda()
+    ref = planes.clone()
+    torch.cuda.synchronize()
+    ctx.ntt_forward(planes, batch)
+    ctx.ntt_inverse(planes, batch)
+    ctx.synchronize()
+    assert torch.equal(planes, ref)
+
+
+@pytest.mark.parametrize("q", [Q_REF33])
+def test_config4_ajtai_2p14_x_2p10_linearity_and_spot_rows(contexts, q):
+    # configs[3]: A = 2^14 x 2^10 ring elements resident in the transform domain (4 GiB per limb)
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    ctx = contexts(q)
+    rows, cols = 1 << 14, 1 << 10
+    A = ctx.vec(rows * cols).fill_synthetic(4)
+    rng = np.random.default_rng(44)
+    s1 = rng.integers(0, q, size=(cols, D), dtype=np.uint64)
+    s2 = rng.integers(0, q, size=(cols, D), dtype=np.uint64)
+    s12 = np.stack([co.poly_add(q, x, y) for x, y in zip(s1, s2)])
+    t1 = lab.matvec_sum(ctx, A, ctx.vec_from(s1), 1, rows, cols).store()
+    t2 = lab.matvec_sum(ctx, A, ctx.vec_from(s2), 1, rows, cols).store()
+    t12 = lab.matvec_sum(ctx, A, ctx.vec_from(s12), 1, rows, cols).store()
+    lin = (t1.astype(object) + t2.astype(object)) % q                      # A(s1+s2) == A s1 + A s2
+    assert np.array_equal(t12.astype(object), lin)
+    for rho in (0, 1, 4097, rows - 1):                                      # spot rows against the oracle
+        a_row = co.synth_fill(4, rho * cols * D, cols * D, q).reshape(cols, D)
+        assert np.array_equal(t1[rho], co.inner_product(q, a_row, s1))
+    # the multi-right-hand-side kernel (r = 32) agrees with the single-RHS kernel column by column
+    S = rng.integers(0, q, size=(cols, 32, D), dtype=np.uint64)
+    S[:, 0] = s1
+    S[:, 31] = s2
+    T = lab.ajtai_commit(ctx, A, ctx.vec_from(S), rows, cols, 32).store().reshape(32, rows, D)
+    assert np.array_equal(T[0], t1) and np.array_equal(T[31], t2)
+    A.close()
+
+
+def test_config3_full_prover_n1024_r32_self_consistent(contexts):
+    # configs[2]: full proof_gen at n = 1024, r = 32, kappa = kappa1 = kappa2 = 1024 (bench.py's workload, here
+    # with kappa1 = kappa2 = 64 to keep the resident B at 3.75 GiB in the test): the GPU verifier's identities
+    # (checks 8-9, 15-20 recomputed with independent kernels) accept it, tampering is caught, and a handful of
+    # outputs are compared with the oracle.
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    q, n, r, kappa, kappa1 = Q_REF33, 1024, 32, 1024, 64
+    ctx = lab.Context(q, 0, 1 << 17)
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, kappa1)
+    S, phi, a, tape = cases.make_inputs(p, seed=3)
+    crs = lab.ResidentCRS(ctx, k, compact=True).fill_synthetic(1000)
+    assert crs.B.compact
+    # b' from the product's own kernels (src/structs.rs:320-341, 373)
+    hS, hphi, ha = ctx.vec_from(S), ctx.vec_from(phi), ctx.vec_from(a)
+    G = lab.gram(ctx, hS, hS, n, r).store()
+    b_poly = (lab.polynomial_vec_inner_product(ctx, ha, ctx.vec_from(G)).store()[0].astype(object) +
+              lab.polynomial_vec_inner_product(ctx, hphi, hS).store()[0].astype(object)) % q
+    b_poly = b_poly.astype(np.uint64)
+    st = lab.State(phi, a, int(b_poly[0]))
+    T = lab.prove_core(ctx, k, S, st, crs, tape)
+    kinf = copy.copy(k)
+    kinf.BETA_PRIME = float("inf")
+    line, s14 = lab.verify_core(ctx, kinf, st, b_poly, crs, T)
+    assert line == 0 and np.isfinite(s14)
+    T2 = copy.copy(T)
+    T2.z = T.z.copy()
+    T2.z[777, 5] = (int(T2.z[777, 5]) + 1) % q
+    assert lab.verify_core(ctx, kinf, st, b_poly, crs, T2)[0] in (15, 16, 17)
+    # oracle spot checks
+    s0 = np.ascontiguousarray(S[:, 0])
+    s5 = np.ascontiguousarray(S[:, 5])
+    assert np.array_equal(T.g_mat[0, 5], co.inner_product(q, s0, s5))
+    a_row = co.synth_fill(1000, 7 * n * D, n * D, q).reshape(n, D)                 # row 7 of A
+    assert np.array_equal(T.t_i_all[5, 7], co.inner_product(q, a_row, s5))
+    assert np.array_equal(T.z[3], co.inner_product(q, S[3], tape["c"]))
+    s_cols = np.ascontiguousarray(S.transpose(1, 0, 2).reshape(r, n * D))
+    assert np.array_equal(T.projection_int, co.jl_project(tape["Pi"], s_cols))
+    # row 2 of u_1: sum_ik <B_ik[2,:], t_i^(k)> + sum_{i<=j,k} g_ij^(k) C_ijk[2]  (src/proofgen.rs:101-153)
+    acc = np.zeros(D, np.uint64)
+    for i in range(r):
+        dec = co.decompose_vec(q, T.t_i_all[i], k.B_1, k.T_1)
+        for kk in range(k.T_1):
+            m = i * k.T_1 + kk
+            b_row = co.synth_fill(1001, ((m * kappa1 + 2) * kappa) * D, kappa * D, q).reshape(kappa, D)
+            acc = co.poly_add(q, acc, co.inner_product(q, b_row, dec[kk]))
+    pair = 0
+    for i in range(r):
+        for j in range(i, r):
+            gdec = co.decompose(q, T.g_mat[i, j], k.B_2, k.T_2)
+            for kk in range(k.T_2):
+                c_elem = co.synth_fill(1002, (((pair * k.T_2 + kk) * kappa1) + 2) * D, D, q)
+                acc = co.poly_add(q, acc, co.polymul(q, gdec[kk], c_elem))
+            pair += 1
+    assert np.array_equal(T.u_1[2], acc)
+    crs.close()
+    ctx.close()
