@@ -125,3 +125,60 @@ def test_raw_ntt_roundtrip_and_convolution(contexts, q):
     ctx.ntt_inverse(y, batch)
     ctx.synchronize()
     assert torch.equal(x, y)
+
+
+def test_context_limb_selection_and_argument_errors():
+    # limb count follows the exactness bound; unusable moduli and oversize reductions are refused with status codes
+    import labrador_snark_amd as lab
+    c = lab.Context(Q_DEFAULT, 0)
+    assert c.nlimbs == 2 and c.max_len > 1 << 20
+    c.close()
+    c = lab.Context(Q_REF33, 0)
+    assert c.nlimbs == 3 and c.max_len == 524285
+    a = c.vec_from(np.zeros((4, D), np.uint64))
+    with pytest.raises(lab.LabradorError):                     # offsets past the end
+        lab.polynomial_vec_inner_product(c, a, a, off1=2, off2=0, length=3)
+    c.close()
+    c = lab.Context(Q_REF33, 0, max_len=1 << 22)               # a longer reduction needs the 4th limb
+    assert c.nlimbs == 4
+    rng = np.random.default_rng(0)
+    x, y = rand_polys(rng, Q_REF33, 50), rand_polys(rng, Q_REF33, 50)
+    from oracle import coracle as co
+    assert np.array_equal(c.negacyclic_polymul(x, y), co.polymul_batch(Q_REF33, x, y))
+    assert np.array_equal(lab.polynomial_vec_inner_product(c, c.vec_from(x), c.vec_from(y)).store()[0],
+                          co.inner_product(Q_REF33, x, y))
+    c.close()
+    c = lab.Context(1073738753, 0)                              # q itself is the NTT prime: single limb
+    assert c.nlimbs == 1 and c.primes == [1073738753]
+    c.close()
+    for bad in (0, 2, 8192, 1 << 40):                           # even / out of range
+        with pytest.raises(lab.LabradorError):
+            lab.Context(bad, 0)
+    small = lab.Context(97, 0)                                  # tiny odd q (not 1 mod 128): generic path, 1 limb suffices
+    u, v = rand_polys(rng, 97, 10), rand_polys(rng, 97, 10)
+    assert np.array_equal(small.negacyclic_polymul(u, v), co.polymul_batch(97, u, v))
+    small.close()
+    big = lab.Context((1 << 39) + 23, 0, max_len=64)            # near the 2^40 ceiling (odd, not necessarily prime)
+    qb = (1 << 39) + 23
+    u, v = rand_polys(rng, qb, 20), rand_polys(rng, qb, 20)
+    assert np.array_equal(big.negacyclic_polymul(u, v), co.polymul_batch(qb, u, v))
+    assert np.array_equal(lab.polynomial_vec_inner_product(big, big.vec_from(u), big.vec_from(v)).store()[0],
+                          co.inner_product(qb, u, v))
+    big.close()
+
+
+def test_reduction_longer_than_the_exactness_bound_is_refused(contexts):
+    import labrador_snark_amd as lab
+    ctx = contexts(Q_REF33)
+    n = ctx.max_len + 3
+    # vectors this long are never allocated: the length check comes first
+    a = ctx.vec(8)
+    with pytest.raises(lab.LabradorError) as e:
+        ctx._check(ctx._lib.lab_matvec_sum(ctx._h, a._h, 0, a._h, 0, n, 1, 1, a._h, 0))
+    assert e.value.code in (lab._lib.LAB_ERR_RANGE, lab._lib.LAB_ERR_LEN_MISMATCH)
+
+
+def test_empty_batches_are_no_ops(contexts):
+    ctx = contexts(Q_DEFAULT)
+    out = ctx.negacyclic_polymul(np.zeros((0, D), np.uint64), np.zeros((0, D), np.uint64))
+    assert out.shape == (0, D)
