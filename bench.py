@@ -273,6 +273,21 @@ def side_measurements(lab, ctx, q, dev):
                                                 "modmuladds_per_s": L * rows * cols * ncols * 64 / t}
         S.close(); o.close()
     A.close()
+    # the same mat-vec shape as the prover's step 3 when q is its own NTT prime (single limb, 4 B per coefficient):
+    # the data point for an NTT-friendly modulus (q = 1073738753, 30 bits); 24 GiB streamed per call
+    try:
+        c1 = lab.Context(1073738753, ctx.device)
+        c1.use_torch_stream()
+        M = c1.vec(96 * 1024 * 1024).fill_synthetic(7)
+        V = c1.vec(96 * 1024).fill_synthetic(8, bound=1023)
+        o = c1.vec(1024)
+        t = _time(lambda: lab.matvec_sum(c1, M, V, 96, 1024, 1024, out=o), 5)
+        out["outer_commitment_single_limb_q1073738753"] = {"ms": t * 1e3, "algorithmic_GBps": 96 * 1024 * 1024 * 256 / t / 1e9}
+        for v in (M, V, o):
+            v.close()
+        c1.close()
+    except Exception as e:  # never let a side measurement break the headline line
+        out["outer_commitment_single_limb_q1073738753"] = {"error": str(e)}
     return out
 
 

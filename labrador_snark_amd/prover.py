@@ -294,3 +294,37 @@ class Verifier:
             k.BETA_PRIME = beta_prime
         line, _ = verify_core(self.ctx, k, st, b_poly, crs, proof)
         return line == 0
+
+
+# ---- challenge space sampling (src/verification.rs:460-489, src/util.rs:83-104, 227-246) — SURVEY §8(f) row f4.
+# The reference draws everything from thread_rng, so only the arithmetic is reproducible: given the sample
+# polynomials, operator_norm is max_k sqrt(f64(|c r_k|^2)) / sqrt(f64(|r_k|^2)) with exact integer norms.
+
+def operator_norm(ctx, c, samples):
+    """util.rs:227-246 with the n_samples random polynomials `samples` ([k][64]) supplied by the caller: one batched
+    ring product and two exact norm kernels on the GPU, the f64 ratio/max on the host (IEEE sqrt and division)."""
+    import math
+    from .api import poly_norm_exact
+    samples = _as_u64(samples)
+    k = samples.shape[0]
+    prod = ctx.negacyclic_polymul(np.broadcast_to(_as_u64(c).reshape(1, D), (k, D)).copy(), samples)
+    num, den = poly_norm_exact(ctx, prod), poly_norm_exact(ctx, samples)
+    sup = 0.0
+    for a, b in zip(num, den):
+        ratio = math.sqrt(float(a)) / math.sqrt(float(b))       # poly_norm_strict(c*r) / poly_norm_strict(r); NaN never wins
+        if ratio > sup:
+            sup = ratio
+    return sup
+
+
+def fetch_challenge(ctx, rng, q, T=15.0, n_samples=1000):
+    """Verifier::fetch_challenge (src/verification.rs:460-489) with a numpy Generator standing in for thread_rng:
+    a random signed arrangement of 23 zeros, 31 ones, 10 twos, redrawn until operator_norm(candidate) <= T."""
+    while True:
+        vals = np.array([0] * 23 + [1] * 31 + [2] * 10, dtype=np.int64)
+        rng.shuffle(vals)
+        signs = rng.integers(0, 2, size=D)
+        cand = np.where((vals > 0) & (signs == 1), q - vals, vals).astype(np.uint64)
+        samples = rng.integers(0, q, size=(n_samples, D), dtype=np.uint64)
+        if operator_norm(ctx, cand, samples) <= T:
+            return cand

@@ -203,3 +203,41 @@ def test_digit_basis_not_offered_for_direct_modulus(contexts):
     with pytest.raises(lab.LabradorError):
         ctx.enable_digit_basis(1000, 1625)
     ctx.close()
+
+
+@pytest.mark.parametrize("q", [Q_DEFAULT, Q_REF33])
+def test_operator_norm_and_fetch_challenge(contexts, q):
+    # util.rs:227-246 / verification.rs:460-489 with the random draws supplied: same f64 value as the oracle route
+    import math
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    ctx = contexts(q)
+    rng = np.random.default_rng(15)
+    c = rp(rng, 3, 1)[0]
+    samples = rp(rng, q, 200)
+    want = 0.0
+    for rpoly in samples:
+        num = co.poly_norm(co.polymul(q, c, rpoly))[0]
+        den = co.poly_norm(rpoly)[0]
+        want = max(want, math.sqrt(num) / math.sqrt(den))
+    assert lab.operator_norm(ctx, c, samples) == want
+    ch = lab.fetch_challenge(ctx, np.random.default_rng(1), q, T=float("inf"), n_samples=50)
+    small = np.minimum(ch, q - ch)
+    assert sorted(small.tolist()) == [0] * 23 + [1] * 31 + [2] * 10
+
+
+def test_sharded_outer_commitment_single_rank(contexts):
+    # parallel.sharded_outer_commitment with world size 1 equals lab_matvec_sum over all (i,k) (src/proofgen.rs:101-132)
+    import torch
+    import labrador_snark_amd as lab
+    from labrador_snark_amd import parallel
+    q = Q_REF33
+    ctx = contexts(q)
+    r, t1, kappa1, kappa = 3, 3, 6, 20
+    B = ctx.vec(r * t1 * kappa1 * kappa).fill_synthetic(5)
+    V = ctx.vec(r * t1 * kappa).fill_synthetic(6, bound=1625)
+    full = lab.matvec_sum(ctx, B, V, r * t1, kappa1, kappa).store()
+    lo, hi = parallel.ik_shard(r, t1, 0, 1)
+    assert (lo, hi) == (0, r * t1)
+    got = parallel.sharded_outer_commitment(ctx, B, V, hi - lo, kappa1, kappa, q)
+    assert np.array_equal(got.cpu().numpy().view(np.uint64), full)
