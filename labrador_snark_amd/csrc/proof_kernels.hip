@@ -369,8 +369,9 @@ k_pi_fused(unsigned long long* __restrict__ proj, uint64_t* __restrict__ W, cons
   const int8_t* pp = Pi + (size_t)i * 256 * cols + (active ? col0 : 0);
 #pragma unroll 2
   for (int m = 0; m < 256; m++) {
-    uint4 w = make_uint4(0, 0, 0, 0);
-    if (active) w = *reinterpret_cast<const uint4*>(pp + (size_t)m * cols);
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t w = {0, 0, 0, 0};
+    if (active) w = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(pp + (size_t)m * cols));  // Pi is read once
     const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
     const uint64_t o = om[m];
     long long a = 0;

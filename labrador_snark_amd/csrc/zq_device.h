@@ -148,7 +148,12 @@ __device__ __forceinline__ void tile_load_u32(uint32_t (&x)[D], const uint32_t* 
   if (base + 64 <= count) {  // wave-uniform: full tile, 16 independent loads in flight
     uint4 v[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) v[i] = g[i * 64 + lane];
+    for (int i = 0; i < 16; i++) {
+      // batches are streamed once: non-temporal loads/stores measured +5..7 % on the 2^20-batch transform
+      typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+      const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(g + i * 64 + lane));
+      v[i] = make_uint4(t.x, t.y, t.z, t.w);
+    }
 #pragma unroll
     for (int i = 0; i < 16; i++)
       *reinterpret_cast<uint4*>(lds + (i * 4 + (lane >> 4)) * TILE_PITCH + (lane & 15) * 4) = v[i];
@@ -180,8 +185,12 @@ __device__ __forceinline__ void tile_store_u32(const uint32_t (&x)[D], uint32_t*
   uint4* g = reinterpret_cast<uint4*>(plane + base * D);
   if (base + 64 <= count) {
 #pragma unroll
-    for (int i = 0; i < 16; i++)
-      g[i * 64 + lane] = *reinterpret_cast<const uint4*>(lds + (i * 4 + (lane >> 4)) * TILE_PITCH + (lane & 15) * 4);
+    for (int i = 0; i < 16; i++) {
+      const uint4 o = *reinterpret_cast<const uint4*>(lds + (i * 4 + (lane >> 4)) * TILE_PITCH + (lane & 15) * 4);
+      typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+      u32x4_t t = {o.x, o.y, o.z, o.w};
+      __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t*>(g + i * 64 + lane));
+    }
   } else {
 #pragma unroll 1
     for (int i = 0; i < 16; i++) {
