@@ -78,7 +78,7 @@ hipError_t launch_pointwise(PointwiseOp op, HatView out, ConstHatView a, ConstHa
 // output slot finishes the sum.
 // Algorithmic traffic per launch: nmat*rows*cols*256 B (matrix) per limb.
 constexpr int MV_ROWS = 4;
-constexpr int MV_WAVES = 4;
+constexpr int MV_WAVES = 8;
 
 // four consecutive NTT slots of a matrix polynomial: 16 B when residues are u32, 8 B when the limb is a
 // small prime stored as u16 (the compact third limb of the digit basis)
@@ -202,10 +202,14 @@ k_matvec_partial(uint32_t* __restrict__ partial, size_t partial_ps, const MT* __
   {
     const int r = threadIdx.x >> 6, j = threadIdx.x & 63;
     if (r < MV_ROWS && row0 + r < rows) {
-      uint32_t x = red[0][r][j];
+      uint32_t x = 0;                     // MV_WAVES canonical residues: reduce after every 4 (4p < 2^32)
 #pragma unroll
-      for (int w = 1; w < MV_WAVES; w++) x += red[w][r][j];
-      x = csub(csub(x, p2), p);
+      for (int w0 = 0; w0 < MV_WAVES; w0 += 4) {
+        uint32_t y = 0;
+#pragma unroll
+        for (int w = w0; w < w0 + 4 && w < MV_WAVES; w++) y += red[w][r][j];
+        x = csub(x + csub(csub(y, p2), p), p);
+      }
       x = mont_mul(x, r2, p, pinv);       // undo the 2^-32 of redc64: plain residue
       partial[(size_t)limb * partial_ps + ((size_t)mat * rows + row0 + r) * D + j] = x;
     }

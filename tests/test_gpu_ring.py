@@ -81,7 +81,8 @@ def test_inner_product_length_mismatch(contexts):
 
 
 @pytest.mark.parametrize("q", ALL_Q)
-@pytest.mark.parametrize("nmat,rows,cols", [(1, 5, 33), (3, 7, 64), (2, 4, 129), (6, 9, 20)])
+@pytest.mark.parametrize("nmat,rows,cols", [(1, 5, 33), (3, 7, 64), (2, 4, 129), (6, 9, 20),
+                                            (1, 5, 1500)])  # long rows: every wave of the block holds a partial sum
 def test_matvec_sum_matches_oracle(contexts, q, nmat, rows, cols):
     import labrador_snark_amd as lab
     from oracle import coracle as co

@@ -13,19 +13,18 @@ L.SO_PATH = sys.argv[1]
 import labrador_snark_amd as lab
 q = (1 << 32) + 15
 ctx = lab.Context(q, 0, 1 << 17); ctx.use_torch_stream()
-L_ = ctx.nlimbs; batch = 1 << 20
-x = torch.randint(0, 1 << 29, (L_, batch, 64), dtype=torch.int32, device="cuda")
-def run(fn, it):
-    for _ in range(3): fn()
+nmat, rows, cols = 48, 1024, 1024
+M = ctx.vec(nmat * rows * cols).fill_synthetic(1); V = ctx.vec(nmat * cols).fill_synthetic(2, bound=1625); out = ctx.vec(rows)
+def run(it):
+    for _ in range(3): lab.matvec_sum(ctx, M, V, nmat, rows, cols, out=out)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(it): fn()
+    for _ in range(it): lab.matvec_sum(ctx, M, V, nmat, rows, cols, out=out)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / it
-f = min(run(lambda: ctx.ntt_forward(x, batch), 20) for _ in range(3))
-i = min(run(lambda: ctx.ntt_inverse(x, batch), 20) for _ in range(3))
-print("%%s fwd %%.1f us %%.0f GB/s | inv %%.1f us %%.0f GB/s" %% (os.path.basename(sys.argv[1]), f * 1e3, L_ * batch * 512 / f / 1e6, i * 1e3, L_ * batch * 512 / i / 1e6))
+ms = min(run(10) for _ in range(3))
+print("%%s %%.4f ms %%.1f GB/s" %% (os.path.basename(sys.argv[1]), ms, ctx.nlimbs * nmat * rows * cols * 256 / ms / 1e6))
 ''' % ROOT
 variants = sorted(f for f in os.listdir(os.path.join(HERE, "variants")) if f.endswith(".so"))
 for rnd in range(2):
