@@ -14,7 +14,6 @@ N > 1   = N independent instances, one per GPU (weak scaling, BASELINE configs[4
           RCCL all-reduce of a 64-bit checksum of the aggregated commitments (u_1, u_2) after the timed steps.
 """
 import argparse
-import ctypes
 import json
 import math
 import os
@@ -23,7 +22,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np
 import torch
@@ -75,6 +73,35 @@ def cpu_baseline(q, products_per_proof, seconds=12.0):
                       % (products, cores, dt, products_per_proof)}
 
 
+def challenge_poly(rng, q):
+    """fetch_challenge's multiset (src/verification.rs:460-479): 23 zeros, 31 ones, 10 twos, random order and sign."""
+    vals = np.array([0] * 23 + [1] * 31 + [2] * 10, dtype=np.int64)
+    rng.shuffle(vals)
+    signs = rng.integers(0, 2, size=D)
+    return np.where((vals > 0) & (signs == 1), q - vals, vals).astype(np.uint64)
+
+
+def make_inputs(k, q, seed):
+    """Seeded synthetic witness / state / challenge tape (same recipe as tests/cases.py, without the oracle):
+    witness coefficients uniform in [0, beta/sqrt(n r d)] so the norm bound of generate_witness holds
+    (src/proofgen.rs:460-518), phi and a uniform (src/structs.rs:289-314), Pi in {-1,0,1} with weights
+    1/4,1/2,1/4 (src/verification.rs:553-566), psi, omega, alpha, beta uniform, c_i challenge-shaped."""
+    rng = np.random.default_rng(seed)
+    n, r = k.N, k.R
+    wb = max(1, int(k.BETA_BOUND / math.sqrt(n * r * D)))
+    S = rng.integers(0, wb + 1, size=(n, r, D), dtype=np.uint64)
+    phi = rng.integers(0, q, size=(n, r, D), dtype=np.uint64)
+    a = rng.integers(0, q, size=(r, r, D), dtype=np.uint64)
+    for i in range(r):
+        for j in range(i):
+            a[i, j] = a[j, i]
+    Pi = rng.choice(np.array([-1, 0, 1], dtype=np.int8), size=(r, 256, n * D), p=[0.25, 0.5, 0.25]).astype(np.int8)
+    tape = dict(Pi=Pi, psi=int(rng.integers(0, q)), omega=rng.integers(0, q, size=256, dtype=np.uint64),
+                alpha=rng.integers(0, q, size=D, dtype=np.uint64), beta=rng.integers(0, q, size=D, dtype=np.uint64),
+                c=np.stack([challenge_poly(rng, q) for _ in range(r)]))
+    return S, phi, a, tape
+
+
 def checksum_u64(t):
     """Order-independent 64-bit checksum of a device tensor of residues (sum mod 2^63)."""
     return (t.to(torch.int64).sum() & ((1 << 62) - 1)).reshape(1)
@@ -111,19 +138,15 @@ def main():
             dist.init_process_group(backend)
 
     import labrador_snark_amd as lab
-    import cases
 
     q, n, r, kappa = args.q, args.n, args.r, args.kappa
-    p = cases.Params(q, n, r, kappa, kappa)
     k = lab.RuntimeConstants(q, n, r, kappa, kappa, kappa)
     # longest reduction in the prover: r*t1*kappa digit terms (small operands) — ask for enough CRT range
     ctx = lab.Context(q, gpu_index, max(65536, n * r + r * r))
     ctx.use_torch_stream()
 
     # instance `50 + rank`: witness/state/tape resident on the device
-    S, phi, a, tape = cases.make_inputs(p, seed=50 + rank)
-    from oracle import coracle as co
-    b_poly = np.empty(D, np.uint64)
+    S, phi, a, tape = make_inputs(k, q, seed=50 + rank)
     # b' = const term of b = sum a_ij<s_i,s_j> + sum <phi_i,s_i> (src/structs.rs:320-341, 373): computed on the GPU
     # with the product's own kernels (the oracle is not on the product path)
     hS, hphi, ha = ctx.vec_from(S), ctx.vec_from(phi), ctx.vec_from(a)

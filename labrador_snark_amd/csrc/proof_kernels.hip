@@ -345,43 +345,52 @@ namespace lab {
 __global__ void __launch_bounds__(256)
 k_pi_fused(unsigned long long* __restrict__ proj, uint64_t* __restrict__ W, const int8_t* __restrict__ Pi,
            const uint64_t* __restrict__ S, const uint64_t* __restrict__ omega, unsigned n, unsigned r, uint64_t q) {
-  __shared__ uint64_t om[256];
+  // Every product here is (entry in {-1,0,1}) x (value < 2^40).  Values are split at bit 20 so each product is one
+  // v_mad_i64_i32 (sign-extended byte times a 20-bit half, accumulated in 64 bits) instead of compare/select chains.
+  __shared__ int om_lo[256], om_hi[256];
   __shared__ long long rowsum[4][256];
-  om[threadIdx.x] = omega[threadIdx.x];
+  {
+    const uint64_t o = omega[threadIdx.x];
+    om_lo[threadIdx.x] = (int)(o & 0xFFFFF);
+    om_hi[threadIdx.x] = (int)(o >> 20);
+  }
   __syncthreads();
   const size_t cols = (size_t)n * D;
   const unsigned i = blockIdx.y;
   const size_t col0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
   const bool active = col0 < cols;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  long long s[16];
-  uint64_t pos[16], neg[16];
+  int s_lo[16], s_hi[16];
+  long long wl[16], wh[16];
 #pragma unroll
-  for (int c = 0; c < 16; c++) { s[c] = 0; pos[c] = 0; neg[c] = 0; }
+  for (int c = 0; c < 16; c++) { s_lo[c] = 0; s_hi[c] = 0; wl[c] = 0; wh[c] = 0; }
   if (active) {
     const uint64_t* sp = S + ((col0 / D) * r + i) * D + (col0 % D);
 #pragma unroll
     for (int c = 0; c < 16; c += 2) {
       const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(sp + c);
-      s[c] = (long long)v.x; s[c + 1] = (long long)v.y;
+      s_lo[c] = (int)(v.x & 0xFFFFF); s_hi[c] = (int)(v.x >> 20);
+      s_lo[c + 1] = (int)(v.y & 0xFFFFF); s_hi[c + 1] = (int)(v.y >> 20);
     }
   }
   const int8_t* pp = Pi + (size_t)i * 256 * cols + (active ? col0 : 0);
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 #pragma unroll 2
   for (int m = 0; m < 256; m++) {
-    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
     u32x4_t w = {0, 0, 0, 0};
     if (active) w = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(pp + (size_t)m * cols));  // Pi is read once
     const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-    const uint64_t o = om[m];
-    long long a = 0;
+    const int ol = om_lo[m], oh = om_hi[m];
+    long long a_lo = 0, a_hi = 0;
 #pragma unroll
     for (int c = 0; c < 16; c++) {
-      const int8_t e = (int8_t)(ww[c >> 2] >> ((c & 3) * 8));
-      a += e > 0 ? s[c] : (e < 0 ? -s[c] : 0);
-      pos[c] += e > 0 ? o : 0;
-      neg[c] += e < 0 ? o : 0;
+      const int e = (int)(int8_t)(ww[c >> 2] >> ((c & 3) * 8));
+      a_lo += (long long)e * s_lo[c];
+      a_hi += (long long)e * s_hi[c];
+      wl[c] += (long long)e * ol;
+      wh[c] += (long long)e * oh;
     }
+    long long a = a_lo + (a_hi << 20);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
     if (lane == 0) rowsum[wave][m] = a;
@@ -396,7 +405,9 @@ k_pi_fused(unsigned long long* __restrict__ proj, uint64_t* __restrict__ W, cons
     const size_t x = col0 / D, k0 = col0 % D;
 #pragma unroll
     for (int c = 0; c < 16; c++) {
-      const uint64_t u = submod(pos[c] % q, neg[c] % q, q);
+      const long long v = wl[c] + (wh[c] << 20);          // sum_m omega[m]*Pi[m][col], |v| < 2^49
+      const uint64_t mag = (uint64_t)(v < 0 ? -v : v) % q;
+      const uint64_t u = v < 0 ? (mag == 0 ? 0 : q - mag) : mag;
       const size_t k = k0 + c;
       W[(x * r + i) * D + (k == 0 ? 0 : D - k)] = k == 0 ? u : (u == 0 ? 0 : q - u);
     }
