@@ -218,7 +218,7 @@ def main():
         result = {
             "metric": "prover constraints/sec", "value": value, "unit": "constraints/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 residues (u64 accumulate)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": "full Prover::proof_gen n=%d r=%d d=64, kappa=kappa1=kappa2=%d, q=%d (%d RNS limbs), "
                                    "CRS resident in transform domain, CRS expansion excluded" % (n, r, kappa, q, ctx.nlimbs),

@@ -125,9 +125,12 @@ extern "C" int lab_prove_core(lab_ctx* c, const lab_prove_input* in, lab_transcr
   auto HV = [&](size_t off) { return HatView{hat_base + off * D, hat_words}; };
   auto HD = [&](size_t off) { return HatView{hatd_base + off * D, hatd_words}; };
   auto CO = [&](size_t elems) { return cv.take<uint64_t>(elems * D); };
-  uint64_t *cT = CO(rk), *cTdec = CO(rk * t1), *cG = CO(rr), *cGup = CO(pairs), *cGdec = CO(pairs * t2), *cW = CO(nr),
-           *cphipp = CO(nr), *capp = CO(rr), *cphif = CO(nr), *cX = CO(rr), *cH = CO(rr), *cHup = CO(pairs),
-           *cHdec = CO(pairs * t1), *cu1 = CO(k1), *cu2 = CO(k2), *cz = CO(n), *cbpp = CO(1), *cab = CO(2);
+  // results the caller wants in device memory are produced in place (no staging copy)
+  auto OUT = [&](uint64_t* user, size_t elems) { return (user && is_device_pointer(user)) ? user : CO(elems); };
+  uint64_t *cT = OUT(out->t_i_all, rk), *cTdec = CO(rk * t1), *cG = OUT(out->g_mat, rr), *cGup = CO(pairs),
+           *cGdec = CO(pairs * t2), *cW = CO(nr), *cphipp = CO(nr), *capp = CO(rr), *cphif = CO(nr), *cX = CO(rr),
+           *cH = OUT(out->h_mat, rr), *cHup = CO(pairs), *cHdec = CO(pairs * t1), *cu1 = OUT(out->u_1, k1),
+           *cu2 = OUT(out->u_2, k2), *cz = OUT(out->z, n), *cbpp = CO(1), *cab = CO(2);
   int64_t* dproj_int = cv.take<int64_t>(256);
   uint64_t* dproj = cv.take<uint64_t>(256);
   Staging st(c, &cv);
@@ -225,7 +228,7 @@ extern "C" int lab_prove_core(lab_ctx* c, const lab_prove_input* in, lab_transcr
       {out->u_1, cu1, k1 * D}, {out->projection, dproj, 256}, {out->b_prime_prime, cbpp, D}, {out->u_2, cu2, k2 * D},
       {out->z, cz, n * D}, {out->t_i_all, cT, rk * D}, {out->g_mat, cG, rr * D}, {out->h_mat, cH, rr * D}};
   for (auto& o : outs)
-    if (o.dst) LAB_HIP(c, hipMemcpyAsync(o.dst, o.src, o.words * 8, hipMemcpyDefault, s));
+    if (o.dst && o.dst != o.src) LAB_HIP(c, hipMemcpyAsync(o.dst, o.src, o.words * 8, hipMemcpyDefault, s));
   if (out->projection_int) LAB_HIP(c, hipMemcpyAsync(out->projection_int, dproj_int, 256 * 8, hipMemcpyDefault, s));
   int64_t hproj[256];
   uint64_t hbpp0 = 0, homega[256];
