@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--n", type=int, default=1024)
     ap.add_argument("--r", type=int, default=32)
     ap.add_argument("--kappa", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=8,
+                    help="independent proofs per step and GPU; they share the common reference string, which is then "
+                         "streamed from HBM once per batch (1 = one proof per call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-compact-crs", action="store_true", help="keep B, C, D in the main RNS basis (12 B/coefficient at the 33-bit q)")
@@ -145,32 +148,36 @@ def main():
     ctx = lab.Context(q, gpu_index, max(65536, n * r + r * r))
     ctx.use_torch_stream()
 
-    # instance `50 + rank`: witness/state/tape resident on the device
-    S, phi, a, tape = make_inputs(k, q, seed=50 + rank)
-    # b' = const term of b = sum a_ij<s_i,s_j> + sum <phi_i,s_i> (src/structs.rs:320-341, 373): computed on the GPU
-    # with the product's own kernels (the oracle is not on the product path)
-    hS, hphi, ha = ctx.vec_from(S), ctx.vec_from(phi), ctx.vec_from(a)
-    G = lab.gram(ctx, hS, hS, n, r)
-    Gc = ctx.vec_from(G.store())
-    t1v = lab.polynomial_vec_inner_product(ctx, ha, Gc).store()[0]
-    t2v = lab.polynomial_vec_inner_product(ctx, hphi, hS).store()[0]
-    b_prime = int((int(t1v[0]) + int(t2v[0])) % q)
-    for v in (hS, hphi, ha, G, Gc):
-        v.close()
-
     def dev64(x):
         return torch.from_numpy(np.ascontiguousarray(x).view(np.int64)).to(dev)
 
-    dS, dphi, da = dev64(S), dev64(phi), dev64(a)
-    dtape = dict(Pi=torch.from_numpy(tape["Pi"]).to(dev), psi=tape["psi"], omega=dev64(tape["omega"]),
-                 alpha=dev64(tape["alpha"]), beta=dev64(tape["beta"]), c=dev64(tape["c"]))
-    st = lab.State(dphi, da, b_prime)
+    # instances 50 + rank*batch + j: witness/state/tape resident on the device
+    nbatch = max(1, args.batch)
+    dSs, sts, dtapes = [], [], []
+    for j in range(nbatch):
+        S, phi, a, tape = make_inputs(k, q, seed=50 + rank * nbatch + j)
+        # b' = const term of b = sum a_ij<s_i,s_j> + sum <phi_i,s_i> (src/structs.rs:320-341, 373): computed on the
+        # GPU with the product's own kernels (the oracle is not on the product path)
+        hS, hphi, ha = ctx.vec_from(S), ctx.vec_from(phi), ctx.vec_from(a)
+        G = lab.gram(ctx, hS, hS, n, r)
+        Gc = ctx.vec_from(G.store())
+        t1v = lab.polynomial_vec_inner_product(ctx, ha, Gc).store()[0]
+        t2v = lab.polynomial_vec_inner_product(ctx, hphi, hS).store()[0]
+        b_prime = int((int(t1v[0]) + int(t2v[0])) % q)
+        for v in (hS, hphi, ha, G, Gc):
+            v.close()
+        dSs.append(dev64(S))
+        sts.append(lab.State(dev64(phi), dev64(a), b_prime))
+        dtapes.append(dict(Pi=torch.from_numpy(tape["Pi"]).to(dev), psi=tape["psi"], omega=dev64(tape["omega"]),
+                           alpha=dev64(tape["alpha"]), beta=dev64(tape["beta"]), c=dev64(tape["c"])))
     # B, C, D are only ever multiplied by decomposition digits: keep them in the digit basis (u16 small limb)
     crs = lab.ResidentCRS(ctx, k, compact=not args.no_compact_crs).fill_synthetic(1000 + 10 * rank)
     torch.cuda.synchronize()
 
     def step():
-        return lab.prove_core(ctx, k, dS, st, crs, dtape, device_outputs=True)
+        if nbatch == 1:
+            return lab.prove_core(ctx, k, dSs[0], sts[0], crs, dtapes[0], device_outputs=True)
+        return lab.prove_core_batch(ctx, k, dSs, sts, crs, dtapes, device_outputs=True)[-1]
 
     for _ in range(args.warmup):
         T = step()
@@ -199,7 +206,7 @@ def main():
 
     result = None
     if rank == 0:
-        proofs = world * args.steps
+        proofs = world * args.steps * nbatch
         value = proofs / elapsed
         per_launch_s = (kernel_ms / 1e3) / max(launches, 1)
         achieved = (alg_bytes / max(launches, 1)) / per_launch_s / 1e9 if launches else 0.0
@@ -210,7 +217,7 @@ def main():
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
-                if rec.get("workload_key") == [q, n, r, kappa, ctx.nlimbs, bool(crs.compact)]:
+                if rec.get("workload_key") == [q, n, r, kappa, ctx.nlimbs, bool(crs.compact), nbatch]:
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -221,10 +228,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": "full Prover::proof_gen n=%d r=%d d=64, kappa=kappa1=kappa2=%d, q=%d (%d RNS limbs), "
-                                   "CRS resident in transform domain, CRS expansion excluded" % (n, r, kappa, q, ctx.nlimbs),
+                                   "CRS resident in transform domain, CRS expansion excluded; %d independent proofs per step share the CRS"
+                                   % (n, r, kappa, q, ctx.nlimbs, nbatch),
                        "q": q, "n": n, "r": r, "kappa": kappa, "t1": k.T_1, "t2": k.T_2, "b1": k.B_1, "b2": k.B_2,
                        "nlimbs": ctx.nlimbs, "crs_basis": ("digit basis %s, u16 last limb" % getattr(ctx, "digit_primes", None))
-                       if crs.compact else "main basis", "instances_per_gpu": 1, "parallelism": "instance-per-gpu x%d" % world},
+                       if crs.compact else "main basis", "proofs_per_step_per_gpu": nbatch, "parallelism": "%d independent proofs per gpu x %d gpus" % (nbatch, world)},
+            "ms_per_proof": elapsed / (args.steps * nbatch) * 1e3,
             "proofs_per_s": value, "witness_Rq_elems_per_s": value * n * r,
             "ring_products_per_proof": sum(counts.values()),
             "checksum_u1_u2": int(chk.item()),

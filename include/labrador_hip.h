@@ -172,6 +172,12 @@ int lab_inner_product(lab_ctx *ctx, lab_vec *out, size_t out_off, const lab_vec 
 int lab_matvec_sum(lab_ctx *ctx, lab_vec *out, size_t out_off, const lab_vec *M, size_t m_off, size_t nmat,
                    size_t rows, size_t cols, const lab_vec *V, size_t v_off);
 
+/* The same sum for nb (1, 2, 4 or 8) independent vector sets that share the matrices — e.g. the outer commitments
+ * of nb independent proofs under one common reference string, which is then streamed from HBM once instead of nb
+ * times:  out[out_off + b*rows + rho] = sum_m < M[m][rho,:], V[v_off + (b*nmat + m)*cols ..+cols] >. */
+int lab_matvec_sum_batched(lab_ctx *ctx, lab_vec *out, size_t out_off, const lab_vec *M, size_t m_off, size_t nmat,
+                           size_t rows, size_t cols, const lab_vec *V, size_t v_off, int nb);
+
 /* The inner Ajtai commitments for all r witness columns at once
  * (src/proofgen.rs:41-49; also verifier check 15, src/verification.rs:274-279):
  *   out[out_off + i*rows + rho] = < A[a_off + rho*inner ..+inner], S[:, i] >,  S = [inner][ncols] row-major
@@ -265,6 +271,16 @@ typedef struct {
  * resamples up to 5 times, src/proofgen.rs:169-181 — the caller does that with a fresh tape), or
  * LAB_ERR_BPP_CHECK when verify_b_prime_prime's assertion would fire (src/verification.rs:550). */
 int lab_prove_core(lab_ctx *ctx, const lab_prove_input *in, lab_transcript *out);
+
+/* `nproofs` independent proofs under ONE common reference string (same A, B, C, D handles, dimensions and
+ * constants; each with its own witness, state and challenge tape).  Per-proof work is issued proof by proof; the
+ * outer commitment sum_{i,k} B_ik t_i^(k) — whose cost is streaming the B matrices from HBM — is issued once per
+ * group of up to 8 proofs with lab_matvec_sum_batched's kernel, so the CRS is read once per group rather than once
+ * per proof.  Every transcript is bit-identical to what lab_prove_core returns for that proof alone.
+ * status[j] (if status != NULL) receives LAB_OK / LAB_ERR_JL_REJECTED / LAB_ERR_BPP_CHECK for proof j and the call
+ * returns LAB_OK; with status == NULL the first failing proof's code is returned. */
+int lab_prove_core_batch(lab_ctx *ctx, size_t nproofs, const lab_prove_input *const *in, lab_transcript *const *out,
+                         int *status);
 
 /* ---- Verifier::verify (src/verification.rs:25-438) on the same kernels — SURVEY §8(f) row f3 ----
  * `in` carries the state, the tape stored in the transcript (pi_i_all as int8, psi, omega, alpha, beta, c) and the

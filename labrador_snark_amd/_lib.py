@@ -101,6 +101,8 @@ SIGNATURES = {
                                     C.c_size_t, C.c_size_t]),
     "lab_matvec_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
                                  C.c_size_t, C.c_void_p, C.c_size_t]),
+    "lab_matvec_sum_batched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
+                                         C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]),
     "lab_ajtai_commit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
                                    C.c_void_p, C.c_size_t, C.c_size_t]),
     "lab_gram": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
@@ -119,6 +121,8 @@ SIGNATURES = {
     "lab_sigma_inv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "lab_jl_project": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     "lab_prove_core": (C.c_int, [C.c_void_p, C.POINTER(lab_prove_input), C.POINTER(lab_transcript)]),
+    "lab_prove_core_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.POINTER(lab_prove_input)),
+                                       C.POINTER(C.POINTER(lab_transcript)), C.POINTER(C.c_int)]),
     "lab_verify_core": (C.c_int, [C.c_void_p, C.POINTER(lab_prove_input), C.POINTER(lab_transcript), C.c_void_p,
                                   C.c_int64, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
 }

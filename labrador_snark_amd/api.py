@@ -214,6 +214,14 @@ def matvec_sum(ctx, M, V, nmat, rows, cols, m_off=0, v_off=0, out=None, out_off=
     return out
 
 
+def matvec_sum_batched(ctx, M, V, nmat, rows, cols, nb, m_off=0, v_off=0, out=None, out_off=0):
+    """nb independent vector sets sharing the matrices M (the CRS is streamed once for all of them)."""
+    if out is None:
+        out = HatVec(ctx, nb * rows, digit=M.digit)
+    ctx._check(ctx._lib.lab_matvec_sum_batched(ctx._h, out._h, out_off, M._h, m_off, nmat, rows, cols, V._h, v_off, nb))
+    return out
+
+
 def ajtai_commit(ctx, A, S, rows, inner, ncols, a_off=0, s_off=0, out=None, out_off=0):
     """t_i_all[i][rho] = <A[rho,:], s_i> for every witness column (src/proofgen.rs:41-49). out: [ncols][rows]."""
     if out is None:

@@ -661,6 +661,32 @@ extern "C" int lab_matvec_sum(lab_ctx* c, lab_vec* out, size_t out_off, const la
 }
 
 namespace lab {
+// partial[b][m][rho] for nb vector sets sharing the (possibly compact) matrices M; V set b at v.base + b*v_bs
+int matvec_partial_batched_any(lab_ctx* c, int nb, HatView partial, size_t partial_bs, const lab_vec* M, size_t m_off,
+                               ConstHatView V, size_t v_bs, size_t nmat, size_t rows, size_t cols) {
+  const int nfull = M->planes32();
+  const bool prof = c->prof_on && nfull > 0;
+  if (prof && c->prof_used == c->prof_events.size()) {
+    hipEvent_t a, b;
+    LAB_HIP(c, hipEventCreate(&a));
+    LAB_HIP(c, hipEventCreate(&b));
+    c->prof_events.emplace_back(a, b);
+  }
+  if (prof) LAB_HIP(c, hipEventRecord(c->prof_events[c->prof_used].first, c->stream));
+  if (nfull > 0)
+    LAB_HIP(c, launch_matvec_partial_batched(nb, partial, partial_bs, M->view(m_off), V, v_bs, nmat, rows, cols, nfull,
+                                             M->tabs(), c->stream));
+  if (prof) {
+    LAB_HIP(c, hipEventRecord(c->prof_events[c->prof_used++].second, c->stream));
+    c->prof_bytes += (double)nfull * 256.0 * ((double)nmat * rows * cols + (double)nb * nmat * cols + (double)nb * nmat * rows);
+  }
+  if (M->compact)
+    LAB_HIP(c, launch_matvec_partial_batched_u16(nb, partial.base + (size_t)nfull * partial.plane_stride, partial_bs,
+                                                 M->d16 + m_off * D, V.base + (size_t)nfull * V.plane_stride, v_bs, nmat,
+                                                 rows, cols, M->tabs() + nfull, c->stream));
+  return LAB_OK;
+}
+
 // number of equal chunks a long inner product is cut into (a single block would otherwise stream it alone)
 size_t inner_product_splits(size_t len) {
   size_t k = 1;
@@ -679,6 +705,33 @@ int inner_product_impl(lab_ctx* c, HatView out, ConstHatView v1, ConstHatView v2
   return LAB_OK;
 }
 }  // namespace lab
+
+extern "C" int lab_matvec_sum_batched(lab_ctx* c, lab_vec* out, size_t out_off, const lab_vec* M, size_t m_off, size_t nmat,
+                                      size_t rows, size_t cols, const lab_vec* V, size_t v_off, int nb) {
+  if (!c) return LAB_ERR_ARG;
+  if (nb != 1 && nb != 2 && nb != 4 && nb != 8) return fail(c, LAB_ERR_ARG, "lab_matvec_sum_batched: nb must be 1, 2, 4 or 8");
+  int rc;
+  if (nmat == 0 || rows == 0 || cols == 0) return fail(c, LAB_ERR_ARG, "lab_matvec_sum_batched: empty dimension");
+  if (rows > 0x7fffffffu || cols > 0x7fffffffu / 64 || nmat > 65535) return fail(c, LAB_ERR_ARG, "lab_matvec_sum_batched: dimension too large");
+  if ((rc = check_range(c, out, out_off, (size_t)nb * rows, "lab_matvec_sum_batched(out)"))) return rc;
+  if ((rc = check_range(c, M, m_off, nmat * rows * cols, "lab_matvec_sum_batched(M)"))) return rc;
+  if ((rc = check_range(c, V, v_off, (size_t)nb * nmat * cols, "lab_matvec_sum_batched(V)"))) return rc;
+  const int basis = M->basis;
+  if ((rc = check_plain(c, V, basis, "lab_matvec_sum_batched(V)")) || (rc = check_plain(c, out, basis, "lab_matvec_sum_batched(out)"))) return rc;
+  const uint64_t limit = basis ? c->dg_terms : c->max_len;
+  if ((u128)nmat * cols > limit) return fail(c, LAB_ERR_RANGE, "lab_matvec_sum_batched: reduction length %zu exceeds the exactness bound %llu of this basis", nmat * cols, (unsigned long long)limit);
+  LAB_HIP(c, hipSetDevice(c->device));
+  const size_t pw = (size_t)nb * nmat * rows * D;
+  if ((rc = ensure_scratch(c, (size_t)M->nlimbs() * pw * 4))) return rc;
+  HatView partial{static_cast<uint32_t*>(c->scratch), pw};
+  ConstHatView vv = V->view(v_off);
+  if ((rc = matvec_partial_batched_any(c, nb, partial, nmat * rows * D, M, m_off, vv, nmat * cols * D, nmat, rows, cols))) return rc;
+  for (int b = 0; b < nb; b++) {
+    HatView pb{partial.base + (size_t)b * nmat * rows * D, pw};
+    LAB_HIP(c, launch_sum_terms(out->view(out_off + (size_t)b * rows), pb, nmat, rows, M->nlimbs(), M->tabs(), c->stream));
+  }
+  return LAB_OK;
+}
 
 extern "C" int lab_inner_product(lab_ctx* c, lab_vec* out, size_t out_off, const lab_vec* v1, size_t off1,
                                  const lab_vec* v2, size_t off2, size_t len) {

@@ -140,6 +140,8 @@ inline const CrtTable* basis_crt(const lab_ctx* c, int basis) { return basis ? c
 // sum_m <M[m][rho,:], V[m]> partials with M possibly compact: all limbs of the matrix's basis
 int matvec_partial_any(lab_ctx* c, HatView partial, const lab_vec* M, size_t m_off, ConstHatView V, size_t nmat,
                        size_t rows, size_t cols);
+int matvec_partial_batched_any(lab_ctx* c, int nb, HatView partial, size_t partial_bs, const lab_vec* M, size_t m_off,
+                               ConstHatView V, size_t v_bs, size_t nmat, size_t rows, size_t cols);
 int axpy_commit_any(lab_ctx* c, HatView out, ConstHatView G, const lab_vec* Cm, size_t c_off, size_t nterms, size_t len,
                     HatView partial);
 

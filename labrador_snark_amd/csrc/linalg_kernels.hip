@@ -94,6 +94,8 @@ template <> struct Quad<uint32_t> {
     const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
   }
+  static __device__ __forceinline__ raw load_raw(const raw* p) { return load(p); }
+  static __device__ __forceinline__ uint4 unpack(const raw& v) { return v; }
 };
 template <> struct Quad<uint16_t> {
   typedef uint2 raw;
@@ -101,140 +103,451 @@ template <> struct Quad<uint16_t> {
     const u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p));
     return make_uint4(v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16);
   }
+  static __device__ __forceinline__ raw load_raw(const raw* p) {
+    const u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p));
+    return make_uint2(v.x, v.y);
+  }
+  static __device__ __forceinline__ uint4 unpack(const raw& v) {
+    return make_uint4(v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16);
+  }
 };
 
-template <typename MT>
+// NB = number of independent right-hand-side sets ("proofs in the batch") that share the streamed matrices:
+// the common reference string is read once for all of them.  Vector set b lives at V + b*v_bs, its partials at
+// partial + b*partial_bs (word strides inside one limb plane).
+template <typename MT, int NB>
 __global__ void __launch_bounds__(64 * MV_WAVES)
-k_matvec_partial(uint32_t* __restrict__ partial, size_t partial_ps, const MT* __restrict__ M, size_t m_ps,
-                 const uint32_t* __restrict__ V, size_t v_ps, unsigned rows, unsigned cols,
+k_matvec_partial(uint32_t* __restrict__ partial, size_t partial_ps, size_t partial_bs, const MT* __restrict__ M, size_t m_ps,
+                 const uint32_t* __restrict__ V, size_t v_ps, size_t v_bs, unsigned rows, unsigned cols,
                  const LimbTable* __restrict__ tabs) {
   typedef typename Quad<MT>::raw mraw;
-  __shared__ uint32_t red[MV_WAVES][MV_ROWS][D];
+  constexpr int ROWS = NB >= 4 ? 2 : MV_ROWS;     // keep the accumulator file at <= 64 x u64 per lane
+  constexpr int GROUP = NB >= 4 ? 2 : 4;          // chunks whose loads are issued together
+  __shared__ uint32_t red[MV_WAVES][ROWS * NB][D];
   const int limb = blockIdx.z;
   const unsigned mat = blockIdx.y;
-  const unsigned row0 = blockIdx.x * MV_ROWS;
+  const unsigned row0 = blockIdx.x * ROWS;
   const uint32_t p = tabs[limb].p, p2 = tabs[limb].p2, pinv = tabs[limb].pinv, r2 = tabs[limb].r2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane >> 4;          // polynomial within the 4-poly chunk
   const int jq = lane & 15;           // slots 4*jq .. 4*jq+3
 
   const uint4* Vp = reinterpret_cast<const uint4*>(V + (size_t)limb * v_ps + (size_t)mat * cols * D);
-  const mraw* Mp[MV_ROWS];
+  const size_t vb4 = v_bs / 4;
+  const mraw* Mp[ROWS];
 #pragma unroll
-  for (int r = 0; r < MV_ROWS; r++) {
+  for (int r = 0; r < ROWS; r++) {
     unsigned row = min(row0 + r, rows - 1);  // clamp: out-of-range rows recompute the last row and are not stored
     Mp[r] = reinterpret_cast<const mraw*>(M + (size_t)limb * m_ps + ((size_t)mat * rows + row) * cols * D);
   }
 
-  uint64_t acc[MV_ROWS][4];
+  uint64_t acc[ROWS][NB][4];
 #pragma unroll
-  for (int r = 0; r < MV_ROWS; r++)
+  for (int r = 0; r < ROWS; r++)
 #pragma unroll
-    for (int k = 0; k < 4; k++) acc[r][k] = 0;
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) acc[r][b][k] = 0;
 
   // chunk index ch covers polynomials 4*ch .. 4*ch+3; this lane's polynomial is 4*ch+sub.
-  // Fast path: 8 full chunks per accumulator fold, loads of 4 chunks x (MV_ROWS+1) streams in flight.
+  // Fast path: 8 full chunks per accumulator fold, loads of GROUP chunks x (ROWS+NB) streams in flight.
   const unsigned full_chunks = cols / 4;
   const unsigned nchunks = (cols + 3) / 4;
   unsigned ch = wave;
   while (ch + 7u * MV_WAVES < full_chunks) {
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-      uint4 v[4], m[4][MV_ROWS];
+    for (int part = 0; part < 8 / GROUP; part++) {
+      uint4 v[GROUP][NB], m[GROUP][ROWS];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < GROUP; u++) {
         const size_t off = (size_t)((ch + u * MV_WAVES) * 4 + sub) * 16 + jq;  // uint4 index of (poly, 4 slots)
-        v[u] = Vp[off];
 #pragma unroll
-        for (int r = 0; r < MV_ROWS; r++) m[u][r] = Quad<MT>::load(Mp[r] + off);
+        for (int b = 0; b < NB; b++) v[u][b] = Vp[off + b * vb4];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) m[u][r] = Quad<MT>::load(Mp[r] + off);
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++)
+      for (int u = 0; u < GROUP; u++)
 #pragma unroll
-        for (int r = 0; r < MV_ROWS; r++) {
-          acc[r][0] += (uint64_t)m[u][r].x * v[u].x;
-          acc[r][1] += (uint64_t)m[u][r].y * v[u].y;
-          acc[r][2] += (uint64_t)m[u][r].z * v[u].z;
-          acc[r][3] += (uint64_t)m[u][r].w * v[u].w;
-        }
-      ch += 4 * MV_WAVES;
+        for (int r = 0; r < ROWS; r++)
+#pragma unroll
+          for (int b = 0; b < NB; b++) {
+            acc[r][b][0] += (uint64_t)m[u][r].x * v[u][b].x;
+            acc[r][b][1] += (uint64_t)m[u][r].y * v[u][b].y;
+            acc[r][b][2] += (uint64_t)m[u][r].z * v[u][b].z;
+            acc[r][b][3] += (uint64_t)m[u][r].w * v[u][b].w;
+          }
+      ch += GROUP * MV_WAVES;
     }
 #pragma unroll
-    for (int r = 0; r < MV_ROWS; r++)
+    for (int r = 0; r < ROWS; r++)
 #pragma unroll
-      for (int k = 0; k < 4; k++) acc[r][k] = acc_fold(acc[r][k], p, p2);
+      for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[r][b][k] = acc_fold(acc[r][b][k], p, p2);
   }
   // tail: at most 8 chunks are left for this wave (the last may be partial)
   for (; ch < nchunks; ch += MV_WAVES) {
     const unsigned c = ch * 4 + sub;
     if (c < cols) {
       const size_t off = (size_t)c * 16 + jq;
-      const uint4 v = Vp[off];
+      uint4 v[NB];
 #pragma unroll
-      for (int r = 0; r < MV_ROWS; r++) {
+      for (int b = 0; b < NB; b++) v[b] = Vp[off + b * vb4];
+#pragma unroll
+      for (int r = 0; r < ROWS; r++) {
         const uint4 m = Quad<MT>::load(Mp[r] + off);
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+          acc[r][b][0] += (uint64_t)m.x * v[b].x;
+          acc[r][b][1] += (uint64_t)m.y * v[b].y;
+          acc[r][b][2] += (uint64_t)m.z * v[b].z;
+          acc[r][b][3] += (uint64_t)m.w * v[b].w;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < ROWS; r++)
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) acc[r][b][k] = acc_fold(acc[r][b][k], p, p2);
+
+  // per-lane partials -> canonical residues (scale 2^-32), then sum the 4 lane groups of the wave
+#pragma unroll
+  for (int r = 0; r < ROWS; r++)
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint32_t x = redc64(acc[r][b][k], p, pinv);
+        x += __shfl_xor(x, 16);
+        x += __shfl_xor(x, 32);             // < 4p < 2^32
+        x = csub(csub(x, p2), p);
+        if (sub == 0) red[wave][r * NB + b][jq * 4 + k] = x;
+      }
+  __syncthreads();
+  // finish the ROWS*NB outputs: 64 lanes per output, MV_WAVES outputs at a time
+  for (int o = wave; o < ROWS * NB; o += MV_WAVES) {
+    const int r = o / NB, b = o % NB, j = lane;
+    if (row0 + r < rows) {
+      uint32_t x = 0;                     // MV_WAVES canonical residues: reduce after every 4 (4p < 2^32)
+#pragma unroll
+      for (int w0 = 0; w0 < MV_WAVES; w0 += 4) {
+        uint32_t y = 0;
+#pragma unroll
+        for (int w = w0; w < w0 + 4 && w < MV_WAVES; w++) y += red[w][o][j];
+        x = csub(x + csub(csub(y, p2), p), p);
+      }
+      x = mont_mul(x, r2, p, pinv);       // undo the 2^-32 of redc64: plain residue
+      partial[(size_t)limb * partial_ps + (size_t)b * partial_bs + ((size_t)mat * rows + row0 + r) * D + j] = x;
+    }
+  }
+}
+
+// Row-split variant for tall matrices and several vector sets: wave w of the block owns rows row0+2w, row0+2w+1
+// and walks ALL chunks of them, so the 8 waves of a block read the same vector chunks (served by L1 after the
+// first wave) and a vector byte fetched from L2 feeds 16 rows x NB sets.  No cross-wave reduction is needed.
+constexpr int RS_ROWS_W = 2;  // rows per wave
+
+template <typename MT, int NB>
+__global__ void __launch_bounds__(64 * MV_WAVES)
+k_matvec_rowsplit(uint32_t* __restrict__ partial, size_t partial_ps, size_t partial_bs, const MT* __restrict__ M, size_t m_ps,
+                  const uint32_t* __restrict__ V, size_t v_ps, size_t v_bs, unsigned rows, unsigned cols,
+                  const LimbTable* __restrict__ tabs) {
+  typedef typename Quad<MT>::raw mraw;
+  constexpr int GROUP = NB >= 4 ? 2 : 4;
+  const int limb = blockIdx.z;
+  const unsigned mat = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned row0 = (blockIdx.x * MV_WAVES + wave) * RS_ROWS_W;
+  if (row0 >= rows) return;  // whole wave idle (no barriers in this kernel)
+  const uint32_t p = tabs[limb].p, p2 = tabs[limb].p2, pinv = tabs[limb].pinv, r2 = tabs[limb].r2;
+  const int sub = lane >> 4, jq = lane & 15;
+  const uint4* Vp = reinterpret_cast<const uint4*>(V + (size_t)limb * v_ps + (size_t)mat * cols * D);
+  const size_t vb4 = v_bs / 4;
+  const mraw* Mp[RS_ROWS_W];
+#pragma unroll
+  for (int r = 0; r < RS_ROWS_W; r++) {
+    unsigned row = min(row0 + r, rows - 1);
+    Mp[r] = reinterpret_cast<const mraw*>(M + (size_t)limb * m_ps + ((size_t)mat * rows + row) * cols * D);
+  }
+  uint64_t acc[RS_ROWS_W][NB][4];
+#pragma unroll
+  for (int r = 0; r < RS_ROWS_W; r++)
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) acc[r][b][k] = 0;
+  const unsigned full_chunks = cols / 4, nchunks = (cols + 3) / 4;
+  unsigned ch = 0;
+  while (ch + 8 <= full_chunks) {
+#pragma unroll
+    for (int part = 0; part < 8 / GROUP; part++) {
+      uint4 v[GROUP][NB], m[GROUP][RS_ROWS_W];
+#pragma unroll
+      for (int u = 0; u < GROUP; u++) {
+        const size_t off = (size_t)((ch + u) * 4 + sub) * 16 + jq;
+#pragma unroll
+        for (int b = 0; b < NB; b++) v[u][b] = Vp[off + b * vb4];
+#pragma unroll
+        for (int r = 0; r < RS_ROWS_W; r++) m[u][r] = Quad<MT>::load(Mp[r] + off);
+      }
+#pragma unroll
+      for (int u = 0; u < GROUP; u++)
+#pragma unroll
+        for (int r = 0; r < RS_ROWS_W; r++)
+#pragma unroll
+          for (int b = 0; b < NB; b++) {
+            acc[r][b][0] += (uint64_t)m[u][r].x * v[u][b].x;
+            acc[r][b][1] += (uint64_t)m[u][r].y * v[u][b].y;
+            acc[r][b][2] += (uint64_t)m[u][r].z * v[u][b].z;
+            acc[r][b][3] += (uint64_t)m[u][r].w * v[u][b].w;
+          }
+      ch += GROUP;
+    }
+#pragma unroll
+    for (int r = 0; r < RS_ROWS_W; r++)
+#pragma unroll
+      for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[r][b][k] = acc_fold(acc[r][b][k], p, p2);
+  }
+  for (; ch < nchunks; ch++) {  // fewer than 8 chunks left
+    const unsigned c = ch * 4 + sub;
+    if (c < cols) {
+      const size_t off = (size_t)c * 16 + jq;
+      uint4 v[NB];
+#pragma unroll
+      for (int b = 0; b < NB; b++) v[b] = Vp[off + b * vb4];
+#pragma unroll
+      for (int r = 0; r < RS_ROWS_W; r++) {
+        const uint4 m = Quad<MT>::load(Mp[r] + off);
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+          acc[r][b][0] += (uint64_t)m.x * v[b].x;
+          acc[r][b][1] += (uint64_t)m.y * v[b].y;
+          acc[r][b][2] += (uint64_t)m.z * v[b].z;
+          acc[r][b][3] += (uint64_t)m.w * v[b].w;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RS_ROWS_W; r++)
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      uint32_t o[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint32_t x = redc64(acc_fold(acc[r][b][k], p, p2), p, pinv);
+        x += __shfl_xor(x, 16);
+        x += __shfl_xor(x, 32);             // < 4p < 2^32
+        o[k] = mont_mul(csub(csub(x, p2), p), r2, p, pinv);
+      }
+      if (sub == 0 && row0 + r < rows)
+        *reinterpret_cast<uint4*>(partial + (size_t)limb * partial_ps + (size_t)b * partial_bs +
+                                  ((size_t)mat * rows + row0 + r) * D + jq * 4) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---- batched mat-vec with the matrix tile staged through LDS ("sets" kernel)
+// For NB >= 2 vector sets the register file cannot hold NB x rows accumulators AND enough matrix loads in flight to
+// cover HBM latency.  Here a 512-thread block owns ST_ROWS = 16 matrix rows and walks the columns in tiles of
+// ST_COLS polynomials: the tile (16 rows x ST_COLS x 256 B) is fetched once with coalesced non-temporal loads,
+// parked in LDS (double buffered, next tile prefetched through registers) and read by every thread.
+// Thread = (slot quad jq, vector set b, row group rg): it accumulates RG = 16*NB/32 rows x 4 slots for ITS set over
+// all columns, so accumulators are RG*4 u64 per lane and no cross-thread reduction exists.  The 4 (or more) lanes
+// of a wave that share (row, jq) read the same LDS address (broadcast), the vector chunk comes from L2 once per
+// 16 rows.  HBM traffic: the matrix, once per batch.
+constexpr int ST_ROWS = 16;
+constexpr int ST_COLS = 4;
+constexpr int ST_THREADS = 512;
+// 16 rows per block, 8 when there are 8 vector sets (keeps rows-per-thread, hence the accumulator file, at 2)
+__host__ __device__ constexpr int st_rows(int nb) { return nb >= 8 ? ST_ROWS / 2 : ST_ROWS; }
+
+template <typename MT, int NB>
+__global__ void __launch_bounds__(ST_THREADS, 4)
+k_matvec_sets(uint32_t* __restrict__ partial, size_t partial_ps, size_t partial_bs, const MT* __restrict__ M, size_t m_ps,
+              const uint32_t* __restrict__ V, size_t v_ps, size_t v_bs, unsigned rows, unsigned cols,
+              const LimbTable* __restrict__ tabs) {
+  typedef typename Quad<MT>::raw mraw;
+  constexpr int SR = st_rows(NB);                             // matrix rows per block
+  constexpr int RG = SR * NB / 32;                            // rows per thread (2 for NB = 4, 8; 1 for NB = 2)
+  constexpr int QPT = SR * ST_COLS * 16 / ST_THREADS;         // matrix quads per thread per tile
+  constexpr int VQ = NB * ST_COLS * 16;                       // vector quads per tile (<= ST_THREADS)
+  __shared__ mraw tile_m[2][SR * ST_COLS * 16];
+  __shared__ uint4 tile_v[2][VQ];
+  const int limb = blockIdx.z;
+  const unsigned mat = blockIdx.y;
+  const unsigned row0 = blockIdx.x * SR;
+  const uint32_t p = tabs[limb].p, p2 = tabs[limb].p2, pinv = tabs[limb].pinv, r2 = tabs[limb].r2;
+  const int t = threadIdx.x;
+  const int jq = t & 15, b = (t >> 4) % NB, rg = (t >> 4) / NB;
+  const MT* Mbase = M + (size_t)limb * m_ps + (size_t)mat * rows * cols * D;
+
+  // producer role for the matrix: thread t fetches quads q = t + i*ST_THREADS of the tile; quad q -> row
+  // q / (ST_COLS*16), (poly, slot quad) = q % (ST_COLS*16): consecutive threads read consecutive bytes of a row
+  const mraw* src[QPT];
+  int src_poly[QPT];
+#pragma unroll
+  for (int i = 0; i < QPT; i++) {
+    const int qd = t + i * ST_THREADS;
+    const unsigned row = min(row0 + qd / (ST_COLS * 16), rows - 1);
+    src[i] = reinterpret_cast<const mraw*>(Mbase + (size_t)row * cols * D) + qd % (ST_COLS * 16);
+    src_poly[i] = (qd % (ST_COLS * 16)) / 16;
+  }
+  // producer role for the vectors: thread t < VQ fetches quad (set t / (ST_COLS*16), poly, slot quad)
+  const bool vprod = t < VQ;
+  const int v_poly = (t % (ST_COLS * 16)) / 16;
+  const uint4* vsrc = reinterpret_cast<const uint4*>(V + (size_t)limb * v_ps + (size_t)(vprod ? t / (ST_COLS * 16) : 0) * v_bs +
+                                                     (size_t)mat * cols * D) + t % (ST_COLS * 16);
+  uint64_t acc[RG][4];
+#pragma unroll
+  for (int r = 0; r < RG; r++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc[r][k] = 0;
+
+  const unsigned ntiles = (cols + ST_COLS - 1) / ST_COLS;
+  // two tiles are kept in flight in registers (sets A and B) on top of the one being consumed from LDS; the tile
+  // loop is unrolled by two so both register sets are statically indexed
+  mraw mA[QPT], mB[QPT];
+  uint4 vA = make_uint4(0, 0, 0, 0), vB = make_uint4(0, 0, 0, 0);
+  auto fetch = [&](unsigned tl, mraw (&mreg)[QPT], uint4& vq) {
+    const unsigned c0 = tl * ST_COLS;
+#pragma unroll
+    for (int i = 0; i < QPT; i++) {
+      mraw z = {};
+      mreg[i] = (c0 + src_poly[i] < cols) ? Quad<MT>::load_raw(src[i] + (size_t)c0 * 16) : z;
+    }
+    vq = (vprod && c0 + v_poly < cols) ? vsrc[(size_t)c0 * 16] : make_uint4(0, 0, 0, 0);
+  };
+  auto park = [&](int buf, const mraw (&mreg)[QPT], const uint4& vq) {
+#pragma unroll
+    for (int i = 0; i < QPT; i++) tile_m[buf][t + i * ST_THREADS] = mreg[i];
+    if (vprod) tile_v[buf][t] = vq;
+  };
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int cc = 0; cc < ST_COLS; cc++) {
+      const uint4 v = tile_v[buf][(b * ST_COLS + cc) * 16 + jq];
+#pragma unroll
+      for (int r = 0; r < RG; r++) {
+        const uint4 m = Quad<MT>::unpack(tile_m[buf][((rg * RG + r) * ST_COLS + cc) * 16 + jq]);
         acc[r][0] += (uint64_t)m.x * v.x;
         acc[r][1] += (uint64_t)m.y * v.y;
         acc[r][2] += (uint64_t)m.z * v.z;
         acc[r][3] += (uint64_t)m.w * v.w;
       }
     }
-  }
+  };
+  auto fold = [&]() {
 #pragma unroll
-  for (int r = 0; r < MV_ROWS; r++)
+    for (int r = 0; r < RG; r++)
 #pragma unroll
-    for (int k = 0; k < 4; k++) acc[r][k] = acc_fold(acc[r][k], p, p2);
-
-  // per-lane partials -> canonical residues (scale 2^-32), then sum the 4 lane groups of the wave
-#pragma unroll
-  for (int r = 0; r < MV_ROWS; r++) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      uint32_t x = redc64(acc[r][k], p, pinv);
-      x += __shfl_xor(x, 16);
-      x += __shfl_xor(x, 32);             // < 4p < 2^32
-      x = csub(csub(x, p2), p);
-      if (sub == 0) red[wave][r][jq * 4 + k] = x;
-    }
-  }
+      for (int k = 0; k < 4; k++) acc[r][k] = acc_fold(acc[r][k], p, p2);
+  };
+  // prologue: tile 0 -> LDS[0], tile 1 -> set A, tile 2 -> set B
+  fetch(0, mA, vA);
+  park(0, mA, vA);
+  if (ntiles > 1) fetch(1, mA, vA);
+  if (ntiles > 2) fetch(2, mB, vB);
   __syncthreads();
-  // 256 threads: thread t finishes output (row = t>>6, slot = t&63)
-  {
-    const int r = threadIdx.x >> 6, j = threadIdx.x & 63;
-    if (r < MV_ROWS && row0 + r < rows) {
-      uint32_t x = 0;                     // MV_WAVES canonical residues: reduce after every 4 (4p < 2^32)
+  for (unsigned tl = 0; tl < ntiles; tl += 2) {
+    // even step: consume tile tl from LDS[0]; tile tl+1 (set A) is parked into LDS[1]; set A is refilled with tl+3
+    compute(0);
+    if (tl + 1 < ntiles) {
+      park(1, mA, vA);
+      if (tl + 3 < ntiles) fetch(tl + 3, mA, vA);
+    }
+    __syncthreads();
+    if (tl + 1 >= ntiles) { fold(); break; }
+    // odd step: consume tile tl+1 from LDS[1]; tile tl+2 (set B) is parked into LDS[0]; set B is refilled with tl+4
+    compute(1);
+    fold();  // 2 tiles x ST_COLS = 8 terms since the last fold
+    if (tl + 2 < ntiles) {
+      park(0, mB, vB);
+      if (tl + 4 < ntiles) fetch(tl + 4, mB, vB);
+    }
+    __syncthreads();
+  }
 #pragma unroll
-      for (int w0 = 0; w0 < MV_WAVES; w0 += 4) {
-        uint32_t y = 0;
-#pragma unroll
-        for (int w = w0; w < w0 + 4 && w < MV_WAVES; w++) y += red[w][r][j];
-        x = csub(x + csub(csub(y, p2), p), p);
-      }
-      x = mont_mul(x, r2, p, pinv);       // undo the 2^-32 of redc64: plain residue
-      partial[(size_t)limb * partial_ps + ((size_t)mat * rows + row0 + r) * D + j] = x;
+  for (int r = 0; r < RG; r++) {
+    const unsigned row = row0 + rg * RG + r;
+    if (row < rows) {
+      uint4 o;
+      o.x = mont_mul(redc64(acc[r][0], p, pinv), r2, p, pinv);
+      o.y = mont_mul(redc64(acc[r][1], p, pinv), r2, p, pinv);
+      o.z = mont_mul(redc64(acc[r][2], p, pinv), r2, p, pinv);
+      o.w = mont_mul(redc64(acc[r][3], p, pinv), r2, p, pinv);
+      *reinterpret_cast<uint4*>(partial + (size_t)limb * partial_ps + (size_t)b * partial_bs +
+                                ((size_t)mat * rows + row) * D + jq * 4) = o;
     }
   }
+}
+
+template <typename MT>
+static hipError_t launch_matvec_nb(int nb, uint32_t* partial, size_t partial_ps, size_t partial_bs, const MT* M, size_t m_ps,
+                                   const uint32_t* V, size_t v_ps, size_t v_bs, size_t nmat, size_t rows, size_t cols,
+                                   int nlimbs, const LimbTable* tabs, hipStream_t s) {
+  if (nmat == 0 || rows == 0 || nlimbs == 0) return hipSuccess;
+  if (nb > 1 && rows >= (size_t)ST_ROWS) {  // tall matrix, several vector sets: LDS-staged "sets" kernel
+    const unsigned sr = (unsigned)st_rows(nb);
+    dim3 g((unsigned)((rows + sr - 1) / sr), (unsigned)nmat, (unsigned)nlimbs);
+#define LAB_ST(NBV)                                                                                                 \
+  hipLaunchKernelGGL((k_matvec_sets<MT, NBV>), g, dim3(ST_THREADS), 0, s, partial, partial_ps, partial_bs, M, m_ps, V, \
+                     v_ps, v_bs, (unsigned)rows, (unsigned)cols, tabs)
+    switch (nb) {
+      case 2: LAB_ST(2); break;
+      case 4: LAB_ST(4); break;
+      case 8: LAB_ST(8); break;
+      default: return hipErrorInvalidValue;
+    }
+#undef LAB_ST
+    return hipGetLastError();
+  }
+  const unsigned rpb = nb >= 4 ? 2 : MV_ROWS;
+  dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)nmat, (unsigned)nlimbs), block(64 * MV_WAVES);
+#define LAB_MV(NBV)                                                                                                  \
+  hipLaunchKernelGGL((k_matvec_partial<MT, NBV>), grid, block, 0, s, partial, partial_ps, partial_bs, M, m_ps, V, v_ps, \
+                     v_bs, (unsigned)rows, (unsigned)cols, tabs)
+  switch (nb) {
+    case 1: LAB_MV(1); break;
+    case 2: LAB_MV(2); break;
+    case 4: LAB_MV(4); break;
+    case 8: LAB_MV(8); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef LAB_MV
+  return hipGetLastError();
 }
 
 const char* matvec_kernel_name() { return "k_matvec_partial"; }
 
 hipError_t launch_matvec_partial(HatView partial, ConstHatView M, ConstHatView V, size_t nmat, size_t rows,
                                  size_t cols, int nlimbs, const LimbTable* tabs, hipStream_t s) {
-  if (nmat == 0 || rows == 0) return hipSuccess;
-  dim3 grid((unsigned)((rows + MV_ROWS - 1) / MV_ROWS), (unsigned)nmat, (unsigned)nlimbs);
-  hipLaunchKernelGGL(k_matvec_partial<uint32_t>, grid, dim3(64 * MV_WAVES), 0, s, partial.base, partial.plane_stride,
-                     M.base, M.plane_stride, V.base, V.plane_stride, (unsigned)rows, (unsigned)cols, tabs);
-  return hipGetLastError();
+  return launch_matvec_nb<uint32_t>(1, partial.base, partial.plane_stride, 0, M.base, M.plane_stride, V.base,
+                                    V.plane_stride, 0, nmat, rows, cols, nlimbs, tabs, s);
 }
 
 // one limb whose matrix residues are stored as u16 (`tab` = that limb's table; partial/V already offset to its plane)
 hipError_t launch_matvec_partial_u16(uint32_t* partial_plane, const uint16_t* M, const uint32_t* V_plane, size_t nmat,
                                      size_t rows, size_t cols, const LimbTable* tab, hipStream_t s) {
-  if (nmat == 0 || rows == 0) return hipSuccess;
-  dim3 grid((unsigned)((rows + MV_ROWS - 1) / MV_ROWS), (unsigned)nmat, 1);
-  hipLaunchKernelGGL(k_matvec_partial<uint16_t>, grid, dim3(64 * MV_WAVES), 0, s, partial_plane, (size_t)0, M,
-                     (size_t)0, V_plane, (size_t)0, (unsigned)rows, (unsigned)cols, tab);
-  return hipGetLastError();
+  return launch_matvec_nb<uint16_t>(1, partial_plane, 0, 0, M, 0, V_plane, 0, 0, nmat, rows, cols, 1, tab, s);
+}
+
+// nb right-hand-side sets at once (nb in {1,2,4,8}); *_bs = word stride between consecutive sets inside a plane
+hipError_t launch_matvec_partial_batched(int nb, HatView partial, size_t partial_bs, ConstHatView M, ConstHatView V,
+                                         size_t v_bs, size_t nmat, size_t rows, size_t cols, int nlimbs,
+                                         const LimbTable* tabs, hipStream_t s) {
+  return launch_matvec_nb<uint32_t>(nb, partial.base, partial.plane_stride, partial_bs, M.base, M.plane_stride, V.base,
+                                    V.plane_stride, v_bs, nmat, rows, cols, nlimbs, tabs, s);
+}
+hipError_t launch_matvec_partial_batched_u16(int nb, uint32_t* partial_plane, size_t partial_bs, const uint16_t* M,
+                                             const uint32_t* V_plane, size_t v_bs, size_t nmat, size_t rows, size_t cols,
+                                             const LimbTable* tab, hipStream_t s) {
+  return launch_matvec_nb<uint16_t>(nb, partial_plane, 0, partial_bs, M, 0, V_plane, 0, v_bs, nmat, rows, cols, 1, tab, s);
 }
 
 // out[rho][j] = sum_m partial[m][rho][j] mod p

@@ -195,8 +195,8 @@ class Prover:
                     raise RuntimeError("failed JL...")
 
 
-def prove_core(ctx, k, witness, st, crs, tape, device_outputs=False):
-    """One call of lab_prove_core.  Arrays may be numpy (host) or torch cuda tensors (device resident)."""
+def _prove_io(ctx, k, witness, st, crs, tape, device_outputs):
+    """ctypes input/output structs for one proof; returns (lab_prove_input, lab_transcript, Transcript, keep-alive list)."""
     n, r = k.N, k.R
     pin = _lib.lab_prove_input()
     pin.n, pin.r, pin.kappa, pin.kappa1, pin.kappa2 = n, r, k.KAPPA, k.KAPPA_1, k.KAPPA_2
@@ -235,9 +235,33 @@ def prove_core(ctx, k, witness, st, crs, tape, device_outputs=False):
     tr = _lib.lab_transcript()
     for name in ("u_1", "projection_int", "projection", "b_prime_prime", "u_2", "z", "t_i_all", "g_mat", "h_mat"):
         setattr(tr, name, _ptr(getattr(T, name)))
-    ctx._check(ctx._lib.lab_prove_core(ctx._h, C.byref(pin), C.byref(tr)))
     T.tape = tape
+    return pin, tr, T, keep
+
+
+def prove_core(ctx, k, witness, st, crs, tape, device_outputs=False):
+    """One call of lab_prove_core.  Arrays may be numpy (host) or torch cuda tensors (device resident)."""
+    pin, tr, T, keep = _prove_io(ctx, k, witness, st, crs, tape, device_outputs)
+    ctx._check(ctx._lib.lab_prove_core(ctx._h, C.byref(pin), C.byref(tr)))
     return T
+
+
+def prove_core_batch(ctx, k, witnesses, states, crs, tapes, device_outputs=False, raise_on_reject=True):
+    """lab_prove_core_batch: independent proofs (own witness, state, tape) under ONE common reference string; the
+    outer-commitment matrices are streamed from HBM once per group of up to 8 proofs.  Returns the list of
+    Transcripts (bit-identical to separate prove_core calls); with raise_on_reject=False also the status codes."""
+    nb = len(witnesses)
+    ios = [_prove_io(ctx, k, witnesses[j], states[j], crs, tapes[j], device_outputs) for j in range(nb)]
+    pins = (C.POINTER(_lib.lab_prove_input) * nb)(*[C.pointer(io[0]) for io in ios])
+    trs = (C.POINTER(_lib.lab_transcript) * nb)(*[C.pointer(io[1]) for io in ios])
+    status = (C.c_int * nb)()
+    ctx._check(ctx._lib.lab_prove_core_batch(ctx._h, nb, pins, trs, status))
+    codes = [int(x) for x in status]
+    if raise_on_reject:
+        for code in codes:
+            _lib.check(ctx._h, code)
+        return [io[2] for io in ios]
+    return [io[2] for io in ios], codes
 
 
 def verify_core(ctx, k, st, b_poly, crs, T, tape=None):

@@ -174,3 +174,36 @@ def test_prove_and_verify_with_compact_crs(q, n, r, kappa, kappa1):
     for v in (crs, res, ref):
         v.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("nb", [2, 3, 5, 8])
+@pytest.mark.parametrize("compact", [False, True])
+def test_prove_core_batch_equals_separate_proofs(nb, compact):
+    # independent proofs under one CRS: batched call (B streamed once per group) == separate calls == oracle
+    import labrador_snark_amd as lab
+    q, n, r, kappa, kappa1 = Q_REF33, 4, 8, 64, 20
+    ctx = lab.Context(q, 0)
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
+    crs = lab.ResidentCRS(ctx, k, compact=compact).fill_synthetic(1000)
+    ws, sts, tapes, wants = [], [], [], []
+    for j in range(nb):
+        case, (S, phi, a, tape) = cases.oracle_case(p, seed=100 + j)
+        ws.append(S); sts.append(lab.State(phi, a, case.b_prime)); tapes.append(tape)
+        wants.append(case.prove() if j in (0, nb - 1) else None)
+    Ts = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes)
+    for j in range(nb):
+        single = lab.prove_core(ctx, k, ws[j], sts[j], crs, tapes[j])
+        for f in ("t_i_all", "g_mat", "h_mat", "u_1", "u_2", "z", "b_prime_prime", "projection_int", "projection"):
+            assert np.array_equal(getattr(Ts[j], f), getattr(single, f)), (j, f)
+        if wants[j] is not None:
+            assert np.array_equal(Ts[j].u_1, wants[j]["u1"]) and np.array_equal(Ts[j].u_2, wants[j]["u2"])
+            assert np.array_equal(Ts[j].t_i_all, wants[j]["t"]) and np.array_equal(Ts[j].z, wants[j]["z"])
+    # per-proof status: a wrong b' in one proof does not affect the others
+    bad = list(sts)
+    bad[1] = lab.State(sts[1].phi, sts[1].a, (sts[1].b_prime + 1) % q)
+    Ts2, codes = lab.prove_core_batch(ctx, k, ws, bad, crs, tapes, raise_on_reject=False)
+    assert codes[1] == lab._lib.LAB_ERR_BPP_CHECK and all(c == 0 for i, c in enumerate(codes) if i != 1)
+    assert np.array_equal(Ts2[0].u_1, Ts[0].u_1)
+    crs.close()
+    ctx.close()

@@ -10,7 +10,7 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 P = "gpurun_out/prof/"
-DOM = "k_matvec_partial<unsigned int>"
+DOM = sys.argv[2] if len(sys.argv) > 2 else "k_matvec_rowsplit<unsigned int, 8>"
 
 shutil.copy(glob.glob(P + "trace/*/*_kernel_stats.csv")[0], "profiles/%s_rocprofv3_kernel_stats.csv" % tag)
 shutil.copy(P + "bench_n1.json", "profiles/%s_bench_n1.json" % tag)
@@ -33,7 +33,7 @@ fs, ws = biggest("fetch", "FETCH_SIZE"), biggest("write", "WRITE_SIZE")
 alg = bench["roofline"]["algorithmic_bytes_per_launch"]
 fetch_bytes, write_bytes = fs[0] * 1024 * 2, ws[0] * 1024
 out = {"kernel": "lab::" + DOM + " (step-3 launch of bench.py: nmat=96, rows=1024, cols=1024, the u32 limbs)",
-       "workload_key": [cfg["q"], cfg["n"], cfg["r"], cfg["kappa"], cfg["nlimbs"], cfg["crs_basis"] != "main basis"],
+       "workload_key": [cfg["q"], cfg["n"], cfg["r"], cfg["kappa"], cfg["nlimbs"], cfg["crs_basis"] != "main basis", cfg["proofs_per_step_per_gpu"]],
        "FETCH_SIZE_KB_raw": fs[0], "WRITE_SIZE_KB_raw": ws[0],
        "correction": "FETCH_SIZE x2 on gfx950 for 16-B/lane coalesced streaming loads (MI355X_MICROARCH.md 'HBM'); "
                      "WRITE_SIZE exact; FETCH and WRITE collected in separate --pmc passes",
