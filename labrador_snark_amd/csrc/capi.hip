@@ -824,6 +824,27 @@ int lab::axpy_commit_any(lab_ctx* c, HatView out, ConstHatView G, const lab_vec*
   return LAB_OK;
 }
 
+// nb sets at once: out_b = out.base + b*out_bs, G_b = G.base + b*g_bs, partial_b = partial.base + b*partial_bs
+int lab::axpy_commit_batched_any(lab_ctx* c, int nb, HatView out, size_t out_bs, ConstHatView G, size_t g_bs, const lab_vec* Cm,
+                                 size_t c_off, size_t nterms, size_t len, HatView partial, size_t partial_bs) {
+  const size_t chunks = axpy_num_chunks(nterms);
+  HatView target = chunks == 1 ? out : partial;
+  const size_t target_bs = chunks == 1 ? out_bs : partial_bs;
+  const int nfull = Cm->planes32();
+  if (nfull > 0)
+    LAB_HIP(c, launch_axpy_partial_batched(nb, target, target_bs, G, g_bs, Cm->view(c_off), nterms, len, nfull, Cm->tabs(), c->stream));
+  if (Cm->compact)
+    LAB_HIP(c, launch_axpy_partial_batched_u16(nb, target.base + (size_t)nfull * target.plane_stride, target_bs,
+                                               G.base + (size_t)nfull * G.plane_stride, g_bs, Cm->d16 + c_off * D, nterms, len,
+                                               Cm->tabs() + nfull, c->stream));
+  if (chunks > 1)
+    for (int b = 0; b < nb; b++)
+      LAB_HIP(c, launch_sum_terms(HatView{out.base + (size_t)b * out_bs, out.plane_stride},
+                                  HatView{partial.base + (size_t)b * partial_bs, partial.plane_stride}, chunks, len,
+                                  Cm->nlimbs(), Cm->tabs(), c->stream));
+  return LAB_OK;
+}
+
 extern "C" int lab_axpy_commit(lab_ctx* c, lab_vec* out, size_t out_off, const lab_vec* G, size_t g_off,
                                const lab_vec* Cm, size_t c_off, size_t nterms, size_t len) {
   if (!c) return LAB_ERR_ARG;

@@ -741,10 +741,12 @@ hipError_t launch_gram(HatView out, ConstHatView P, ConstHatView S, size_t n, si
 // instruction covers 4 consecutive rho (1 KiB contiguous).
 constexpr int AX_CHUNK = 64;
 
-template <typename MT>
+// NB = number of independent digit-vector sets (proofs) sharing the streamed C: set b reads G + b*g_bs and writes
+// partial + b*partial_bs (word strides inside one limb plane).
+template <typename MT, int NB>
 __global__ void __launch_bounds__(256)
-k_axpy_partial(uint32_t* __restrict__ partial, size_t partial_ps, const uint32_t* __restrict__ G, size_t g_ps,
-               const MT* __restrict__ C, size_t c_ps, unsigned nterms, unsigned len,
+k_axpy_partial(uint32_t* __restrict__ partial, size_t partial_ps, size_t partial_bs, const uint32_t* __restrict__ G,
+               size_t g_ps, size_t g_bs, const MT* __restrict__ C, size_t c_ps, unsigned nterms, unsigned len,
                const LimbTable* __restrict__ tabs) {
   typedef typename Quad<MT>::raw mraw;
   const int limb = blockIdx.z;
@@ -754,44 +756,85 @@ k_axpy_partial(uint32_t* __restrict__ partial, size_t partial_ps, const uint32_t
   const unsigned m0 = blockIdx.y * AX_CHUNK, m1 = min(m0 + AX_CHUNK, nterms);
   if (rho >= len) return;
   const uint4* Gp = reinterpret_cast<const uint4*>(G + (size_t)limb * g_ps) + jq;
+  const size_t gb4 = g_bs / 4;
   const mraw* Cp = reinterpret_cast<const mraw*>(C + (size_t)limb * c_ps) + (size_t)rho * 16 + jq;
-  uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  uint64_t acc[NB][4];
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc[b][k] = 0;
   unsigned m = m0;
   while (m < m1) {
     const unsigned me = min(m + 8, m1);
     for (; m < me; m++) {
-      const uint4 g = Gp[(size_t)m * 16];
       const uint4 c = Quad<MT>::load(Cp + (size_t)m * len * 16);
-      a0 += (uint64_t)g.x * c.x; a1 += (uint64_t)g.y * c.y; a2 += (uint64_t)g.z * c.z; a3 += (uint64_t)g.w * c.w;
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        const uint4 g = Gp[(size_t)m * 16 + b * gb4];
+        acc[b][0] += (uint64_t)g.x * c.x; acc[b][1] += (uint64_t)g.y * c.y;
+        acc[b][2] += (uint64_t)g.z * c.z; acc[b][3] += (uint64_t)g.w * c.w;
+      }
     }
-    a0 = acc_fold(a0, p, p2); a1 = acc_fold(a1, p, p2); a2 = acc_fold(a2, p, p2); a3 = acc_fold(a3, p, p2);
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) acc[b][k] = acc_fold(acc[b][k], p, p2);
   }
-  uint4 o;
-  o.x = mont_mul(redc64(a0, p, pinv), r2, p, pinv);
-  o.y = mont_mul(redc64(a1, p, pinv), r2, p, pinv);
-  o.z = mont_mul(redc64(a2, p, pinv), r2, p, pinv);
-  o.w = mont_mul(redc64(a3, p, pinv), r2, p, pinv);
-  reinterpret_cast<uint4*>(partial + (size_t)limb * partial_ps)[((size_t)blockIdx.y * len + rho) * 16 + jq] = o;
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    uint4 o;
+    o.x = mont_mul(redc64(acc[b][0], p, pinv), r2, p, pinv);
+    o.y = mont_mul(redc64(acc[b][1], p, pinv), r2, p, pinv);
+    o.z = mont_mul(redc64(acc[b][2], p, pinv), r2, p, pinv);
+    o.w = mont_mul(redc64(acc[b][3], p, pinv), r2, p, pinv);
+    reinterpret_cast<uint4*>(partial + (size_t)limb * partial_ps + (size_t)b * partial_bs)[((size_t)blockIdx.y * len + rho) * 16 + jq] = o;
+  }
 }
 
 size_t axpy_num_chunks(size_t nterms) { return (nterms + AX_CHUNK - 1) / AX_CHUNK; }
 
+template <typename MT>
+static hipError_t launch_axpy_nb(int nb, uint32_t* partial, size_t partial_ps, size_t partial_bs, const uint32_t* G, size_t g_ps,
+                                 size_t g_bs, const MT* C, size_t c_ps, size_t nterms, size_t len, int nlimbs,
+                                 const LimbTable* tabs, hipStream_t s) {
+  if (nterms == 0 || len == 0 || nlimbs == 0) return hipSuccess;
+  dim3 grid((unsigned)((len + 15) / 16), (unsigned)axpy_num_chunks(nterms), (unsigned)nlimbs);
+#define LAB_AX(NBV)                                                                                                   \
+  hipLaunchKernelGGL((k_axpy_partial<MT, NBV>), grid, dim3(256), 0, s, partial, partial_ps, partial_bs, G, g_ps, g_bs, C, \
+                     c_ps, (unsigned)nterms, (unsigned)len, tabs)
+  switch (nb) {
+    case 1: LAB_AX(1); break;
+    case 2: LAB_AX(2); break;
+    case 4: LAB_AX(4); break;
+    case 8: LAB_AX(8); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef LAB_AX
+  return hipGetLastError();
+}
+
 hipError_t launch_axpy_partial(HatView partial, ConstHatView G, ConstHatView C, size_t nterms, size_t len, int nlimbs,
                                const LimbTable* tabs, hipStream_t s) {
-  if (nterms == 0 || len == 0) return hipSuccess;
-  dim3 grid((unsigned)((len + 15) / 16), (unsigned)axpy_num_chunks(nterms), (unsigned)nlimbs);
-  hipLaunchKernelGGL(k_axpy_partial<uint32_t>, grid, dim3(256), 0, s, partial.base, partial.plane_stride, G.base,
-                     G.plane_stride, C.base, C.plane_stride, (unsigned)nterms, (unsigned)len, tabs);
-  return hipGetLastError();
+  return launch_axpy_nb<uint32_t>(1, partial.base, partial.plane_stride, 0, G.base, G.plane_stride, 0, C.base,
+                                  C.plane_stride, nterms, len, nlimbs, tabs, s);
 }
 
 hipError_t launch_axpy_partial_u16(uint32_t* partial_plane, const uint32_t* G_plane, const uint16_t* C, size_t nterms,
                                    size_t len, const LimbTable* tab, hipStream_t s) {
-  if (nterms == 0 || len == 0) return hipSuccess;
-  dim3 grid((unsigned)((len + 15) / 16), (unsigned)axpy_num_chunks(nterms), 1);
-  hipLaunchKernelGGL(k_axpy_partial<uint16_t>, grid, dim3(256), 0, s, partial_plane, (size_t)0, G_plane, (size_t)0, C,
-                     (size_t)0, (unsigned)nterms, (unsigned)len, tab);
-  return hipGetLastError();
+  return launch_axpy_nb<uint16_t>(1, partial_plane, 0, 0, G_plane, 0, 0, C, 0, nterms, len, 1, tab, s);
+}
+
+// nb digit-vector sets sharing C (nb in {1,2,4,8}); *_bs = word stride between consecutive sets inside a plane
+hipError_t launch_axpy_partial_batched(int nb, HatView partial, size_t partial_bs, ConstHatView G, size_t g_bs,
+                                       ConstHatView C, size_t nterms, size_t len, int nlimbs, const LimbTable* tabs,
+                                       hipStream_t s) {
+  return launch_axpy_nb<uint32_t>(nb, partial.base, partial.plane_stride, partial_bs, G.base, G.plane_stride, g_bs, C.base,
+                                  C.plane_stride, nterms, len, nlimbs, tabs, s);
+}
+hipError_t launch_axpy_partial_batched_u16(int nb, uint32_t* partial_plane, size_t partial_bs, const uint32_t* G_plane,
+                                           size_t g_bs, const uint16_t* C, size_t nterms, size_t len, const LimbTable* tab,
+                                           hipStream_t s) {
+  return launch_axpy_nb<uint16_t>(nb, partial_plane, 0, partial_bs, G_plane, 0, g_bs, C, 0, nterms, len, 1, tab, s);
 }
 
 // u32 residues of one limb plane -> u16 (the limb prime is < 2^16)

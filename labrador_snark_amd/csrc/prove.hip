@@ -222,15 +222,34 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     j0 += g;
   }
 
-  // ================= phase B, per proof: steps 4-10
+  // groups of 8/4/2/1 proofs for the kernels that stream shared CRS data
+  auto for_groups = [&](auto&& fn) -> int {
+    for (size_t j0 = 0; j0 < np;) {
+      int g = 1;
+      while (g < 8 && j0 + 2 * (size_t)g <= np) g *= 2;
+      int e = fn(j0, g);
+      if (e) return e;
+      j0 += g;
+    }
+    return LAB_OK;
+  };
+
+  // ================= step 4 (:137-148): rhs = sum_{i<=j,k} g_ij^(k) C_ijk ; u_1 = lhs + rhs (:153)
   for (size_t j = 0; j < np; j++) {
     Job& J = jobs[j];
-    const lab_prove_input* x = ins[j];
-    // step 4 (:137-148): rhs = sum_{i<=j,k} g_ij^(k) C_ijk ; u_1 = lhs + rhs (:153)
     LAB_HIP(c, launch_gather_upper(J.cGup, J.cG, r, s));
     LAB_HIP(c, launch_decompose(J.cGdec, J.cGup, pairs, q, (uint64_t)in->b2, t2, 1, s));  // [pair][k]
     if ((rc = to_hat(c, J.cGdec, HD(j, hGdec), pairs * t2, bdig))) return rc;
-    if ((rc = axpy_commit_any(c, HD(j, hrhs), HD(j, hGdec), in->C, in->c_off, pairs * t2, k2, HD(j, hpartd)))) return rc;
+  }
+  if ((rc = for_groups([&](size_t j0, int g) {   // C streamed once per group
+        return axpy_commit_batched_any(c, g, HD(j0, hrhs), perd * D, HD(j0, hGdec), perd * D, in->C, in->c_off, pairs * t2, k2,
+                                       HD(j0, hpartd), perd * D);
+      }))) return rc;
+
+  // ================= per proof: u_1, steps 5-8, digits of H
+  for (size_t j = 0; j < np; j++) {
+    Job& J = jobs[j];
+    const lab_prove_input* x = ins[j];
     LAB_HIP(c, launch_pointwise(PW_ADD, HD(j, hlhs), HD(j, hlhs), HD(j, hrhs), k1, Ld, tabsd, s));
     if ((rc = from_hat(c, HD(j, hlhs), k1, dense_tmp, J.cu1, bdig))) return rc;
 
@@ -266,14 +285,22 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     if ((rc = from_hat(c, HV(j, hX), rr, dense_tmp, J.cX))) return rc;
     LAB_HIP(c, launch_symmetrize_half(J.cH, J.cX, r, q, inv2_mod(q), s));
 
-    // step 9 (:364-378): u_2 = sum_{i<=j,k} h_ij^(k) D_ijk
+    // digits of the upper triangle of H for step 9
     LAB_HIP(c, launch_gather_upper(J.cHup, J.cH, r, s));
     LAB_HIP(c, launch_decompose(J.cHdec, J.cHup, pairs, q, (uint64_t)in->b1, t1, 1, s));
     if ((rc = to_hat(c, J.cHdec, HD(j, hHdec), pairs * t1, bdig))) return rc;
-    if ((rc = axpy_commit_any(c, HD(j, hu2), HD(j, hHdec), in->Dm, in->d_off, pairs * t1, k2, HD(j, hpartd)))) return rc;
-    if ((rc = from_hat(c, HD(j, hu2), k2, dense_tmp, J.cu2, bdig))) return rc;
+  }
 
-    // step 10 (:380-399): z = sum_i c_i s_i
+  // ================= step 9 (:364-378): u_2 = sum_{i<=j,k} h_ij^(k) D_ijk ; D streamed once per group
+  if ((rc = for_groups([&](size_t j0, int g) {
+        return axpy_commit_batched_any(c, g, HD(j0, hu2), perd * D, HD(j0, hHdec), perd * D, in->Dm, in->d_off, pairs * t1, k2,
+                                       HD(j0, hpartd), perd * D);
+      }))) return rc;
+
+  // ================= per proof: u_2 out, step 10 (:380-399): z = sum_i c_i s_i
+  for (size_t j = 0; j < np; j++) {
+    Job& J = jobs[j];
+    if ((rc = from_hat(c, HD(j, hu2), k2, dense_tmp, J.cu2, bdig))) return rc;
     LAB_HIP(c, launch_matvec_partial(HV(j, hz), HV(j, hS), HV(j, hc), 1, n, r, L, tabs, s));
     if ((rc = from_hat(c, HV(j, hz), n, dense_tmp, J.cz))) return rc;
   }
