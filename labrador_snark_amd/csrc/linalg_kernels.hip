@@ -8,6 +8,7 @@
 // the coefficient domain; here operands are transformed once, products are
 // accumulated per NTT slot in 64-bit registers and reduced once per output.
 #include "kernels.h"
+#include <type_traits>
 
 namespace lab {
 
@@ -487,12 +488,347 @@ k_matvec_sets(uint32_t* __restrict__ partial, size_t partial_ps, size_t partial_
   }
 }
 
+// ---- batched mat-vec with LANE = ROW ("bcast" kernel)
+// The sets kernel above reads one LDS quad per 4..8 multiply-adds and is bound by the LDS, not by HBM, from 4 sets
+// on.  Here the roles are turned round: a 1024-thread block owns BC_ROWS = 64 matrix rows, LANE = ROW and
+// WAVE = SLOT QUAD.  The vector operand v[set][col][4 slots of this wave] is then wave-uniform: one broadcast LDS
+// read serves 64 rows, and one matrix quad read serves all NB sets.  The matrix tile (64 rows x BC_COLS
+// polynomials) is fetched with coalesced non-temporal loads (a row's 512 B contiguous), parked in LDS row-major with
+// a pitch of BC_COLS*16+1 quads, and read back transposed (lane = row: the 16 lanes of an LDS lane group hit 16
+// different 16-byte slots).  Per column and wave: 1 + NB LDS reads feed 4*NB multiply-adds on 64 lanes.
+// (Scalar loads of v straight from global memory were tried first: no LDS at all, but every tile then waits a
+// full HBM latency on the scalar path, 3x slower.)
+// Accumulators: NB x 4 u64 per lane.
+constexpr int BC_ROWS = 64;
+constexpr int BC_COLS = 2;
+constexpr int BC_THREADS = 1024;
+
+template <typename MT, int NB>
+__global__ void __launch_bounds__(BC_THREADS)
+k_matvec_bcast(uint32_t* __restrict__ partial, size_t partial_ps, size_t partial_bs, const MT* __restrict__ M, size_t m_ps,
+               const uint32_t* __restrict__ V, size_t v_ps, size_t v_bs, unsigned rows, unsigned cols,
+               const LimbTable* __restrict__ tabs) {
+  typedef typename Quad<MT>::raw mraw;
+  constexpr int PITCH = BC_COLS * 16 + 1;
+  constexpr int QPT = BC_ROWS * BC_COLS * 16 / BC_THREADS;    // matrix quads per thread per tile (2)
+  constexpr int VQ = NB * BC_COLS * 16;                       // vector quads per tile (<= 256)
+  __shared__ mraw tile[2][BC_ROWS * PITCH];
+  __shared__ uint4 tile_v[2][VQ];
+  const int limb = blockIdx.z;
+  const unsigned mat = blockIdx.y;
+  const unsigned row0 = blockIdx.x * BC_ROWS;
+  const uint32_t p = tabs[limb].p, p2 = tabs[limb].p2, pinv = tabs[limb].pinv, r2 = tabs[limb].r2;
+  const int t = threadIdx.x, lane = t & 63;
+  const int jq = __builtin_amdgcn_readfirstlane(t >> 6);
+  const MT* Mbase = M + (size_t)limb * m_ps + (size_t)mat * rows * cols * D;
+
+  const mraw* src[QPT];
+  int dst[QPT], src_poly[QPT];
+#pragma unroll
+  for (int i = 0; i < QPT; i++) {
+    const int qd = t + i * BC_THREADS;
+    const int rr = qd / (BC_COLS * 16), within = qd % (BC_COLS * 16);
+    const unsigned row = min(row0 + rr, rows - 1);
+    src[i] = reinterpret_cast<const mraw*>(Mbase + (size_t)row * cols * D) + within;
+    src_poly[i] = within / 16;
+    dst[i] = rr * PITCH + within;
+  }
+  // producer role for the vectors: thread t < VQ fetches quad (set t / (BC_COLS*16), poly, slot quad)
+  const bool vprod = t < VQ;
+  const int v_poly = (t % (BC_COLS * 16)) / 16;
+  const uint4* vsrc = reinterpret_cast<const uint4*>(V + (size_t)limb * v_ps + (size_t)(vprod ? t / (BC_COLS * 16) : 0) * v_bs +
+                                                     (size_t)mat * cols * D) + t % (BC_COLS * 16);
+
+  uint64_t acc[NB][4];
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc[b][k] = 0;
+
+  const unsigned ntiles = (cols + BC_COLS - 1) / BC_COLS;
+  mraw mA[QPT], mB[QPT];
+  uint4 vA = make_uint4(0, 0, 0, 0), vB = make_uint4(0, 0, 0, 0);
+  auto fetch = [&](unsigned tl, mraw (&mreg)[QPT], uint4& vq) {
+    const unsigned c0 = tl * BC_COLS;
+#pragma unroll
+    for (int i = 0; i < QPT; i++) {
+      mraw z = {};
+      mreg[i] = (c0 + src_poly[i] < cols) ? Quad<MT>::load_raw(src[i] + (size_t)c0 * 16) : z;
+    }
+    vq = (vprod && c0 + v_poly < cols) ? vsrc[(size_t)c0 * 16] : make_uint4(0, 0, 0, 0);
+  };
+  auto park = [&](int buf, const mraw (&mreg)[QPT], const uint4& vq) {
+#pragma unroll
+    for (int i = 0; i < QPT; i++) tile[buf][dst[i]] = mreg[i];
+    if (vprod) tile_v[buf][t] = vq;
+  };
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int cc = 0; cc < BC_COLS; cc++) {
+      const uint4 m = Quad<MT>::unpack(tile[buf][lane * PITCH + cc * 16 + jq]);
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        const uint4 v = tile_v[buf][(b * BC_COLS + cc) * 16 + jq];   // wave-uniform address: broadcast
+        acc[b][0] += (uint64_t)m.x * v.x;
+        acc[b][1] += (uint64_t)m.y * v.y;
+        acc[b][2] += (uint64_t)m.z * v.z;
+        acc[b][3] += (uint64_t)m.w * v.w;
+        if (NB > 4 && (b & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep at most 4 vector quads live
+      }
+    }
+  };
+  auto fold = [&]() {
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) acc[b][k] = acc_fold_lazy(acc[b][k], p2);
+  };
+  fetch(0, mA, vA);
+  park(0, mA, vA);
+  if (ntiles > 1) fetch(1, mA, vA);
+  if (ntiles > 2) fetch(2, mB, vB);
+  __syncthreads();
+  for (unsigned tl = 0; tl < ntiles; tl += 2) {
+    compute(0);
+    if (tl + 1 < ntiles) {
+      park(1, mA, vA);
+      if (tl + 3 < ntiles) fetch(tl + 3, mA, vA);
+    }
+    __syncthreads();
+    if (tl + 1 >= ntiles) break;
+    compute(1);
+    if (tl & 2) fold();  // 4 tiles x BC_COLS = 8 terms since the last fold
+    if (tl + 2 < ntiles) {
+      park(0, mB, vB);
+      if (tl + 4 < ntiles) fetch(tl + 4, mB, vB);
+    }
+    __syncthreads();
+  }
+  const unsigned row = row0 + lane;
+  if (row < rows) {
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      uint4 o;
+      o.x = mont_mul(redc64(acc_fold(acc[b][0], p, p2), p, pinv), r2, p, pinv);
+      o.y = mont_mul(redc64(acc_fold(acc[b][1], p, p2), p, pinv), r2, p, pinv);
+      o.z = mont_mul(redc64(acc_fold(acc[b][2], p, p2), p, pinv), r2, p, pinv);
+      o.w = mont_mul(redc64(acc_fold(acc[b][3], p, p2), p, pinv), r2, p, pinv);
+      *reinterpret_cast<uint4*>(partial + (size_t)limb * partial_ps + (size_t)b * partial_bs +
+                                ((size_t)mat * rows + row) * D + jq * 4) = o;
+    }
+  }
+}
+
+// ---- the bcast kernel with the tiles moved by LDS-DMA (global_load_lds_dwordx4) into a 3-deep LDS ring
+// Same lane = row / wave = slot-quad arithmetic as k_matvec_bcast, but no staging registers: two tiles stay in
+// flight behind the one being consumed, one raw s_barrier per tile, counted vmcnt waits.  This is what lets 8 sets
+// (64 accumulator VGPRs) fit the 128-VGPR budget of a 1024-thread block.  One DMA instruction writes 1 KiB of LDS
+// contiguously (wave-uniform base + lane*16), i.e. 2 matrix rows of a u32 tile (4 of a u16 tile); pieces are spaced
+// 1040 B apart so that the transposed reads (lane = row) spread over the banks (2-way / 4-way instead of 32-way).
+// Requires cols % BC_COLS == 0 (a DMA cannot zero-fill); other shapes take the register-staged kernel.
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// LDS reads of the DMA ring are written as inline asm: the compiler's wait-count pass treats an LDS read it can
+// see as possibly aliasing every LDS-DMA in flight and drains the DMA queue (vmcnt(0)) in front of it, which
+// would serialise the ring.  The s_waitcnt sits inside the same statement, so the results are defined when the
+// statement ends and nothing can be scheduled between the reads and the wait.
+// GS vector quads (sets b0 .. b0+GS-1 of column cc) from vaddr + V0 + i*VS, optionally preceded by the matrix quad.
+__device__ __forceinline__ uint4 unpack_quad(const u32x4_t& r) { return make_uint4(r.x, r.y, r.z, r.w); }
+__device__ __forceinline__ uint4 unpack_quad(const u32x2_t& r) {
+  return make_uint4(r.x & 0xFFFFu, r.x >> 16, r.y & 0xFFFFu, r.y >> 16);
+}
+template <int MOFF>
+__device__ __forceinline__ void lds_issue_m(u32x4_t& m, uint32_t maddr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(m) : "v"(maddr), "n"(MOFF));
+}
+template <int MOFF>
+__device__ __forceinline__ void lds_issue_m(u32x2_t& m, uint32_t maddr) {
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(m) : "v"(maddr), "n"(MOFF));
+}
+template <int GS, int V0, int VS, typename MR>
+__device__ __forceinline__ void lds_read_v(MR& m, u32x4_t (&v)[4], uint32_t vaddr) {
+  // "+v"(m): the matrix quad issued just before becomes valid at this wait too
+  if constexpr (GS == 4) {
+    asm volatile(
+        "ds_read_b128 %1, %5 offset:%6\n\t"
+        "ds_read_b128 %2, %5 offset:%7\n\t"
+        "ds_read_b128 %3, %5 offset:%8\n\t"
+        "ds_read_b128 %4, %5 offset:%9\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "+v"(m), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+        : "v"(vaddr), "n"(V0), "n"(V0 + VS), "n"(V0 + 2 * VS), "n"(V0 + 3 * VS));
+  } else {
+    asm volatile(
+        "ds_read_b128 %1, %3 offset:%4\n\t"
+        "ds_read_b128 %2, %3 offset:%5\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "+v"(m), "=&v"(v[0]), "=&v"(v[1])
+        : "v"(vaddr), "n"(V0), "n"(V0 + VS));
+  }
+}
+
+template <typename MT, int NB>
+__global__ void __launch_bounds__(BC_THREADS)
+k_matvec_bcast_dma(uint32_t* __restrict__ partial, size_t partial_ps, size_t partial_bs, const MT* __restrict__ M, size_t m_ps,
+                   const uint32_t* __restrict__ V, size_t v_ps, size_t v_bs, unsigned rows, unsigned cols,
+                   const LimbTable* __restrict__ tabs) {
+  typedef typename Quad<MT>::raw mraw;
+  constexpr int RAWB = sizeof(mraw);                 // bytes per slot quad in the matrix: 16 (u32) / 8 (u16)
+  constexpr int ROWB = BC_COLS * 16 * RAWB;          // tile bytes per matrix row: 512 / 256
+  constexpr int RPI = 1024 / ROWB;                   // rows per DMA instruction: 2 / 4
+  constexpr int LPR = 64 / RPI;                      // lanes per row: 32 / 16
+  constexpr int NI = BC_ROWS / RPI;                  // matrix DMA instructions per tile: 32 / 16
+  constexpr int MI = NI / 16;                        // ... per wave: 2 / 1
+  constexpr int PIECE = 1024 + 16;
+  constexpr int NV = NB * BC_COLS * 256 / 1024;      // vector DMA instructions per tile: NB / 2
+  constexpr int G = MI + 1;                          // DMA instructions per wave per tile
+  // three ring slots as separate LDS objects: the compiler then knows that the reads of one slot do not alias the
+  // DMA writes into another and does not drain the DMA queue (vmcnt(0)) in front of every LDS read
+  __shared__ __attribute__((aligned(16))) unsigned char tm0[NI * PIECE], tm1[NI * PIECE], tm2[NI * PIECE];
+  __shared__ uint4 tv0[NB * BC_COLS * 16], tv1[NB * BC_COLS * 16], tv2[NB * BC_COLS * 16];
+  const int limb = blockIdx.z;
+  const unsigned mat = blockIdx.y;
+  const unsigned row0 = blockIdx.x * BC_ROWS;
+  const uint32_t p = tabs[limb].p, p2 = tabs[limb].p2, pinv = tabs[limb].pinv, r2 = tabs[limb].r2;
+  const int t = threadIdx.x, lane = t & 63;
+  const int jq = __builtin_amdgcn_readfirstlane(t >> 6);   // wave index = slot quad
+  const unsigned char* Mbase = reinterpret_cast<const unsigned char*>(M + (size_t)limb * m_ps + (size_t)mat * rows * cols * D);
+
+  // sources as wave-uniform base + 32-bit lane offset (the launcher checks rows*cols*256 < 2^32)
+  uint32_t moffs[MI];
+#pragma unroll
+  for (int i = 0; i < MI; i++) {
+    const unsigned row = min(row0 + (jq * MI + i) * RPI + lane / LPR, rows - 1) - row0;
+    moffs[i] = row * cols * 16 * RAWB + (lane % LPR) * 16;
+  }
+  const unsigned char* mrow0 = Mbase + (size_t)row0 * cols * 16 * RAWB;
+  const int kv = jq % NV;                              // waves beyond NV repeat a vector piece (same bytes, same place)
+  const uint32_t* vbase = V + (size_t)limb * v_ps + (size_t)(kv * 2) * v_bs + (size_t)mat * cols * D;
+  const uint32_t voff = (uint32_t)((lane / 32) * v_bs + (lane % 32) * 4) * 4;   // bytes
+
+  uint64_t acc[NB][4];
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc[b][k] = 0;
+
+  const unsigned ntiles = cols / BC_COLS;
+  // tile index clamped: past the end the last tile is fetched again into a slot nobody reads, so every step issues
+  // and waits for the same number of DMA instructions (straight-line counts the compiler can follow)
+  auto issue = [&](unsigned tl, unsigned char* tm, uint4* tv) {
+    tl = min(tl, ntiles - 1);
+    const unsigned char* mb = mrow0 + (size_t)tl * ROWB;
+    const unsigned char* vb = reinterpret_cast<const unsigned char*>(vbase + (size_t)tl * BC_COLS * D);
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+      __builtin_amdgcn_global_load_lds((gptr_t)(mb + moffs[i]), (lptr_t)(tm + (jq * MI + i) * PIECE), 16, 0, 2);
+    __builtin_amdgcn_global_load_lds((gptr_t)(vb + voff), (lptr_t)(tv + kv * 64), 16, 0, 0);
+  };
+  const uint32_t moff = (lane / RPI) * PIECE + (lane % RPI) * ROWB + jq * RAWB;
+  const uint32_t voffl = jq * 16;
+  constexpr int GS = NB < 4 ? NB : 4;
+  // one tile: consume ring slot (tm, tv) while tile tl+2 is sent to slot (nm, nv), the one tile tl-1 was read from
+  auto step = [&](unsigned tl, unsigned char* tm, uint4* tv, unsigned char* nm, uint4* nv) {
+    // this wave's pieces of tile tl have landed (tile tl+1's G instructions stay in flight) ...
+    // (the builtin, not inline asm: the compiler's own wait-count pass has to see it)
+    __builtin_amdgcn_s_waitcnt(0x0F70 | G);   // vmcnt(G), expcnt/lgkmcnt untouched
+    // ... and after the barrier so have everybody's; everybody has also finished reading tile tl-1
+    __builtin_amdgcn_s_barrier();
+    issue(tl + 2, nm, nv);
+    const uint32_t maddr = (uint32_t)(uintptr_t)(lptr_t)tm + moff;
+    const uint32_t vaddr = (uint32_t)(uintptr_t)(lptr_t)tv + voffl;      // wave-uniform: broadcast reads
+    auto column = [&](auto cc_tag) {
+      constexpr int cc = decltype(cc_tag)::value;
+      typename std::conditional<RAWB == 16, u32x4_t, u32x2_t>::type mr;
+      lds_issue_m<cc * 16 * RAWB>(mr, maddr);
+      uint4 m;
+#pragma unroll
+      for (int g = 0; g < NB / GS; g++) {
+        u32x4_t v[4];
+        if (g == 0) lds_read_v<GS, cc * 256, BC_COLS * 256>(mr, v, vaddr);
+        else lds_read_v<GS, (GS * BC_COLS + cc) * 256, BC_COLS * 256>(mr, v, vaddr);
+        if (g == 0)
+          m = unpack_quad(mr);
+#pragma unroll
+        for (int i = 0; i < GS; i++) {
+          const int b = g * GS + i;
+          acc[b][0] += (uint64_t)m.x * v[i].x;
+          acc[b][1] += (uint64_t)m.y * v[i].y;
+          acc[b][2] += (uint64_t)m.z * v[i].z;
+          acc[b][3] += (uint64_t)m.w * v[i].w;
+        }
+      }
+    };
+    static_assert(BC_COLS == 2 && NB / GS <= 2, "column() is written out for two columns, at most two groups");
+    column(std::integral_constant<int, 0>{});
+    column(std::integral_constant<int, 1>{});
+    if ((tl & 3) == 3) {      // 4 tiles x BC_COLS = 8 terms since the last fold
+#pragma unroll
+      for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[b][k] = acc_fold_lazy(acc[b][k], p2);
+    }
+  };
+  issue(0, tm0, tv0);
+  issue(1, tm1, tv1);
+  for (unsigned tl = 0; tl < ntiles; tl += 3) {
+    step(tl, tm0, tv0, tm2, tv2);
+    if (tl + 1 >= ntiles) break;
+    step(tl + 1, tm1, tv1, tm0, tv0);
+    if (tl + 2 >= ntiles) break;
+    step(tl + 2, tm2, tv2, tm1, tv1);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // no DMA may still be writing this block's LDS when it ends
+  const unsigned row = row0 + lane;
+  if (row < rows) {
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      uint4 o;
+      o.x = mont_mul(redc64(acc_fold(acc[b][0], p, p2), p, pinv), r2, p, pinv);
+      o.y = mont_mul(redc64(acc_fold(acc[b][1], p, p2), p, pinv), r2, p, pinv);
+      o.z = mont_mul(redc64(acc_fold(acc[b][2], p, p2), p, pinv), r2, p, pinv);
+      o.w = mont_mul(redc64(acc_fold(acc[b][3], p, p2), p, pinv), r2, p, pinv);
+      *reinterpret_cast<uint4*>(partial + (size_t)limb * partial_ps + (size_t)b * partial_bs +
+                                ((size_t)mat * rows + row) * D + jq * 4) = o;
+    }
+  }
+}
+
 template <typename MT>
 static hipError_t launch_matvec_nb(int nb, uint32_t* partial, size_t partial_ps, size_t partial_bs, const MT* M, size_t m_ps,
                                    const uint32_t* V, size_t v_ps, size_t v_bs, size_t nmat, size_t rows, size_t cols,
                                    int nlimbs, const LimbTable* tabs, hipStream_t s) {
   if (nmat == 0 || rows == 0 || nlimbs == 0) return hipSuccess;
-  if (nb > 1 && rows >= (size_t)ST_ROWS) {  // tall matrix, several vector sets: LDS-staged "sets" kernel
+  if (nb > 1 && rows >= (size_t)BC_ROWS / 2 && (v_bs % 4) == 0 && cols % BC_COLS == 0 &&
+      (uint64_t)rows * cols * 256 < (1ull << 32) && v_bs * 8 < (1ull << 32)) {  // ... tiles by LDS-DMA
+    dim3 g((unsigned)((rows + BC_ROWS - 1) / BC_ROWS), (unsigned)nmat, (unsigned)nlimbs);
+#define LAB_BD(NBV)                                                                                                  \
+  hipLaunchKernelGGL((k_matvec_bcast_dma<MT, NBV>), g, dim3(BC_THREADS), 0, s, partial, partial_ps, partial_bs, M, m_ps, \
+                     V, v_ps, v_bs, (unsigned)rows, (unsigned)cols, tabs)
+    switch (nb) {
+      case 2: LAB_BD(2); break;
+      case 4: LAB_BD(4); break;
+      case 8: LAB_BD(8); break;
+      default: return hipErrorInvalidValue;
+    }
+#undef LAB_BD
+    return hipGetLastError();
+  }
+  if (nb > 1 && nb < 8 && rows >= (size_t)BC_ROWS / 2 && (v_bs % 4) == 0) {  // tall matrix, several vector sets: "bcast" kernel
+    dim3 g((unsigned)((rows + BC_ROWS - 1) / BC_ROWS), (unsigned)nmat, (unsigned)nlimbs);
+#define LAB_BC(NBV)                                                                                                  \
+  hipLaunchKernelGGL((k_matvec_bcast<MT, NBV>), g, dim3(BC_THREADS), 0, s, partial, partial_ps, partial_bs, M, m_ps, V, \
+                     v_ps, v_bs, (unsigned)rows, (unsigned)cols, tabs)
+    switch (nb) {
+      case 2: LAB_BC(2); break;
+      case 4: LAB_BC(4); break;
+      default: return hipErrorInvalidValue;
+    }
+#undef LAB_BC
+    return hipGetLastError();
+  }
+  if (nb > 1 && rows >= (size_t)ST_ROWS) {  // fewer rows: LDS-staged "sets" kernel
     const unsigned sr = (unsigned)st_rows(nb);
     dim3 g((unsigned)((rows + sr - 1) / sr), (unsigned)nmat, (unsigned)nlimbs);
 #define LAB_ST(NBV)                                                                                                 \

@@ -67,11 +67,21 @@ __device__ __forceinline__ uint32_t mont_mul(uint32_t a, uint32_t b, uint32_t p,
 }
 
 // Bring the high word of a 64-bit accumulator back below p.  Precondition:
-// acc < p*2^32 + 8*p^2 (at most 8 canonical products were added since the last call), so hi < 3p.
+// acc < p*2^32 + 8*p^2 (at most 8 canonical products were added since the last call), so hi < 3p
+// (the two conditional subtractions in fact accept any hi < 4p).
 __device__ __forceinline__ uint64_t acc_fold(uint64_t acc, uint32_t p, uint32_t p2) {
   uint32_t hi = (uint32_t)(acc >> 32);
   hi = min(hi, hi - p2);
   hi = min(hi, hi - p);
+  return ((uint64_t)hi << 32) | (uint32_t)acc;
+}
+
+// Cheaper fold for multiply-add bound loops: keeps the high word below 2p instead of p.  Precondition: the high word
+// was < 2p before at most 8 canonical products were added, so it is < 2p + 8p^2/2^32 < 4p < 2^32 now (p < 2^30).
+// acc_fold (which accepts any high word < 4p) must be applied before redc64.
+__device__ __forceinline__ uint64_t acc_fold_lazy(uint64_t acc, uint32_t p2) {
+  uint32_t hi = (uint32_t)(acc >> 32);
+  hi = min(hi, hi - p2);
   return ((uint64_t)hi << 32) | (uint32_t)acc;
 }
 

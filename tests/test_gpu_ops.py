@@ -241,3 +241,53 @@ def test_sharded_outer_commitment_single_rank(contexts):
     assert (lo, hi) == (0, r * t1)
     got = parallel.sharded_outer_commitment(ctx, B, V, hi - lo, kappa1, kappa, q)
     assert np.array_equal(got.cpu().numpy().view(np.uint64), full)
+
+
+@pytest.mark.parametrize("nb", [2, 4, 8])
+@pytest.mark.parametrize("rows,cols,nmat", [(9, 40, 3), (20, 37, 2), (33, 1, 1), (64, 37, 3), (100, 8, 2), (130, 515, 1),
+                                            (32, 2, 1), (64, 4, 2), (65, 6, 1), (200, 26, 2), (1024, 16, 1)])
+@pytest.mark.parametrize("compact", [False, True])
+def test_matvec_sum_batched_all_kernels(nb, rows, cols, nmat, compact):
+    # nb vector sets sharing one matrix stream (the batched outer commitment, src/proofgen.rs:101-132 for nb proofs):
+    # every dispatch target (chunk-split, LDS "sets", lane=row "bcast" kernel register-staged (odd cols) and with the
+    # LDS-DMA ring (even cols: 1, 2, 3, 4, 8, 13 tiles); u32 and u16 matrix limbs) gives
+    # the single-set result set by set, and the oracle's result on a sample of rows
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    q = Q_REF33
+    ctx = lab.Context(q, 0)
+    bound = 1625
+    ctx.enable_digit_basis(5000, bound)
+    rng = np.random.default_rng(nb * 1000 + rows)
+    M = rp(rng, q, nmat, rows, cols)
+    V = rng.integers(0, bound, size=(nb, nmat, cols, D), dtype=np.uint64)
+    hM = ctx.vec(nmat * rows * cols, digit=True, compact=compact).load(M)
+    hV = ctx.vec(nb * nmat * cols, digit=True).load(V)
+    got = lab.matvec_sum_batched(ctx, hM, hV, nmat, rows, cols, nb).store().reshape(nb, rows, D)
+    for b in range(nb):
+        one = lab.matvec_sum(ctx, hM, hV, nmat, rows, cols, v_off=b * nmat * cols).store()
+        assert np.array_equal(got[b], one), (b,)
+    for b, r_ in ((0, 0), (nb - 1, rows - 1), (nb // 2, rows // 2)):
+        want = np.zeros(D, np.uint64)
+        for m in range(nmat):
+            want = co.poly_add(q, want, co.inner_product(q, M[m, r_], V[b, m]))
+        assert np.array_equal(got[b, r_], want)
+    ctx.close()
+
+
+@pytest.mark.parametrize("q", [Q_REF33, Q_DIRECT])
+def test_matvec_sum_batched_main_basis_full_residues(contexts, q):
+    # same, operands in the context's main basis with full-range residues (worst case for the 64-bit accumulators:
+    # the lazy fold keeps the high word below 2p across 8-term groups)
+    import labrador_snark_amd as lab
+    ctx = contexts(q)
+    rng = np.random.default_rng(77)
+    nb, nmat, rows, cols = 8, 2, 70, 300
+    M = np.full((nmat, rows, cols, D), q - 1, np.uint64)
+    M[:, ::3] = rp(rng, q, nmat, len(range(0, rows, 3)), cols)
+    V = np.full((nb, nmat, cols, D), q - 1, np.uint64)
+    V[1::2] = rp(rng, q, nb // 2, nmat, cols)
+    hM, hV = ctx.vec_from(M), ctx.vec_from(V)
+    got = lab.matvec_sum_batched(ctx, hM, hV, nmat, rows, cols, nb).store().reshape(nb, rows, D)
+    for b in range(nb):
+        assert np.array_equal(got[b], lab.matvec_sum(ctx, hM, hV, nmat, rows, cols, v_off=b * nmat * cols).store())

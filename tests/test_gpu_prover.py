@@ -176,12 +176,13 @@ def test_prove_and_verify_with_compact_crs(q, n, r, kappa, kappa1):
     ctx.close()
 
 
-@pytest.mark.parametrize("nb", [2, 3, 5, 8])
+@pytest.mark.parametrize("nb,kappa1", [(2, 20), (3, 20), (5, 20), (8, 20), (7, 64), (8, 96)])
 @pytest.mark.parametrize("compact", [False, True])
-def test_prove_core_batch_equals_separate_proofs(nb, compact):
+def test_prove_core_batch_equals_separate_proofs(nb, kappa1, compact):
     # independent proofs under one CRS: batched call (B streamed once per group) == separate calls == oracle
+    # (kappa1 = 20 runs the LDS "sets" kernel in step 3, kappa1 >= 32 the lane=row kernel with the LDS-DMA ring)
     import labrador_snark_amd as lab
-    q, n, r, kappa, kappa1 = Q_REF33, 4, 8, 64, 20
+    q, n, r, kappa = Q_REF33, 4, 8, 64
     ctx = lab.Context(q, 0)
     p = cases.Params(q, n, r, kappa, kappa1)
     k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
