@@ -765,7 +765,11 @@ extern "C" int lab_ajtai_commit(lab_ctx* c, lab_vec* out, size_t out_off, const 
       (rc = check_plain(c, out, 0, "lab_ajtai_commit"))) return rc;
   if (inner > c->max_len) return fail(c, LAB_ERR_RANGE, "lab_ajtai_commit: reduction length %zu exceeds the exactness bound %llu", inner, (unsigned long long)c->max_len);
   LAB_HIP(c, hipSetDevice(c->device));
-  LAB_HIP(c, launch_matmul_t(out->view(out_off), A->view(a_off), S->view(s_off), rows, inner, ncols, c->nlimbs, c->d_tabs, c->stream));
+  hipError_t e = launch_matmul_bcast(out->view(out_off), rows * D, 0, A->view(a_off), S->view(s_off), D, ncols * D, 0, 1, rows,
+                                     inner, ncols, c->nlimbs, c->d_tabs, c->stream);
+  if (e == hipErrorNotSupported)
+    e = launch_matmul_t(out->view(out_off), A->view(a_off), S->view(s_off), rows, inner, ncols, c->nlimbs, c->d_tabs, c->stream);
+  LAB_HIP(c, e);
   return LAB_OK;
 }
 

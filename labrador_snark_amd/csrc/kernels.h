@@ -81,6 +81,9 @@ hipError_t launch_axpy_partial_batched_u16(int nb, uint32_t* partial_plane, size
 hipError_t launch_pack_u16(uint16_t* dst16, const uint32_t* src32, size_t count, bool unpack, uint32_t* udst32,
                            hipStream_t s);
 // out[i*rows + rho] = <A[rho,:], S[:,i]>   A: [rows][inner], S: [inner][ncols]
+hipError_t launch_matmul_bcast(HatView out, size_t out_set_stride, size_t out_job_stride, ConstHatView A, ConstHatView S,
+                               size_t s_set_stride, size_t s_col_stride, size_t s_job_stride, size_t njobs, size_t rows,
+                               size_t inner, size_t nsets, int nlimbs, const LimbTable* tabs, hipStream_t s);
 hipError_t launch_matmul_t(HatView out, ConstHatView A, ConstHatView S, size_t rows, size_t inner, size_t ncols,
                            int nlimbs, const LimbTable* tabs, hipStream_t s);
 // out[i*r + k] = sum_x P[x*r+i] * S[x*r+k]

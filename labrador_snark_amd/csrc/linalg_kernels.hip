@@ -668,11 +668,25 @@ __device__ __forceinline__ void lds_read_v(MR& m, u32x4_t (&v)[4], uint32_t vadd
   }
 }
 
+// Shapes served (BcastArgs): the batched mat-vec (ngroups = 1: NB vector sets, grid = row blocks x matrices x limbs)
+// and the matrix-matrix product out[set][row] = sum_c M[row][c] * V[c][set] with many sets (the Ajtai commitment
+// t_i = A s_i of every witness column of every proof in the batch): the sets are cut into `ngroups` groups of NB,
+// and blockIdx.x is decoded so that the groups of one row block run on ONE XCD at the same time — the first of them
+// pulls the matrix tile from HBM, the others hit that XCD's L2.
+struct BcastArgs {
+  uint32_t* partial;        // out + limb*partial_ps + job*partial_js + group*partial_gs + b*partial_bs + (mat*rows+row)*64
+  size_t partial_ps, partial_bs, partial_gs, partial_js;
+  const void* M;
+  size_t m_ps;
+  const uint32_t* V;        // V + limb*v_ps + job*v_js + group*v_gs + b*v_bs + (mat*cols + c)*v_cs
+  size_t v_ps, v_bs, v_cs, v_gs, v_js;
+  unsigned rows, cols, rowblocks, ngroups, groups_per_job;
+  const LimbTable* tabs;
+};
+
 template <typename MT, int NB>
 __global__ void __launch_bounds__(BC_THREADS)
-k_matvec_bcast_dma(uint32_t* __restrict__ partial, size_t partial_ps, size_t partial_bs, const MT* __restrict__ M, size_t m_ps,
-                   const uint32_t* __restrict__ V, size_t v_ps, size_t v_bs, unsigned rows, unsigned cols,
-                   const LimbTable* __restrict__ tabs) {
+k_matvec_bcast_dma(const BcastArgs a) {
   typedef typename Quad<MT>::raw mraw;
   constexpr int RAWB = sizeof(mraw);                 // bytes per slot quad in the matrix: 16 (u32) / 8 (u16)
   constexpr int ROWB = BC_COLS * 16 * RAWB;          // tile bytes per matrix row: 512 / 256
@@ -689,11 +703,25 @@ k_matvec_bcast_dma(uint32_t* __restrict__ partial, size_t partial_ps, size_t par
   __shared__ uint4 tv0[NB * BC_COLS * 16], tv1[NB * BC_COLS * 16], tv2[NB * BC_COLS * 16];
   const int limb = blockIdx.z;
   const unsigned mat = blockIdx.y;
-  const unsigned row0 = blockIdx.x * BC_ROWS;
+  unsigned rb = blockIdx.x, grp = 0;
+  if (a.ngroups > 1) {      // XCD x = blockIdx.x % 8 walks (row block x + 8k, group 0 .. ngroups-1), k = 0, 1, ...
+    const unsigned x = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    rb = x + 8 * (seq / a.ngroups);
+    grp = seq % a.ngroups;
+    if (rb >= a.rowblocks) return;   // whole block, before any barrier
+  }
+  const unsigned job = grp / a.groups_per_job, gin = grp % a.groups_per_job;
+  const unsigned rows = a.rows, cols = a.cols;
+  const size_t v_bs = a.v_bs, v_cs = a.v_cs;
+  const unsigned row0 = rb * BC_ROWS;
+  const LimbTable* tabs = a.tabs;
   const uint32_t p = tabs[limb].p, p2 = tabs[limb].p2, pinv = tabs[limb].pinv, r2 = tabs[limb].r2;
   const int t = threadIdx.x, lane = t & 63;
   const int jq = __builtin_amdgcn_readfirstlane(t >> 6);   // wave index = slot quad
-  const unsigned char* Mbase = reinterpret_cast<const unsigned char*>(M + (size_t)limb * m_ps + (size_t)mat * rows * cols * D);
+  const unsigned char* Mbase = reinterpret_cast<const unsigned char*>(static_cast<const MT*>(a.M) + (size_t)limb * a.m_ps +
+                                                                      (size_t)mat * rows * cols * D);
+  uint32_t* partial = a.partial + (size_t)limb * a.partial_ps + (size_t)job * a.partial_js + (size_t)gin * a.partial_gs;
+  const size_t partial_bs = a.partial_bs;
 
   // sources as wave-uniform base + 32-bit lane offset (the launcher checks rows*cols*256 < 2^32)
   uint32_t moffs[MI];
@@ -704,8 +732,10 @@ k_matvec_bcast_dma(uint32_t* __restrict__ partial, size_t partial_ps, size_t par
   }
   const unsigned char* mrow0 = Mbase + (size_t)row0 * cols * 16 * RAWB;
   const int kv = jq % NV;                              // waves beyond NV repeat a vector piece (same bytes, same place)
-  const uint32_t* vbase = V + (size_t)limb * v_ps + (size_t)(kv * 2) * v_bs + (size_t)mat * cols * D;
-  const uint32_t voff = (uint32_t)((lane / 32) * v_bs + (lane % 32) * 4) * 4;   // bytes
+  const uint32_t* vbase = a.V + (size_t)limb * a.v_ps + (size_t)job * a.v_js + (size_t)gin * a.v_gs + (size_t)(kv * 2) * v_bs +
+                          (size_t)mat * cols * v_cs;
+  // lane -> (set kv*2 + lane/32, column (lane%32)/16, slot quad lane%16); bytes
+  const uint32_t voff = (uint32_t)((lane / 32) * v_bs + ((lane % 32) / 16) * v_cs + (lane % 16) * 4) * 4;
 
   uint64_t acc[NB][4];
 #pragma unroll
@@ -719,7 +749,7 @@ k_matvec_bcast_dma(uint32_t* __restrict__ partial, size_t partial_ps, size_t par
   auto issue = [&](unsigned tl, unsigned char* tm, uint4* tv) {
     tl = min(tl, ntiles - 1);
     const unsigned char* mb = mrow0 + (size_t)tl * ROWB;
-    const unsigned char* vb = reinterpret_cast<const unsigned char*>(vbase + (size_t)tl * BC_COLS * D);
+    const unsigned char* vb = reinterpret_cast<const unsigned char*>(vbase + (size_t)tl * BC_COLS * v_cs);
 #pragma unroll
     for (int i = 0; i < MI; i++)
       __builtin_amdgcn_global_load_lds((gptr_t)(mb + moffs[i]), (lptr_t)(tm + (jq * MI + i) * PIECE), 16, 0, 2);
@@ -789,10 +819,32 @@ k_matvec_bcast_dma(uint32_t* __restrict__ partial, size_t partial_ps, size_t par
       o.y = mont_mul(redc64(acc_fold(acc[b][1], p, p2), p, pinv), r2, p, pinv);
       o.z = mont_mul(redc64(acc_fold(acc[b][2], p, p2), p, pinv), r2, p, pinv);
       o.w = mont_mul(redc64(acc_fold(acc[b][3], p, p2), p, pinv), r2, p, pinv);
-      *reinterpret_cast<uint4*>(partial + (size_t)limb * partial_ps + (size_t)b * partial_bs +
-                                ((size_t)mat * rows + row) * D + jq * 4) = o;
+      *reinterpret_cast<uint4*>(partial + (size_t)b * partial_bs + ((size_t)mat * rows + row) * D + jq * 4) = o;
     }
   }
+}
+
+// out[job][set][row] = sum_c A[row][c] * S[job][c][set]: every job's sets share A (sets % 8 == 0, inner % BC_COLS == 0,
+// rows >= 32; strides in words inside a limb plane).  Returns hipErrorNotSupported for shapes this kernel does not take.
+hipError_t launch_matmul_bcast(HatView out, size_t out_set_stride, size_t out_job_stride, ConstHatView A, ConstHatView S,
+                               size_t s_set_stride, size_t s_col_stride, size_t s_job_stride, size_t njobs, size_t rows,
+                               size_t inner, size_t nsets, int nlimbs, const LimbTable* tabs, hipStream_t s) {
+  if (njobs == 0 || rows == 0 || nsets == 0) return hipSuccess;
+  if (nsets % 8 || inner % BC_COLS || inner == 0 || rows < (size_t)BC_ROWS / 2 || (uint64_t)rows * inner * 256 >= (1ull << 32) ||
+      (s_set_stride * 2 + s_col_stride) * 4 >= (1ull << 32) || njobs * (nsets / 8) > 65535)
+    return hipErrorNotSupported;
+  BcastArgs a;
+  a.partial = out.base; a.partial_ps = out.plane_stride; a.partial_bs = out_set_stride; a.partial_gs = 8 * out_set_stride;
+  a.partial_js = out_job_stride;
+  a.M = A.base; a.m_ps = A.plane_stride;
+  a.V = S.base; a.v_ps = S.plane_stride; a.v_bs = s_set_stride; a.v_cs = s_col_stride; a.v_gs = 8 * s_set_stride; a.v_js = s_job_stride;
+  a.rows = (unsigned)rows; a.cols = (unsigned)inner; a.rowblocks = (unsigned)((rows + BC_ROWS - 1) / BC_ROWS);
+  a.groups_per_job = (unsigned)(nsets / 8); a.ngroups = (unsigned)(njobs * (nsets / 8));
+  a.tabs = tabs;
+  // ngroups == 1 would be read as the plain row-block grid by the kernel: it is one, with 8 * ceil(rb/8) blocks
+  dim3 g(a.ngroups > 1 ? 8 * a.ngroups * ((a.rowblocks + 7) / 8) : a.rowblocks, 1, (unsigned)nlimbs);
+  hipLaunchKernelGGL((k_matvec_bcast_dma<uint32_t, 8>), g, dim3(BC_THREADS), 0, s, a);
+  return hipGetLastError();
 }
 
 template <typename MT>
@@ -803,9 +855,13 @@ static hipError_t launch_matvec_nb(int nb, uint32_t* partial, size_t partial_ps,
   if (nb > 1 && rows >= (size_t)BC_ROWS / 2 && (v_bs % 4) == 0 && cols % BC_COLS == 0 &&
       (uint64_t)rows * cols * 256 < (1ull << 32) && v_bs * 8 < (1ull << 32)) {  // ... tiles by LDS-DMA
     dim3 g((unsigned)((rows + BC_ROWS - 1) / BC_ROWS), (unsigned)nmat, (unsigned)nlimbs);
-#define LAB_BD(NBV)                                                                                                  \
-  hipLaunchKernelGGL((k_matvec_bcast_dma<MT, NBV>), g, dim3(BC_THREADS), 0, s, partial, partial_ps, partial_bs, M, m_ps, \
-                     V, v_ps, v_bs, (unsigned)rows, (unsigned)cols, tabs)
+    BcastArgs a;
+    a.partial = partial; a.partial_ps = partial_ps; a.partial_bs = partial_bs; a.partial_gs = 0; a.partial_js = 0;
+    a.M = M; a.m_ps = m_ps;
+    a.V = V; a.v_ps = v_ps; a.v_bs = v_bs; a.v_cs = D; a.v_gs = 0; a.v_js = 0;
+    a.rows = (unsigned)rows; a.cols = (unsigned)cols; a.rowblocks = g.x; a.ngroups = 1; a.groups_per_job = 1;
+    a.tabs = tabs;
+#define LAB_BD(NBV) hipLaunchKernelGGL((k_matvec_bcast_dma<MT, NBV>), g, dim3(BC_THREADS), 0, s, a)
     switch (nb) {
       case 2: LAB_BD(2); break;
       case 4: LAB_BD(4); break;

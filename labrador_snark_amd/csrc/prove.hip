@@ -196,8 +196,21 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     LAB_HIP(c, hipMemcpyAsync(J.cab + D, J.dbeta, D * 8, hipMemcpyDeviceToDevice, s));
     if ((rc = to_hat(c, J.cab, HV(j, hab), 2))) return rc;
     if ((rc = to_hat(c, J.dc, HV(j, hc), r))) return rc;
-    // step 1 (src/proofgen.rs:41-49): t_i = A s_i
-    LAB_HIP(c, launch_matmul_t(HV(j, hT), in->A->view(in->a_off), HV(j, hS), kappa, n, r, L, tabs, s));
+  }
+  // ================= step 1 (src/proofgen.rs:41-49): t_i = A s_i for every column of every proof; A is shared, so the
+  // whole batch is one (kappa x n)(n x np*r) product (falls back to one launch per proof for shapes it does not take)
+  {
+    hipError_t e = launch_matmul_bcast(HV(0, hT), kappa * D, per * D, in->A->view(in->a_off), HV(0, hS), D, r * D, per * D, np,
+                                       kappa, n, r, L, tabs, s);
+    if (e == hipErrorNotSupported) {
+      for (size_t j = 0; j < np; j++)
+        LAB_HIP(c, launch_matmul_t(HV(j, hT), in->A->view(in->a_off), HV(j, hS), kappa, n, r, L, tabs, s));
+    } else {
+      LAB_HIP(c, e);
+    }
+  }
+  for (size_t j = 0; j < np; j++) {
+    Job& J = jobs[j];
     if ((rc = from_hat(c, HV(j, hT), rk, dense_tmp, J.cT))) return rc;
     // step 2 (:59-70): G = S^T S
     if ((rc = gram_impl(c, HV(j, hG), HV(j, hS), HV(j, hS), n, r, HV(j, hpart)))) return rc;
