@@ -196,6 +196,11 @@ int lab_gram(lab_ctx *ctx, lab_vec *out, size_t out_off, const lab_vec *P, size_
  *   out[out_off + rho] = sum_{m<nterms} G[g_off + m] * C[c_off + m*len + rho] */
 int lab_axpy_commit(lab_ctx *ctx, lab_vec *out, size_t out_off, const lab_vec *G, size_t g_off, const lab_vec *C,
                     size_t c_off, size_t nterms, size_t len);
+/* The same for nb in {1,2,4,8} independent digit vectors sharing C (C is streamed once for all of them — the C / D
+ * commitments of nb proofs under one common reference string): set b reads G[g_off + b*nterms + m] and writes
+ * out[out_off + b*len + rho]. */
+int lab_axpy_commit_batched(lab_ctx *ctx, lab_vec *out, size_t out_off, const lab_vec *G, size_t g_off, const lab_vec *C,
+                            size_t c_off, size_t nterms, size_t len, int nb);
 
 /* z = sum_i c_i * s_i (src/proofgen.rs:380-399): out[out_off + x] = sum_{i<r} S[s_off + x*r + i] * c[c_off + i] */
 int lab_amortize_z(lab_ctx *ctx, lab_vec *out, size_t out_off, const lab_vec *S, size_t s_off, size_t n, size_t r,

@@ -109,6 +109,8 @@ SIGNATURES = {
                            C.c_size_t, C.c_size_t]),
     "lab_axpy_commit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                   C.c_size_t, C.c_size_t]),
+    "lab_axpy_commit_batched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                          C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]),
     "lab_amortize_z": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
                                  C.c_void_p, C.c_size_t]),
     "lab_pointwise": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,

@@ -238,6 +238,14 @@ def gram(ctx, P, S, n, r, p_off=0, s_off=0, out=None, out_off=0):
     return out
 
 
+def axpy_commit_batched(ctx, G, Cm, nterms, length, nb, g_off=0, c_off=0, out=None, out_off=0):
+    """nb independent digit vectors sharing C (streamed once): out[b][rho] = sum_m G[b][m] * C[m][rho]."""
+    if out is None:
+        out = HatVec(ctx, nb * length, digit=Cm.digit)
+    ctx._check(ctx._lib.lab_axpy_commit_batched(ctx._h, out._h, out_off, G._h, g_off, Cm._h, c_off, nterms, length, nb))
+    return out
+
+
 def axpy_commit(ctx, G, Cm, nterms, length, g_off=0, c_off=0, out=None, out_off=0):
     """out[rho] = sum_m G[m] * C[m][rho] (src/proofgen.rs:137-148, 364-378)."""
     if out is None:

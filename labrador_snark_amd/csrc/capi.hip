@@ -829,12 +829,33 @@ int lab::axpy_commit_any(lab_ctx* c, HatView out, ConstHatView G, const lab_vec*
 }
 
 // nb sets at once: out_b = out.base + b*out_bs, G_b = G.base + b*g_bs, partial_b = partial.base + b*partial_bs
+// `partial` holds max(axpy_num_chunks(nterms), min(64, ...)) * len elements per set: callers size it with
+// axpy_partial_elems(nterms, len)
 int lab::axpy_commit_batched_any(lab_ctx* c, int nb, HatView out, size_t out_bs, ConstHatView G, size_t g_bs, const lab_vec* Cm,
                                  size_t c_off, size_t nterms, size_t len, HatView partial, size_t partial_bs) {
-  const size_t chunks = axpy_num_chunks(nterms);
+  size_t chunks = axpy_num_chunks(nterms);
+  const int nfull = Cm->planes32();
+  // several digit vectors, long commitments: lane = rho product on the LDS-DMA kernel (partials fit the same scratch)
+  const size_t bchunk = nb >= 2 ? axpy_bcast_chunk(nterms, len) : 0;
+  if (bchunk) {
+    hipError_t e = hipSuccess;
+    if (nfull > 0)
+      e = launch_axpy_bcast_u32(nb, partial, partial_bs, G, g_bs, Cm->view(c_off), nterms, bchunk, len, nfull, Cm->tabs(), c->stream);
+    if (e == hipSuccess && Cm->compact)
+      e = launch_axpy_bcast_u16(nb, partial.base + (size_t)nfull * partial.plane_stride, partial_bs,
+                                G.base + (size_t)nfull * G.plane_stride, g_bs, Cm->d16 + c_off * D, nterms, bchunk, len,
+                                Cm->tabs() + nfull, c->stream);
+    if (e != hipErrorNotSupported) {
+      LAB_HIP(c, e);
+      for (int b = 0; b < nb; b++)
+        LAB_HIP(c, launch_sum_terms(HatView{out.base + (size_t)b * out_bs, out.plane_stride},
+                                    HatView{partial.base + (size_t)b * partial_bs, partial.plane_stride}, nterms / bchunk, len,
+                                    Cm->nlimbs(), Cm->tabs(), c->stream));
+      return LAB_OK;
+    }
+  }
   HatView target = chunks == 1 ? out : partial;
   const size_t target_bs = chunks == 1 ? out_bs : partial_bs;
-  const int nfull = Cm->planes32();
   if (nfull > 0)
     LAB_HIP(c, launch_axpy_partial_batched(nb, target, target_bs, G, g_bs, Cm->view(c_off), nterms, len, nfull, Cm->tabs(), c->stream));
   if (Cm->compact)
@@ -866,6 +887,33 @@ extern "C" int lab_axpy_commit(lab_ctx* c, lab_vec* out, size_t out_off, const l
   if ((rc = ensure_scratch(c, (size_t)Cm->nlimbs() * chunks * len * D * 4))) return rc;
   return axpy_commit_any(c, out->view(out_off), G->view(g_off), Cm, c_off, nterms, len,
                          HatView{static_cast<uint32_t*>(c->scratch), chunks * len * D});
+}
+
+size_t lab::axpy_partial_elems(size_t nterms, size_t len) {
+  size_t chunks = axpy_num_chunks(nterms);
+  const size_t bchunk = axpy_bcast_chunk(nterms, len);
+  if (bchunk && nterms / bchunk > chunks) chunks = nterms / bchunk;
+  return chunks * len;
+}
+
+extern "C" int lab_axpy_commit_batched(lab_ctx* c, lab_vec* out, size_t out_off, const lab_vec* G, size_t g_off,
+                                       const lab_vec* Cm, size_t c_off, size_t nterms, size_t len, int nb) {
+  if (!c) return LAB_ERR_ARG;
+  int rc;
+  if (nb != 1 && nb != 2 && nb != 4 && nb != 8) return fail(c, LAB_ERR_ARG, "lab_axpy_commit_batched: nb must be 1, 2, 4 or 8");
+  if (nterms == 0 || len == 0 || len > 0x7fffffffu / 64 || nterms > 0x3fffffu) return fail(c, LAB_ERR_ARG, "lab_axpy_commit_batched: bad dimension");
+  if ((rc = check_range(c, out, out_off, (size_t)nb * len, "lab_axpy_commit_batched(out)"))) return rc;
+  if ((rc = check_range(c, G, g_off, (size_t)nb * nterms, "lab_axpy_commit_batched(G)"))) return rc;
+  if ((rc = check_range(c, Cm, c_off, nterms * len, "lab_axpy_commit_batched(C)"))) return rc;
+  const int basis = Cm->basis;
+  if ((rc = check_plain(c, G, basis, "lab_axpy_commit_batched(G)")) || (rc = check_plain(c, out, basis, "lab_axpy_commit_batched(out)"))) return rc;
+  const uint64_t limit = basis ? c->dg_terms : c->max_len;
+  if (nterms > limit) return fail(c, LAB_ERR_RANGE, "lab_axpy_commit_batched: %zu terms exceed the exactness bound %llu of this basis", nterms, (unsigned long long)limit);
+  LAB_HIP(c, hipSetDevice(c->device));
+  const size_t pe = axpy_partial_elems(nterms, len);
+  if ((rc = ensure_scratch(c, (size_t)Cm->nlimbs() * nb * pe * D * 4))) return rc;
+  return axpy_commit_batched_any(c, nb, out->view(out_off), len * D, G->view(g_off), nterms * D, Cm, c_off, nterms, len,
+                                 HatView{static_cast<uint32_t*>(c->scratch), (size_t)nb * pe * D}, pe * D);
 }
 
 extern "C" int lab_amortize_z(lab_ctx* c, lab_vec* out, size_t out_off, const lab_vec* S, size_t s_off, size_t n,

@@ -142,6 +142,7 @@ int matvec_partial_any(lab_ctx* c, HatView partial, const lab_vec* M, size_t m_o
                        size_t rows, size_t cols);
 int matvec_partial_batched_any(lab_ctx* c, int nb, HatView partial, size_t partial_bs, const lab_vec* M, size_t m_off,
                                ConstHatView V, size_t v_bs, size_t nmat, size_t rows, size_t cols);
+size_t axpy_partial_elems(size_t nterms, size_t len);
 int axpy_commit_batched_any(lab_ctx* c, int nb, HatView out, size_t out_bs, ConstHatView G, size_t g_bs, const lab_vec* Cm,
                             size_t c_off, size_t nterms, size_t len, HatView partial, size_t partial_bs);
 int axpy_commit_any(lab_ctx* c, HatView out, ConstHatView G, const lab_vec* Cm, size_t c_off, size_t nterms, size_t len,

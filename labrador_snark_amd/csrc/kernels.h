@@ -77,6 +77,11 @@ hipError_t launch_axpy_partial_batched(int nb, HatView partial, size_t partial_b
 hipError_t launch_axpy_partial_batched_u16(int nb, uint32_t* partial_plane, size_t partial_bs, const uint32_t* G_plane,
                                            size_t g_bs, const uint16_t* C, size_t nterms, size_t len, const LimbTable* tab,
                                            hipStream_t s);
+size_t axpy_bcast_chunk(size_t nterms, size_t len);
+hipError_t launch_axpy_bcast_u32(int nb, HatView partial, size_t partial_bs, ConstHatView G, size_t g_bs, ConstHatView C,
+                                 size_t nterms, size_t chunk, size_t len, int nlimbs, const LimbTable* tabs, hipStream_t s);
+hipError_t launch_axpy_bcast_u16(int nb, uint32_t* partial_plane, size_t partial_bs, const uint32_t* G_plane, size_t g_bs,
+                                 const uint16_t* C, size_t nterms, size_t chunk, size_t len, const LimbTable* tab, hipStream_t s);
 // pack (unpack = false: dst16 <- src32) or unpack (unpack = true: udst32 <- dst16) one limb plane of `count` elements
 hipError_t launch_pack_u16(uint16_t* dst16, const uint32_t* src32, size_t count, bool unpack, uint32_t* udst32,
                            hipStream_t s);

@@ -676,8 +676,8 @@ __device__ __forceinline__ void lds_read_v(MR& m, u32x4_t (&v)[4], uint32_t vadd
 struct BcastArgs {
   uint32_t* partial;        // out + limb*partial_ps + job*partial_js + group*partial_gs + b*partial_bs + (mat*rows+row)*64
   size_t partial_ps, partial_bs, partial_gs, partial_js;
-  const void* M;
-  size_t m_ps;
+  const void* M;            // element (mat, row, c) at M + limb*m_ps + mat*m_ms + row*m_rs + c*m_cs (strides in residues)
+  size_t m_ps, m_ms, m_rs, m_cs;
   const uint32_t* V;        // V + limb*v_ps + job*v_js + group*v_gs + b*v_bs + (mat*cols + c)*v_cs
   size_t v_ps, v_bs, v_cs, v_gs, v_js;
   unsigned rows, cols, rowblocks, ngroups, groups_per_job;
@@ -719,18 +719,21 @@ k_matvec_bcast_dma(const BcastArgs a) {
   const int t = threadIdx.x, lane = t & 63;
   const int jq = __builtin_amdgcn_readfirstlane(t >> 6);   // wave index = slot quad
   const unsigned char* Mbase = reinterpret_cast<const unsigned char*>(static_cast<const MT*>(a.M) + (size_t)limb * a.m_ps +
-                                                                      (size_t)mat * rows * cols * D);
+                                                                      (size_t)mat * a.m_ms);
+  const uint32_t m_rsb = (uint32_t)(a.m_rs * sizeof(MT)), m_csb = (uint32_t)(a.m_cs * sizeof(MT));   // strides in bytes
   uint32_t* partial = a.partial + (size_t)limb * a.partial_ps + (size_t)job * a.partial_js + (size_t)gin * a.partial_gs;
   const size_t partial_bs = a.partial_bs;
 
-  // sources as wave-uniform base + 32-bit lane offset (the launcher checks rows*cols*256 < 2^32)
+  // sources as wave-uniform base + 32-bit lane offset (the launcher checks that 64 rows + 2 columns span < 2^32 bytes)
+  // lane -> (row k*RPI + lane/LPR of the block, column (lane%LPR)/(LPR/2) of the tile, 16-byte piece of the element)
+  constexpr int LPE = LPR / BC_COLS;                 // lanes per ring element: 16 (u32) / 8 (u16)
   uint32_t moffs[MI];
 #pragma unroll
   for (int i = 0; i < MI; i++) {
     const unsigned row = min(row0 + (jq * MI + i) * RPI + lane / LPR, rows - 1) - row0;
-    moffs[i] = row * cols * 16 * RAWB + (lane % LPR) * 16;
+    moffs[i] = row * m_rsb + ((lane % LPR) / LPE) * m_csb + (lane % LPE) * 16;
   }
-  const unsigned char* mrow0 = Mbase + (size_t)row0 * cols * 16 * RAWB;
+  const unsigned char* mrow0 = Mbase + (size_t)row0 * m_rsb;
   const int kv = jq % NV;                              // waves beyond NV repeat a vector piece (same bytes, same place)
   const uint32_t* vbase = a.V + (size_t)limb * a.v_ps + (size_t)job * a.v_js + (size_t)gin * a.v_gs + (size_t)(kv * 2) * v_bs +
                           (size_t)mat * cols * v_cs;
@@ -748,7 +751,7 @@ k_matvec_bcast_dma(const BcastArgs a) {
   // and waits for the same number of DMA instructions (straight-line counts the compiler can follow)
   auto issue = [&](unsigned tl, unsigned char* tm, uint4* tv) {
     tl = min(tl, ntiles - 1);
-    const unsigned char* mb = mrow0 + (size_t)tl * ROWB;
+    const unsigned char* mb = mrow0 + (size_t)tl * BC_COLS * m_csb;
     const unsigned char* vb = reinterpret_cast<const unsigned char*>(vbase + (size_t)tl * BC_COLS * v_cs);
 #pragma unroll
     for (int i = 0; i < MI; i++)
@@ -830,13 +833,13 @@ hipError_t launch_matmul_bcast(HatView out, size_t out_set_stride, size_t out_jo
                                size_t s_set_stride, size_t s_col_stride, size_t s_job_stride, size_t njobs, size_t rows,
                                size_t inner, size_t nsets, int nlimbs, const LimbTable* tabs, hipStream_t s) {
   if (njobs == 0 || rows == 0 || nsets == 0) return hipSuccess;
-  if (nsets % 8 || inner % BC_COLS || inner == 0 || rows < (size_t)BC_ROWS / 2 || (uint64_t)rows * inner * 256 >= (1ull << 32) ||
+  if (nsets % 8 || inner % BC_COLS || inner == 0 || rows < (size_t)BC_ROWS / 2 || (uint64_t)(64 * inner + 2) * 256 >= (1ull << 32) ||
       (s_set_stride * 2 + s_col_stride) * 4 >= (1ull << 32) || njobs * (nsets / 8) > 65535)
     return hipErrorNotSupported;
   BcastArgs a;
   a.partial = out.base; a.partial_ps = out.plane_stride; a.partial_bs = out_set_stride; a.partial_gs = 8 * out_set_stride;
   a.partial_js = out_job_stride;
-  a.M = A.base; a.m_ps = A.plane_stride;
+  a.M = A.base; a.m_ps = A.plane_stride; a.m_ms = 0; a.m_rs = inner * D; a.m_cs = D;
   a.V = S.base; a.v_ps = S.plane_stride; a.v_bs = s_set_stride; a.v_cs = s_col_stride; a.v_gs = 8 * s_set_stride; a.v_js = s_job_stride;
   a.rows = (unsigned)rows; a.cols = (unsigned)inner; a.rowblocks = (unsigned)((rows + BC_ROWS - 1) / BC_ROWS);
   a.groups_per_job = (unsigned)(nsets / 8); a.ngroups = (unsigned)(njobs * (nsets / 8));
@@ -847,17 +850,63 @@ hipError_t launch_matmul_bcast(HatView out, size_t out_set_stride, size_t out_jo
   return hipGetLastError();
 }
 
+// out_b[rho] = sum_m G_b[m] * C[m][rho] for nb digit vectors sharing C (nb in {2,4,8}), as a lane = rho product on the
+// LDS-DMA kernel: "rows" are the rho, "columns" the terms, split into chunks of `chunk` terms that become the
+// kernel's matrices (partial sums per chunk in `partial`, to be added up by launch_sum_terms).
+// Returns hipErrorNotSupported for shapes this path does not take.
+template <typename MT>
+static hipError_t launch_axpy_bcast(int nb, uint32_t* partial, size_t partial_ps, size_t partial_bs, const uint32_t* G, size_t g_ps,
+                                    size_t g_bs, const MT* C, size_t c_ps, size_t nterms, size_t chunk, size_t len, int nlimbs,
+                                    const LimbTable* tabs, hipStream_t s) {
+  if (nb < 2 || len < (size_t)BC_ROWS / 2 || chunk % BC_COLS || nterms % chunk || (63 * D + len * D) * sizeof(MT) >= (1ull << 32) ||
+      g_bs * 8 >= (1ull << 32))
+    return hipErrorNotSupported;
+  BcastArgs a;
+  a.partial = partial; a.partial_ps = partial_ps; a.partial_bs = partial_bs; a.partial_gs = 0; a.partial_js = 0;
+  a.M = C; a.m_ps = c_ps; a.m_ms = chunk * len * D; a.m_rs = D; a.m_cs = len * D;
+  a.V = G; a.v_ps = g_ps; a.v_bs = g_bs; a.v_cs = D; a.v_gs = 0; a.v_js = 0;
+  a.rows = (unsigned)len; a.cols = (unsigned)chunk; a.rowblocks = (unsigned)((len + BC_ROWS - 1) / BC_ROWS);
+  a.ngroups = 1; a.groups_per_job = 1; a.tabs = tabs;
+  dim3 g(a.rowblocks, (unsigned)(nterms / chunk), (unsigned)nlimbs);
+  switch (nb) {
+    case 2: hipLaunchKernelGGL((k_matvec_bcast_dma<MT, 2>), g, dim3(BC_THREADS), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((k_matvec_bcast_dma<MT, 4>), g, dim3(BC_THREADS), 0, s, a); break;
+    case 8: hipLaunchKernelGGL((k_matvec_bcast_dma<MT, 8>), g, dim3(BC_THREADS), 0, s, a); break;
+    default: return hipErrorNotSupported;
+  }
+  return hipGetLastError();
+}
+// chunk length for the path above: nterms / (the smallest chunk count in 8..64 that leaves an even chunk length, else
+// the largest below 8); 0 = none
+size_t axpy_bcast_chunk(size_t nterms, size_t len) {
+  if (len < (size_t)BC_ROWS / 2) return 0;
+  for (size_t nch = 8; nch <= 64; nch++)
+    if (nterms % nch == 0 && (nterms / nch) % BC_COLS == 0) return nterms / nch;
+  for (size_t nch = 7; nch >= 1; nch--)
+    if (nterms % nch == 0 && (nterms / nch) % BC_COLS == 0) return nterms / nch;
+  return 0;
+}
+hipError_t launch_axpy_bcast_u32(int nb, HatView partial, size_t partial_bs, ConstHatView G, size_t g_bs, ConstHatView C,
+                                 size_t nterms, size_t chunk, size_t len, int nlimbs, const LimbTable* tabs, hipStream_t s) {
+  return launch_axpy_bcast<uint32_t>(nb, partial.base, partial.plane_stride, partial_bs, G.base, G.plane_stride, g_bs, C.base,
+                                     C.plane_stride, nterms, chunk, len, nlimbs, tabs, s);
+}
+hipError_t launch_axpy_bcast_u16(int nb, uint32_t* partial_plane, size_t partial_bs, const uint32_t* G_plane, size_t g_bs,
+                                 const uint16_t* C, size_t nterms, size_t chunk, size_t len, const LimbTable* tab, hipStream_t s) {
+  return launch_axpy_bcast<uint16_t>(nb, partial_plane, 0, partial_bs, G_plane, 0, g_bs, C, 0, nterms, chunk, len, 1, tab, s);
+}
+
 template <typename MT>
 static hipError_t launch_matvec_nb(int nb, uint32_t* partial, size_t partial_ps, size_t partial_bs, const MT* M, size_t m_ps,
                                    const uint32_t* V, size_t v_ps, size_t v_bs, size_t nmat, size_t rows, size_t cols,
                                    int nlimbs, const LimbTable* tabs, hipStream_t s) {
   if (nmat == 0 || rows == 0 || nlimbs == 0) return hipSuccess;
   if (nb > 1 && rows >= (size_t)BC_ROWS / 2 && (v_bs % 4) == 0 && cols % BC_COLS == 0 &&
-      (uint64_t)rows * cols * 256 < (1ull << 32) && v_bs * 8 < (1ull << 32)) {  // ... tiles by LDS-DMA
+      (uint64_t)(64 * cols + 2) * 256 < (1ull << 32) && v_bs * 8 < (1ull << 32)) {  // ... tiles by LDS-DMA
     dim3 g((unsigned)((rows + BC_ROWS - 1) / BC_ROWS), (unsigned)nmat, (unsigned)nlimbs);
     BcastArgs a;
     a.partial = partial; a.partial_ps = partial_ps; a.partial_bs = partial_bs; a.partial_gs = 0; a.partial_js = 0;
-    a.M = M; a.m_ps = m_ps;
+    a.M = M; a.m_ps = m_ps; a.m_ms = rows * cols * D; a.m_rs = cols * D; a.m_cs = D;
     a.V = V; a.v_ps = v_ps; a.v_bs = v_bs; a.v_cs = D; a.v_gs = 0; a.v_js = 0;
     a.rows = (unsigned)rows; a.cols = (unsigned)cols; a.rowblocks = g.x; a.ngroups = 1; a.groups_per_job = 1;
     a.tabs = tabs;

@@ -125,9 +125,8 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   const size_t hTdec = hd.take(rk * t1), hGdec = hd.take(pairs * t2), hlhs = hd.take(k1), hrhs = hd.take(k1),
                hHdec = hd.take(pairs * t1), hu2 = hd.take(k2);
   size_t partd_elems = r * (size_t)t1 * k1;
-  const size_t ax_chunks_c = axpy_num_chunks(pairs * t2), ax_chunks_d = axpy_num_chunks(pairs * t1);
-  if (ax_chunks_c * k2 > partd_elems) partd_elems = ax_chunks_c * k2;
-  if (ax_chunks_d * k2 > partd_elems) partd_elems = ax_chunks_d * k2;
+  if (axpy_partial_elems(pairs * t2, k2) > partd_elems) partd_elems = axpy_partial_elems(pairs * t2, k2);
+  if (axpy_partial_elems(pairs * t1, k2) > partd_elems) partd_elems = axpy_partial_elems(pairs * t1, k2);
   const size_t hpartd = hd.take(partd_elems);
   const int Ld = basis_nlimbs(c, bdig);
   const LimbTable* tabsd = basis_tabs(c, bdig);

@@ -293,3 +293,34 @@ def test_matvec_sum_batched_main_basis_full_residues(contexts, q):
     got = lab.matvec_sum_batched(ctx, hM, hV, nmat, rows, cols, nb).store().reshape(nb, rows, D)
     for b in range(nb):
         assert np.array_equal(got[b], lab.matvec_sum(ctx, hM, hV, nmat, rows, cols, v_off=b * nmat * cols).store())
+
+
+@pytest.mark.parametrize("nb", [1, 2, 4, 8])
+@pytest.mark.parametrize("nterms,length", [(130, 21), (72, 40), (96, 64), (66, 100), (1056, 33), (17, 70), (2, 32)])
+@pytest.mark.parametrize("compact", [False, True])
+def test_axpy_commit_batched_all_kernels(nb, nterms, length, compact):
+    # nb digit vectors sharing C (the C / D commitments of nb proofs, src/proofgen.rs:137-148, 364-378): the
+    # register kernel (short commitments, odd term counts) and the lane=rho LDS-DMA kernel (length >= 32 and an even
+    # chunk length: 9x8, 8x12, 11x6 (7 < 8 chunks: 6x11 odd -> 3x22), 8x132, 1x2) agree with the single-vector op
+    # and with the oracle
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    q = Q_REF33
+    ctx = lab.Context(q, 0)
+    bound = 1625
+    ctx.enable_digit_basis(5000, bound)
+    rng = np.random.default_rng(nb * 7 + nterms)
+    G = rng.integers(0, bound, size=(nb, nterms, D), dtype=np.uint64)
+    Cm = rp(rng, q, nterms, length)
+    hC = ctx.vec(nterms * length, digit=True, compact=compact).load(Cm)
+    hG = ctx.vec(nb * nterms, digit=True).load(G)
+    got = lab.axpy_commit_batched(ctx, hG, hC, nterms, length, nb).store().reshape(nb, length, D)
+    for b in range(nb):
+        assert np.array_equal(got[b], lab.axpy_commit(ctx, hG, hC, nterms, length, g_off=b * nterms).store()), (b,)
+    b = nb - 1
+    for rho in (0, length // 2, length - 1):
+        want = np.zeros(D, np.uint64)
+        for m in range(nterms):
+            want = co.poly_add(q, want, co.polymul(q, G[b, m], Cm[m, rho]))
+        assert np.array_equal(got[b, rho], want)
+    ctx.close()
