@@ -336,17 +336,32 @@ hipError_t launch_check18(uint64_t* res, const uint64_t* s1, const uint64_t* H, 
 
 namespace lab {
 
+// Wave-wide integer sum through DPP (no LDS round trips): inclusive prefix sums inside each row of 16 lanes
+// (row_shr 1, 2, 4, 8), then row 0 -> row 1 and row 2 -> row 3 (row_bcast:15), then lane 31 -> rows 2, 3
+// (row_bcast:31).  The total is valid in lane 63 only.
+__device__ __forceinline__ int wave_sum_to_lane63(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+  return x;
+}
+
 // ---- one pass over Pi for both of its uses (src/proofgen.rs:429-456 and :244-253):
 //   proj[m]    += sum_col Pi_i[m][col] * s_i[col]                       (JL projection, integers)
 //   W[x][i][.]  = sum_m omega[m] * sigma_inv(poly(Pi_i[m][64x..]))      (Pi part of phi'')
 // A block owns witness column i and a 4096-column chunk and walks all 256 rows: a thread keeps 16
-// witness coefficients and 16+16 column accumulators in registers, loads 16 B of Pi per row, reduces
-// the row sum with wave shuffles.  Pi (1 byte per entry) is read exactly once.
-__global__ void __launch_bounds__(256)
+// witness coefficients and 16+16 column accumulators in registers, loads 16 B of Pi per row (8 rows issued
+// together, the next 8 in flight while these are consumed: a CU needs > 50 KB outstanding to stream at HBM rate),
+// reduces the row sum across the wave with DPP adds.  Pi (1 byte per entry) is read exactly once.
+// Every product is (entry in {-1,0,1}) x (20-bit half of a value < 2^40), and every sum of them stays below 2^31
+// (row part: 16 columns x 64 lanes x 2^20; column part: 256 rows x 2^20), so all accumulation is v_mad_i32_i24.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_pi_fused(unsigned long long* __restrict__ proj, uint64_t* __restrict__ W, const int8_t* __restrict__ Pi,
            const uint64_t* __restrict__ S, const uint64_t* __restrict__ omega, unsigned n, unsigned r, uint64_t q) {
-  // Every product here is (entry in {-1,0,1}) x (value < 2^40).  Values are split at bit 20 so each product is one
-  // v_mad_i64_i32 (sign-extended byte times a 20-bit half, accumulated in 64 bits) instead of compare/select chains.
+  constexpr int GR = 4;                      // rows per load group
   __shared__ int om_lo[256], om_hi[256];
   __shared__ long long rowsum[4][256];
   {
@@ -360,8 +375,7 @@ k_pi_fused(unsigned long long* __restrict__ proj, uint64_t* __restrict__ W, cons
   const size_t col0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
   const bool active = col0 < cols;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int s_lo[16], s_hi[16];
-  long long wl[16], wh[16];
+  int s_lo[16], s_hi[16], wl[16], wh[16];
 #pragma unroll
   for (int c = 0; c < 16; c++) { s_lo[c] = 0; s_hi[c] = 0; wl[c] = 0; wh[c] = 0; }
   if (active) {
@@ -373,27 +387,39 @@ k_pi_fused(unsigned long long* __restrict__ proj, uint64_t* __restrict__ W, cons
       s_lo[c + 1] = (int)(v.y & 0xFFFFF); s_hi[c + 1] = (int)(v.y >> 20);
     }
   }
+  // inactive threads (ragged last chunk) read column 0 of their row: no divergence in the loop, their witness
+  // coefficients are 0 (row sums unaffected) and their column sums are never stored
   const int8_t* pp = Pi + (size_t)i * 256 * cols + (active ? col0 : 0);
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-#pragma unroll 2
-  for (int m = 0; m < 256; m++) {
-    u32x4_t w = {0, 0, 0, 0};
-    if (active) w = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(pp + (size_t)m * cols));  // Pi is read once
-    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-    const int ol = om_lo[m], oh = om_hi[m];
-    long long a_lo = 0, a_hi = 0;
+  u32x4_t cur[GR], nxt[GR];
 #pragma unroll
-    for (int c = 0; c < 16; c++) {
-      const int e = (int)(int8_t)(ww[c >> 2] >> ((c & 3) * 8));
-      a_lo += (long long)e * s_lo[c];
-      a_hi += (long long)e * s_hi[c];
-      wl[c] += (long long)e * ol;
-      wh[c] += (long long)e * oh;
+  for (int u = 0; u < GR; u++) cur[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(pp + (size_t)u * cols));
+  for (int m0 = 0; m0 < 256; m0 += GR) {
+    if (m0 + GR < 256) {
+#pragma unroll
+      for (int u = 0; u < GR; u++)
+        nxt[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(pp + (size_t)(m0 + GR + u) * cols));
     }
-    long long a = a_lo + (a_hi << 20);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
-    if (lane == 0) rowsum[wave][m] = a;
+    for (int u = 0; u < GR; u++) {
+      const int m = m0 + u;
+      const uint32_t ww[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
+      const int ol = om_lo[m], oh = om_hi[m];
+      int a_lo = 0, a_hi = 0;
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        const int e = (int)(int8_t)(ww[c >> 2] >> ((c & 3) * 8));   // inactive threads: s = 0, W not stored
+        a_lo = __mul24(e, s_lo[c]) + a_lo;
+        a_hi = __mul24(e, s_hi[c]) + a_hi;
+        wl[c] = __mul24(e, ol) + wl[c];
+        wh[c] = __mul24(e, oh) + wh[c];
+      }
+      a_lo = wave_sum_to_lane63(a_lo);
+      a_hi = wave_sum_to_lane63(a_hi);
+      if (lane == 63) rowsum[wave][m] = (long long)a_lo + ((long long)a_hi << 20);
+    }
+#pragma unroll
+    for (int u = 0; u < GR; u++) cur[u] = nxt[u];
   }
   __syncthreads();
   {
@@ -405,7 +431,7 @@ k_pi_fused(unsigned long long* __restrict__ proj, uint64_t* __restrict__ W, cons
     const size_t x = col0 / D, k0 = col0 % D;
 #pragma unroll
     for (int c = 0; c < 16; c++) {
-      const long long v = wl[c] + (wh[c] << 20);          // sum_m omega[m]*Pi[m][col], |v| < 2^49
+      const long long v = (long long)wl[c] + ((long long)wh[c] << 20);   // sum_m omega[m]*Pi[m][col], |v| < 2^49
       const uint64_t mag = (uint64_t)(v < 0 ? -v : v) % q;
       const uint64_t u = v < 0 ? (mag == 0 ? 0 : q - mag) : mag;
       const size_t k = k0 + c;
