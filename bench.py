@@ -195,6 +195,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches, alg_bytes = ctx.profile_end()
+    step3_kernel = ctx.profile_kernel()
 
     # aggregate of the commitments across instances: one RCCL all-reduce of a checksum (outside the timed steps)
     chk = checksum_u64(T.u_1) + checksum_u64(T.u_2)
@@ -237,9 +238,9 @@ def main():
             "proofs_per_s": value, "witness_Rq_elems_per_s": value * n * r,
             "ring_products_per_proof": sum(counts.values()),
             "checksum_u1_u2": int(chk.item()),
-            "roofline": {"bound": "hbm", "kernel": "lab::k_matvec_partial<unsigned int> — the u32 limbs of the outer commitment "
-                                                   "sum_ik B_ik t_i^(k) (src/proofgen.rs:101-132); its u16 limb runs as a second, "
-                                                   "4x smaller launch of the same kernel template",
+            "roofline": {"bound": "hbm", "kernel": "lab::%s — the u32 limbs of the outer commitment sum_ik B_ik t_i^(k) "
+                                                   "(src/proofgen.rs:101-132) for the %d proofs of a step; the u16 limb runs as a "
+                                                   "second launch of the same kernel template" % (step3_kernel, nbatch),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "launches": launches, "avg_launch_ms": per_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1),

@@ -100,6 +100,8 @@ int lab_ctx_synchronize(lab_ctx *ctx);
  * bytes those launches moved (matrix + vector + output, all limbs). */
 int lab_ctx_profile_begin(lab_ctx *ctx);
 int lab_ctx_profile_end(lab_ctx *ctx, double *kernel_ms, uint64_t *launches, double *algorithmic_bytes);
+/* name (template arguments included) of the kernel the most recent launch timed by the hook was dispatched to */
+const char *lab_ctx_profile_kernel(const lab_ctx *ctx);
 
 /* Digit basis (no reference counterpart; a storage/bandwidth optimisation).  The outer commitments multiply CRS
  * matrices by decomposition DIGITS (< b_1, b_2 ~ 2^11, src/util.rs:389-442), so their exact integer results need

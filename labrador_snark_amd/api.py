@@ -111,6 +111,10 @@ class Context:
         self._check(self._lib.lab_ctx_profile_end(self._h, C.byref(ms), C.byref(n), C.byref(b)))
         return ms.value, int(n.value), b.value
 
+    def profile_kernel(self):
+        """Name of the kernel the most recent launch timed by the profiling hook was dispatched to."""
+        return self._lib.lab_ctx_profile_kernel(self._h).decode()
+
     # ---- PLAN.negacyclic_polymul + transform_slice_u64_to_zq (src/algebraic.rs:396-397), batched
     def negacyclic_polymul(self, lhs, rhs, out=None):
         lhs, rhs = _as_u64(lhs), _as_u64(rhs)

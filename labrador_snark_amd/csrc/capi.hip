@@ -320,6 +320,10 @@ extern "C" int lab_ctx_profile_begin(lab_ctx* c) {
   return LAB_OK;
 }
 
+extern "C" const char* lab_ctx_profile_kernel(const lab_ctx* c) {
+  return c ? c->prof_kernel : "";
+}
+
 extern "C" int lab_ctx_profile_end(lab_ctx* c, double* kernel_ms, uint64_t* launches, double* algorithmic_bytes) {
   if (!c) return LAB_ERR_ARG;
   LAB_HIP(c, hipStreamSynchronize(c->stream));
@@ -353,6 +357,7 @@ int lab::matvec_partial_timed(lab_ctx* c, HatView partial, ConstHatView M, Const
   LAB_HIP(c, hipEventRecord(ev.first, c->stream));
   LAB_HIP(c, launch_matvec_partial(partial, M, V, nmat, rows, cols, nlimbs, tabs, c->stream));
   LAB_HIP(c, hipEventRecord(ev.second, c->stream));
+  c->prof_kernel = matvec_kernel_name();
   c->prof_bytes += (double)nlimbs * 256.0 * ((double)nmat * rows * cols + (double)nmat * cols + (double)nmat * rows);
   return LAB_OK;
 }
@@ -678,6 +683,7 @@ int matvec_partial_batched_any(lab_ctx* c, int nb, HatView partial, size_t parti
                                              M->tabs(), c->stream));
   if (prof) {
     LAB_HIP(c, hipEventRecord(c->prof_events[c->prof_used++].second, c->stream));
+    c->prof_kernel = matvec_kernel_name();
     c->prof_bytes += (double)nfull * 256.0 * ((double)nmat * rows * cols + (double)nb * nmat * cols + (double)nb * nmat * rows);
   }
   if (M->compact)

@@ -43,6 +43,7 @@ struct lab_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   size_t prof_used = 0;
   double prof_bytes = 0.0;
+  const char* prof_kernel = "";   // kernel the last profiled mat-vec launch was dispatched to
 };
 
 struct lab_vec {

@@ -9,6 +9,8 @@
 // accumulated per NTT slot in 64-bit registers and reduced once per output.
 #include "kernels.h"
 #include <type_traits>
+#include <cstdlib>
+#include <cstdio>
 
 namespace lab {
 
@@ -625,7 +627,13 @@ k_matvec_bcast(uint32_t* __restrict__ partial, size_t partial_ps, size_t partial
 // (64 accumulator VGPRs) fit the 128-VGPR budget of a 1024-thread block.  One DMA instruction writes 1 KiB of LDS
 // contiguously (wave-uniform base + lane*16), i.e. 2 matrix rows of a u32 tile (4 of a u16 tile); pieces are spaced
 // 1040 B apart so that the transposed reads (lane = row) spread over the banks (2-way / 4-way instead of 32-way).
-// Requires cols % BC_COLS == 0 (a DMA cannot zero-fill); other shapes take the register-staged kernel.
+// Requires an even column count (a DMA cannot zero-fill); other shapes take the register-staged kernel.
+// What bounds it (measured, tools/ubench_mad.hip and timing-only builds): with 8 sets the kernel is VALU-bound, not
+// LDS-bound — dropping 3/4 of the vector LDS reads changes nothing, dropping 3/4 of the multiply-adds does.  A
+// v_mad_u64_u32 whose two multiplicands are distinct VGPRs issues in 9.3 cycles per wave64 (6.8 with an SGPR
+// multiplier, 4.9 when it re-reads its own accumulator): 1.65e13 multiply-adds/s chip-wide, of which the 8-set
+// launches reach 85-90 %.  Step 3 at 8 sets needs 1.0e11 of them per u32 limb pair: that, no longer HBM, is the
+// floor of this formulation.
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -684,23 +692,29 @@ struct BcastArgs {
   const LimbTable* tabs;
 };
 
-template <typename MT, int NB>
+// TC = ring-slot width in columns (2 or 4), DEPTH = ring slots (3: two tiles in flight behind the one being
+// consumed; 2: one, with twice the work between barriers when TC = 4).
+template <typename MT, int NB, int TC, int DEPTH>
 __global__ void __launch_bounds__(BC_THREADS)
 k_matvec_bcast_dma(const BcastArgs a) {
   typedef typename Quad<MT>::raw mraw;
   constexpr int RAWB = sizeof(mraw);                 // bytes per slot quad in the matrix: 16 (u32) / 8 (u16)
-  constexpr int ROWB = BC_COLS * 16 * RAWB;          // tile bytes per matrix row: 512 / 256
-  constexpr int RPI = 1024 / ROWB;                   // rows per DMA instruction: 2 / 4
-  constexpr int LPR = 64 / RPI;                      // lanes per row: 32 / 16
-  constexpr int NI = BC_ROWS / RPI;                  // matrix DMA instructions per tile: 32 / 16
-  constexpr int MI = NI / 16;                        // ... per wave: 2 / 1
+  constexpr int ROWB = TC * 16 * RAWB;               // tile bytes per matrix row
+  constexpr int RPI = 1024 / ROWB;                   // rows per DMA instruction (1 KiB pieces)
+  constexpr int LPR = 64 / RPI;                      // lanes per row
+  constexpr int LPE = LPR / TC;                      // lanes per ring element: 16 (u32) / 8 (u16)
+  constexpr int NI = BC_ROWS / RPI;                  // matrix DMA instructions per tile
+  constexpr int MI = NI / 16;                        // ... per wave
   constexpr int PIECE = 1024 + 16;
-  constexpr int NV = NB * BC_COLS * 256 / 1024;      // vector DMA instructions per tile: NB / 2
+  constexpr int SPP = 4 / TC;                        // vector sets per DMA instruction (a set's TC columns are TC*256 B)
+  constexpr int NV = NB / SPP;                       // vector DMA instructions per tile
   constexpr int G = MI + 1;                          // DMA instructions per wave per tile
-  // three ring slots as separate LDS objects: the compiler then knows that the reads of one slot do not alias the
-  // DMA writes into another and does not drain the DMA queue (vmcnt(0)) in front of every LDS read
-  __shared__ __attribute__((aligned(16))) unsigned char tm0[NI * PIECE], tm1[NI * PIECE], tm2[NI * PIECE];
-  __shared__ uint4 tv0[NB * BC_COLS * 16], tv1[NB * BC_COLS * 16], tv2[NB * BC_COLS * 16];
+  constexpr int FOLD_TILES = 8 / TC;                 // tiles between accumulator folds (8 terms)
+  static_assert(RPI >= 1 && MI >= 1 && NV >= 1 && NV <= 16 && (DEPTH == 2 || DEPTH == 3) && (TC == 2 || TC == 4), "tile shape");
+  // ring slots as separate LDS objects: the compiler then knows that accesses to one slot do not alias the DMA
+  // writes into another
+  __shared__ __attribute__((aligned(16))) unsigned char tm0[NI * PIECE], tm1[NI * PIECE], tm2[DEPTH == 3 ? NI * PIECE : 16];
+  __shared__ uint4 tv0[NB * TC * 16], tv1[NB * TC * 16], tv2[DEPTH == 3 ? NB * TC * 16 : 1];
   const int limb = blockIdx.z;
   const unsigned mat = blockIdx.y;
   unsigned rb = blockIdx.x, grp = 0;
@@ -724,9 +738,8 @@ k_matvec_bcast_dma(const BcastArgs a) {
   uint32_t* partial = a.partial + (size_t)limb * a.partial_ps + (size_t)job * a.partial_js + (size_t)gin * a.partial_gs;
   const size_t partial_bs = a.partial_bs;
 
-  // sources as wave-uniform base + 32-bit lane offset (the launcher checks that 64 rows + 2 columns span < 2^32 bytes)
-  // lane -> (row k*RPI + lane/LPR of the block, column (lane%LPR)/(LPR/2) of the tile, 16-byte piece of the element)
-  constexpr int LPE = LPR / BC_COLS;                 // lanes per ring element: 16 (u32) / 8 (u16)
+  // sources as wave-uniform base + 32-bit lane offset (the launcher checks that 64 rows + TC columns span < 2^32 bytes)
+  // lane -> (row k*RPI + lane/LPR of the block, column (lane%LPR)/LPE of the tile, 16-byte piece of the element)
   uint32_t moffs[MI];
 #pragma unroll
   for (int i = 0; i < MI; i++) {
@@ -735,10 +748,10 @@ k_matvec_bcast_dma(const BcastArgs a) {
   }
   const unsigned char* mrow0 = Mbase + (size_t)row0 * m_rsb;
   const int kv = jq % NV;                              // waves beyond NV repeat a vector piece (same bytes, same place)
-  const uint32_t* vbase = a.V + (size_t)limb * a.v_ps + (size_t)job * a.v_js + (size_t)gin * a.v_gs + (size_t)(kv * 2) * v_bs +
+  const uint32_t* vbase = a.V + (size_t)limb * a.v_ps + (size_t)job * a.v_js + (size_t)gin * a.v_gs + (size_t)(kv * SPP) * v_bs +
                           (size_t)mat * cols * v_cs;
-  // lane -> (set kv*2 + lane/32, column (lane%32)/16, slot quad lane%16); bytes
-  const uint32_t voff = (uint32_t)((lane / 32) * v_bs + ((lane % 32) / 16) * v_cs + (lane % 16) * 4) * 4;
+  // lane -> (set kv*SPP + lane/(16*TC), column (lane/16)%TC, slot quad lane%16); bytes
+  const uint32_t voff = (uint32_t)((lane / (16 * TC)) * v_bs + ((lane / 16) % TC) * v_cs + (lane % 16) * 4) * 4;
 
   uint64_t acc[NB][4];
 #pragma unroll
@@ -746,13 +759,13 @@ k_matvec_bcast_dma(const BcastArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; k++) acc[b][k] = 0;
 
-  const unsigned ntiles = cols / BC_COLS;
+  const unsigned ntiles = cols / TC;
   // tile index clamped: past the end the last tile is fetched again into a slot nobody reads, so every step issues
   // and waits for the same number of DMA instructions (straight-line counts the compiler can follow)
   auto issue = [&](unsigned tl, unsigned char* tm, uint4* tv) {
     tl = min(tl, ntiles - 1);
-    const unsigned char* mb = mrow0 + (size_t)tl * BC_COLS * m_csb;
-    const unsigned char* vb = reinterpret_cast<const unsigned char*>(vbase + (size_t)tl * BC_COLS * v_cs);
+    const unsigned char* mb = mrow0 + (size_t)tl * TC * m_csb;
+    const unsigned char* vb = reinterpret_cast<const unsigned char*>(vbase + (size_t)tl * TC * v_cs);
 #pragma unroll
     for (int i = 0; i < MI; i++)
       __builtin_amdgcn_global_load_lds((gptr_t)(mb + moffs[i]), (lptr_t)(tm + (jq * MI + i) * PIECE), 16, 0, 2);
@@ -761,14 +774,14 @@ k_matvec_bcast_dma(const BcastArgs a) {
   const uint32_t moff = (lane / RPI) * PIECE + (lane % RPI) * ROWB + jq * RAWB;
   const uint32_t voffl = jq * 16;
   constexpr int GS = NB < 4 ? NB : 4;
-  // one tile: consume ring slot (tm, tv) while tile tl+2 is sent to slot (nm, nv), the one tile tl-1 was read from
+  // one tile: consume ring slot (tm, tv) while tile tl+DEPTH-1 is sent to slot (nm, nv), the one tile tl-1 was read from
   auto step = [&](unsigned tl, unsigned char* tm, uint4* tv, unsigned char* nm, uint4* nv) {
-    // this wave's pieces of tile tl have landed (tile tl+1's G instructions stay in flight) ...
+    // this wave's pieces of tile tl have landed (with 3 slots tile tl+1's G instructions stay in flight) ...
     // (the builtin, not inline asm: the compiler's own wait-count pass has to see it)
-    __builtin_amdgcn_s_waitcnt(0x0F70 | G);   // vmcnt(G), expcnt/lgkmcnt untouched
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (DEPTH == 3 ? G : 0));   // vmcnt(G) / vmcnt(0), expcnt/lgkmcnt untouched
     // ... and after the barrier so have everybody's; everybody has also finished reading tile tl-1
     __builtin_amdgcn_s_barrier();
-    issue(tl + 2, nm, nv);
+    issue(tl + DEPTH - 1, nm, nv);
     const uint32_t maddr = (uint32_t)(uintptr_t)(lptr_t)tm + moff;
     const uint32_t vaddr = (uint32_t)(uintptr_t)(lptr_t)tv + voffl;      // wave-uniform: broadcast reads
     auto column = [&](auto cc_tag) {
@@ -779,8 +792,8 @@ k_matvec_bcast_dma(const BcastArgs a) {
 #pragma unroll
       for (int g = 0; g < NB / GS; g++) {
         u32x4_t v[4];
-        if (g == 0) lds_read_v<GS, cc * 256, BC_COLS * 256>(mr, v, vaddr);
-        else lds_read_v<GS, (GS * BC_COLS + cc) * 256, BC_COLS * 256>(mr, v, vaddr);
+        if (g == 0) lds_read_v<GS, cc * 256, TC * 256>(mr, v, vaddr);
+        else lds_read_v<GS, (GS * TC + cc) * 256, TC * 256>(mr, v, vaddr);
         if (g == 0)
           m = unpack_quad(mr);
 #pragma unroll
@@ -793,24 +806,37 @@ k_matvec_bcast_dma(const BcastArgs a) {
         }
       }
     };
-    static_assert(BC_COLS == 2 && NB / GS <= 2, "column() is written out for two columns, at most two groups");
+    static_assert(NB / GS <= 2, "column() handles at most two groups of vector sets");
     column(std::integral_constant<int, 0>{});
     column(std::integral_constant<int, 1>{});
-    if ((tl & 3) == 3) {      // 4 tiles x BC_COLS = 8 terms since the last fold
+    if constexpr (TC == 4) {
+      column(std::integral_constant<int, 2>{});
+      column(std::integral_constant<int, 3>{});
+    }
+    if ((tl & (FOLD_TILES - 1)) == FOLD_TILES - 1) {      // 8 terms since the last fold
 #pragma unroll
       for (int b = 0; b < NB; b++)
 #pragma unroll
         for (int k = 0; k < 4; k++) acc[b][k] = acc_fold_lazy(acc[b][k], p2);
     }
   };
-  issue(0, tm0, tv0);
-  issue(1, tm1, tv1);
-  for (unsigned tl = 0; tl < ntiles; tl += 3) {
-    step(tl, tm0, tv0, tm2, tv2);
-    if (tl + 1 >= ntiles) break;
-    step(tl + 1, tm1, tv1, tm0, tv0);
-    if (tl + 2 >= ntiles) break;
-    step(tl + 2, tm2, tv2, tm1, tv1);
+  if constexpr (DEPTH == 3) {
+    issue(0, tm0, tv0);
+    issue(1, tm1, tv1);
+    for (unsigned tl = 0; tl < ntiles; tl += 3) {
+      step(tl, tm0, tv0, tm2, tv2);
+      if (tl + 1 >= ntiles) break;
+      step(tl + 1, tm1, tv1, tm0, tv0);
+      if (tl + 2 >= ntiles) break;
+      step(tl + 2, tm2, tv2, tm1, tv1);
+    }
+  } else {
+    issue(0, tm0, tv0);
+    for (unsigned tl = 0; tl < ntiles; tl += 2) {
+      step(tl, tm0, tv0, tm1, tv1);
+      if (tl + 1 >= ntiles) break;
+      step(tl + 1, tm1, tv1, tm0, tv0);
+    }
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // no DMA may still be writing this block's LDS when it ends
   const unsigned row = row0 + lane;
@@ -825,6 +851,31 @@ k_matvec_bcast_dma(const BcastArgs a) {
       *reinterpret_cast<uint4*>(partial + (size_t)b * partial_bs + ((size_t)mat * rows + row) * D + jq * 4) = o;
     }
   }
+}
+
+static void set_last_matvec_kernel(const char* n);
+// tile shape per matrix type and column count; LAB_BCAST_TC / LAB_BCAST_DEPTH (environment) override it for tuning
+template <typename MT, int NB>
+static hipError_t launch_bcast_dma(const BcastArgs& a, dim3 g, hipStream_t s) {
+  static const int env_tc = getenv("LAB_BCAST_TC") ? atoi(getenv("LAB_BCAST_TC")) : 0;
+  static const int env_depth = getenv("LAB_BCAST_DEPTH") ? atoi(getenv("LAB_BCAST_DEPTH")) : 0;
+  int tc = a.cols % 4 == 0 ? 4 : 2, depth = tc == 4 ? 2 : 3;
+  if (env_tc == 2 || (env_tc == 4 && a.cols % 4 == 0)) { tc = env_tc; depth = tc == 4 ? 2 : 3; }
+  if (env_depth == 2 || env_depth == 3) depth = env_depth;
+  if (tc == 4 && depth == 3 && (sizeof(MT) == 4 || NB * 4 * 256 * 3 + 3 * 33280 > 160 * 1024)) depth = 2;   // LDS budget
+  if (sizeof(MT) == 4 && a.ngroups == 1 && a.m_cs == (size_t)D) {   // a mat-vec launch (not the Ajtai / C, D shapes)
+    static char name[64];
+    snprintf(name, sizeof name, "k_matvec_bcast_dma<unsigned int, %d, %d, %d>", NB, tc, depth);
+    set_last_matvec_kernel(name);
+  }
+  if (tc == 2 && depth == 3) hipLaunchKernelGGL((k_matvec_bcast_dma<MT, NB, 2, 3>), g, dim3(BC_THREADS), 0, s, a);
+  else if (tc == 2) hipLaunchKernelGGL((k_matvec_bcast_dma<MT, NB, 2, 2>), g, dim3(BC_THREADS), 0, s, a);
+  else if (depth == 2) hipLaunchKernelGGL((k_matvec_bcast_dma<MT, NB, 4, 2>), g, dim3(BC_THREADS), 0, s, a);
+  else {
+    if constexpr (sizeof(MT) == 2) hipLaunchKernelGGL((k_matvec_bcast_dma<MT, NB, 4, 3>), g, dim3(BC_THREADS), 0, s, a);
+    else return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 // out[job][set][row] = sum_c A[row][c] * S[job][c][set]: every job's sets share A (sets % 8 == 0, inner % BC_COLS == 0,
@@ -846,8 +897,7 @@ hipError_t launch_matmul_bcast(HatView out, size_t out_set_stride, size_t out_jo
   a.tabs = tabs;
   // ngroups == 1 would be read as the plain row-block grid by the kernel: it is one, with 8 * ceil(rb/8) blocks
   dim3 g(a.ngroups > 1 ? 8 * a.ngroups * ((a.rowblocks + 7) / 8) : a.rowblocks, 1, (unsigned)nlimbs);
-  hipLaunchKernelGGL((k_matvec_bcast_dma<uint32_t, 8>), g, dim3(BC_THREADS), 0, s, a);
-  return hipGetLastError();
+  return launch_bcast_dma<uint32_t, 8>(a, g, s);
 }
 
 // out_b[rho] = sum_m G_b[m] * C[m][rho] for nb digit vectors sharing C (nb in {2,4,8}), as a lane = rho product on the
@@ -869,12 +919,11 @@ static hipError_t launch_axpy_bcast(int nb, uint32_t* partial, size_t partial_ps
   a.ngroups = 1; a.groups_per_job = 1; a.tabs = tabs;
   dim3 g(a.rowblocks, (unsigned)(nterms / chunk), (unsigned)nlimbs);
   switch (nb) {
-    case 2: hipLaunchKernelGGL((k_matvec_bcast_dma<MT, 2>), g, dim3(BC_THREADS), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((k_matvec_bcast_dma<MT, 4>), g, dim3(BC_THREADS), 0, s, a); break;
-    case 8: hipLaunchKernelGGL((k_matvec_bcast_dma<MT, 8>), g, dim3(BC_THREADS), 0, s, a); break;
+    case 2: return launch_bcast_dma<MT, 2>(a, g, s);
+    case 4: return launch_bcast_dma<MT, 4>(a, g, s);
+    case 8: return launch_bcast_dma<MT, 8>(a, g, s);
     default: return hipErrorNotSupported;
   }
-  return hipGetLastError();
 }
 // chunk length for the path above: nterms / (the smallest chunk count in 8..64 that leaves an even chunk length, else
 // the largest below 8); 0 = none
@@ -910,15 +959,12 @@ static hipError_t launch_matvec_nb(int nb, uint32_t* partial, size_t partial_ps,
     a.V = V; a.v_ps = v_ps; a.v_bs = v_bs; a.v_cs = D; a.v_gs = 0; a.v_js = 0;
     a.rows = (unsigned)rows; a.cols = (unsigned)cols; a.rowblocks = g.x; a.ngroups = 1; a.groups_per_job = 1;
     a.tabs = tabs;
-#define LAB_BD(NBV) hipLaunchKernelGGL((k_matvec_bcast_dma<MT, NBV>), g, dim3(BC_THREADS), 0, s, a)
     switch (nb) {
-      case 2: LAB_BD(2); break;
-      case 4: LAB_BD(4); break;
-      case 8: LAB_BD(8); break;
+      case 2: return launch_bcast_dma<MT, 2>(a, g, s);
+      case 4: return launch_bcast_dma<MT, 4>(a, g, s);
+      case 8: return launch_bcast_dma<MT, 8>(a, g, s);
       default: return hipErrorInvalidValue;
     }
-#undef LAB_BD
-    return hipGetLastError();
   }
   if (nb > 1 && nb < 8 && rows >= (size_t)BC_ROWS / 2 && (v_bs % 4) == 0) {  // tall matrix, several vector sets: "bcast" kernel
     dim3 g((unsigned)((rows + BC_ROWS - 1) / BC_ROWS), (unsigned)nmat, (unsigned)nlimbs);
@@ -935,6 +981,7 @@ static hipError_t launch_matvec_nb(int nb, uint32_t* partial, size_t partial_ps,
   }
   if (nb > 1 && rows >= (size_t)ST_ROWS) {  // fewer rows: LDS-staged "sets" kernel
     const unsigned sr = (unsigned)st_rows(nb);
+    if (sizeof(MT) == 4) set_last_matvec_kernel(nb == 2 ? "k_matvec_sets<unsigned int, 2>" : nb == 4 ? "k_matvec_sets<unsigned int, 4>" : "k_matvec_sets<unsigned int, 8>");
     dim3 g((unsigned)((rows + sr - 1) / sr), (unsigned)nmat, (unsigned)nlimbs);
 #define LAB_ST(NBV)                                                                                                 \
   hipLaunchKernelGGL((k_matvec_sets<MT, NBV>), g, dim3(ST_THREADS), 0, s, partial, partial_ps, partial_bs, M, m_ps, V, \
@@ -948,6 +995,7 @@ static hipError_t launch_matvec_nb(int nb, uint32_t* partial, size_t partial_ps,
 #undef LAB_ST
     return hipGetLastError();
   }
+  if (sizeof(MT) == 4) set_last_matvec_kernel(nb == 1 ? "k_matvec_partial<unsigned int, 1>" : nb == 2 ? "k_matvec_partial<unsigned int, 2>" : nb == 4 ? "k_matvec_partial<unsigned int, 4>" : "k_matvec_partial<unsigned int, 8>");
   const unsigned rpb = nb >= 4 ? 2 : MV_ROWS;
   dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)nmat, (unsigned)nlimbs), block(64 * MV_WAVES);
 #define LAB_MV(NBV)                                                                                                  \
@@ -964,7 +1012,11 @@ static hipError_t launch_matvec_nb(int nb, uint32_t* partial, size_t partial_ps,
   return hipGetLastError();
 }
 
-const char* matvec_kernel_name() { return "k_matvec_partial"; }
+// name of the kernel the last u32 mat-vec dispatch chose (for lab_ctx_profile_kernel)
+static void set_last_matvec_kernel(const char* n);
+static const char* g_last_matvec_kernel = "k_matvec_partial<unsigned int, 1>";
+const char* matvec_kernel_name() { return g_last_matvec_kernel; }
+static void set_last_matvec_kernel(const char* n) { g_last_matvec_kernel = n; }
 
 hipError_t launch_matvec_partial(HatView partial, ConstHatView M, ConstHatView V, size_t nmat, size_t rows,
                                  size_t cols, int nlimbs, const LimbTable* tabs, hipStream_t s) {

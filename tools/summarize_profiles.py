@@ -2,6 +2,7 @@
 """Turns the rocprofv3 outputs under gpurun_out/prof/ (kernel trace + two PMC passes of bench.py) into the small
 summaries committed under profiles/ (round tag as argv[1], default r01)."""
 import collections
+import os
 import csv
 import glob
 import json
@@ -10,16 +11,21 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 P = "gpurun_out/prof/"
-DOM = sys.argv[2] if len(sys.argv) > 2 else "k_matvec_rowsplit<unsigned int, 8>"
+# the dominant kernel is the one bench.py's profiling hook reports ("lab::<name> — ...")
+DOM = sys.argv[2] if len(sys.argv) > 2 else json.load(open(P + "bench_n1.json"))["roofline"]["kernel"].split(" — ")[0].replace("lab::", "")
 
-shutil.copy(glob.glob(P + "trace/*/*_kernel_stats.csv")[0], "profiles/%s_rocprofv3_kernel_stats.csv" % tag)
+def newest(pattern):
+    return max(glob.glob(pattern), key=os.path.getmtime)   # gpurun merges into gpurun_out/: older runs may still be there
+
+
+shutil.copy(newest(P + "trace/*/*_kernel_stats.csv"), "profiles/%s_rocprofv3_kernel_stats.csv" % tag)
 shutil.copy(P + "bench_n1.json", "profiles/%s_bench_n1.json" % tag)
 bench = json.load(open(P + "pmc_fetch_bench.json"))
 cfg = bench["config"]
 
 
 def biggest(kind, name):
-    f = glob.glob(P + "pmc_%s/*/*_counter_collection.csv" % kind)[0]
+    f = newest(P + "pmc_%s/*/*_counter_collection.csv" % kind)
     best = None
     for r in csv.DictReader(open(f)):
         if DOM in r["Kernel_Name"] and r["Counter_Name"] == name:
@@ -32,7 +38,7 @@ def biggest(kind, name):
 fs, ws = biggest("fetch", "FETCH_SIZE"), biggest("write", "WRITE_SIZE")
 alg = bench["roofline"]["algorithmic_bytes_per_launch"]
 fetch_bytes, write_bytes = fs[0] * 1024 * 2, ws[0] * 1024
-out = {"kernel": "lab::" + DOM + " (step-3 launch of bench.py: nmat=96, rows=1024, cols=1024, the u32 limbs)",
+out = {"kernel": "lab::" + DOM + " (step-3 launch of bench.py: nmat=96, rows=1024, cols=1024, the u32 limbs, all proofs of the step)",
        "workload_key": [cfg["q"], cfg["n"], cfg["r"], cfg["kappa"], cfg["nlimbs"], cfg["crs_basis"] != "main basis", cfg["proofs_per_step_per_gpu"]],
        "FETCH_SIZE_KB_raw": fs[0], "WRITE_SIZE_KB_raw": ws[0],
        "correction": "FETCH_SIZE x2 on gfx950 for 16-B/lane coalesced streaming loads (MI355X_MICROARCH.md 'HBM'); "
@@ -44,8 +50,11 @@ out = {"kernel": "lab::" + DOM + " (step-3 launch of bench.py: nmat=96, rows=102
                   "--no-extras --steps 2 --warmup 1"}
 json.dump(out, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
 
-tr = list(csv.DictReader(open(glob.glob(P + "trace/*/*_kernel_trace.csv")[0])))
-big = [i for i, r in enumerate(tr) if DOM in r["Kernel_Name"] and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 3e6]
+tr = list(csv.DictReader(open(newest(P + "trace/*/*_kernel_trace.csv"))))
+tr.sort(key=lambda r: int(r["Start_Timestamp"]))
+# the Ajtai product of the batch runs on the same kernel template: the step-3 launches are the long ones
+dom_durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr if DOM in r["Kernel_Name"]]
+big = [i for i, r in enumerate(tr) if DOM in r["Kernel_Name"] and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 0.6 * max(dom_durs)]
 tb = json.load(open(P + "trace_bench.json"))
 lines = ["# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras  (%s)" % tag,
          "# workload: " + tb["config"]["workload"] + " | CRS: " + tb["config"]["crs_basis"],
