@@ -193,6 +193,20 @@ int lab_ajtai_commit(lab_ctx *ctx, lab_vec *out, size_t out_off, const lab_vec *
 int lab_gram(lab_ctx *ctx, lab_vec *out, size_t out_off, const lab_vec *P, size_t p_off, const lab_vec *S,
              size_t s_off, size_t n, size_t r);
 
+/* ---- the batched outer commitment on the matrix cores (no reference counterpart; exact) ----
+ * For 8 or more proofs per batch lab_matvec_sum_batched is bound by the 64-bit multiply-add issue rate, not by HBM.
+ * lab_mat8_pack re-stores the matrices M (as for lab_matvec_sum: nmat matrices of rows x cols elements, plain or
+ * compact, either basis) once as signed base-256 digit planes in MFMA operand-tile order (same bytes per residue);
+ * lab_matvec_sum_mfma then computes, for ns in {8,16,32} vector sets V_s (set s at v_off + s*nmat*cols),
+ *   out[out_off + s*rows + rho] = sum_{m,c} M[m][rho][c] * V_s[m*cols + c]
+ * as exact int8 GEMMs (v_mfma_i32_32x32x32_i8, int32 accumulation: nmat*cols must stay below 2^17) followed by a
+ * recombination mod each limb prime.  Bit-identical to lab_matvec_sum. */
+typedef struct lab_mat8 lab_mat8;
+int lab_mat8_pack(lab_ctx *ctx, const lab_vec *M, size_t m_off, size_t nmat, size_t rows, size_t cols, lab_mat8 **out);
+int lab_mat8_destroy(lab_mat8 *m);
+size_t lab_mat8_bytes(const lab_mat8 *m);
+int lab_matvec_sum_mfma(lab_ctx *ctx, lab_vec *out, size_t out_off, const lab_mat8 *M8, const lab_vec *V, size_t v_off, int ns);
+
 /* sum_m poly_by_poly_vec(G[m], C[m]) — the C and D parts of the outer commitments
  * (src/proofgen.rs:137-148 `rhs`, 364-378 `u_2`):
  *   out[out_off + rho] = sum_{m<nterms} G[g_off + m] * C[c_off + m*len + rho] */

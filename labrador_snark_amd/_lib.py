@@ -104,6 +104,10 @@ SIGNATURES = {
                                  C.c_size_t, C.c_void_p, C.c_size_t]),
     "lab_matvec_sum_batched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
                                          C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]),
+    "lab_mat8_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "lab_mat8_destroy": (C.c_int, [C.c_void_p]),
+    "lab_mat8_bytes": (C.c_size_t, [C.c_void_p]),
+    "lab_matvec_sum_mfma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "lab_ajtai_commit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
                                    C.c_void_p, C.c_size_t, C.c_size_t]),
     "lab_gram": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,

@@ -226,6 +226,39 @@ def matvec_sum_batched(ctx, M, V, nmat, rows, cols, nb, m_off=0, v_off=0, out=No
     return out
 
 
+class Mat8:
+    """Matrices re-stored as signed base-256 digit planes in MFMA operand-tile order (lab_mat8_pack)."""
+
+    def __init__(self, ctx, M, nmat, rows, cols, m_off=0):
+        self.ctx, self.nmat, self.rows, self.cols, self.digit = ctx, nmat, rows, cols, M.digit
+        h = C.c_void_p()
+        ctx._check(ctx._lib.lab_mat8_pack(ctx._h, M._h, m_off, nmat, rows, cols, C.byref(h)))
+        self._h = h
+
+    @property
+    def nbytes(self):
+        return int(self.ctx._lib.lab_mat8_bytes(self._h))
+
+    def close(self):
+        if self._h:
+            self.ctx._lib.lab_mat8_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def matvec_sum_mfma(ctx, M8, V, ns, v_off=0, out=None, out_off=0):
+    """lab_matvec_sum_batched for ns in {8,16,32} vector sets on the matrix cores (exact int8 GEMMs)."""
+    if out is None:
+        out = HatVec(ctx, ns * M8.rows, digit=M8.digit)
+    ctx._check(ctx._lib.lab_matvec_sum_mfma(ctx._h, out._h, out_off, M8._h, V._h, v_off, ns))
+    return out
+
+
 def ajtai_commit(ctx, A, S, rows, inner, ncols, a_off=0, s_off=0, out=None, out_off=0):
     """t_i_all[i][rho] = <A[rho,:], s_i> for every witness column (src/proofgen.rs:41-49). out: [ncols][rows]."""
     if out is None:

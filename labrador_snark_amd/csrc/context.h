@@ -10,6 +10,8 @@
 #include "../../include/labrador_hip.h"
 #include "kernels.h"
 
+struct lab_mat8;
+
 struct lab_ctx {
   uint64_t q = 0;
   int device = 0;
@@ -129,6 +131,10 @@ struct Staging {
 // out[i*r+k] = sum_x P[x*r+i]*S[x*r+k]; `partial` must hold gram_num_chunks(n)*r*r elements (unused when 1 chunk)
 int gram_impl(lab_ctx* c, HatView out, ConstHatView P, ConstHatView S, size_t n, size_t r, HatView partial);
 int check_range(lab_ctx* c, const lab_vec* v, size_t off, size_t n, const char* what);
+// int8-MFMA outer commitment (mfma_api.hip)
+size_t mfma_scratch_bytes(const lab_mat8* m, int ns);
+int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_mat8* m, ConstHatView V, size_t v_set_stride, int ns,
+                     void* scratch);
 // launch_matvec_partial wrapped in the profiling events when the hook is active
 int matvec_partial_timed(lab_ctx* c, HatView partial, ConstHatView M, ConstHatView V, size_t nmat, size_t rows, size_t cols,
                          int nlimbs = 0, const LimbTable* tabs = nullptr);

@@ -1,0 +1,266 @@
+// mfma_kernels.hip — the batched outer commitment  out_s[rho] = sum_{m,c} M[m][rho][c] * V_s[m][c]  (src/proofgen.rs:101-132
+// for many proofs at once) as exact int8 GEMMs on the gfx950 matrix cores.
+//
+// With 8 or more vector sets the VALU formulation (linalg_kernels.hip) is bound by the issue rate of v_mad_u64_u32
+// (1.65e13 multiply-adds/s chip-wide).  Here every residue x in [0, p) is written in signed base-256 digits
+// x = sum_i d_i 256^i, d_i in [-128, 127] (PL = 4 digit planes for the 30-bit limb primes, 2 for a prime < 2^15), and
+// per NTT slot j and limb the sum over k = (m, c) becomes PL x PLV int8 GEMMs
+//     D[i][rho][(i', s)] = sum_k Md_i[rho][k] * Vd_i'[k][s]          (int32, exact: |D| <= K * 2^14 < 2^31 for K < 2^17)
+//     out_s[rho] = sum_{i,i'} 256^(i+i') D[i][rho][(i',s)]  mod p      (epilogue kernel)
+// on v_mfma_i32_32x32x32_i8 (32768 multiply-adds per 32 cycles per SIMD: 16 byte products per modular product still
+// leave ~9x the VALU rate).  The matrix is stored once, at CRS build time, in MFMA A-operand tile order:
+//     M8[limb][slot j][plane i][row tile rt][k tile kt][lane 64][16 B]
+// (lane l of a tile holds row rt*32 + (l & 31), k = kt*32 + 16*(l >> 5) + 0..15: one wave-wide 16-byte load is one
+// A operand, 1 KiB contiguous), 4 bytes per residue as before.  The vectors are re-packed per batch into B-operand
+// tiles V8[limb][slot j][k tile][col tile][lane][16 B], column n = i' * NS + s.
+#include "kernels.h"
+
+namespace lab {
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x16_t __attribute__((ext_vector_type(16)));
+
+// signed base-256 digits of x (x < 2^31): digit i in [-128,127] for i < planes-1, the rest in the last plane
+__device__ __forceinline__ void signed_digits(uint32_t x, int planes, int8_t (&d)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (i < planes - 1) {
+      const int8_t lo = (int8_t)(x & 0xFF);
+      d[i] = lo;
+      x = (x - (uint32_t)(int32_t)lo) >> 8;   // exact: x - lo is a multiple of 256 (lo sign-extended)
+    } else if (i == planes - 1) {
+      d[i] = (int8_t)x;
+    } else {
+      d[i] = 0;
+    }
+  }
+}
+
+// ---- matrix -> A-operand tiles.  Block = (row rho, k tile kt): the 32 polynomials M[rho][kt*32 .. +31] (8 KiB of
+// u32 residues) go through LDS, thread (j, h) then owns slot j and k half h and emits 16 bytes per plane.
+template <typename MT>
+__global__ void __launch_bounds__(128)
+k_pack_matrix_i8(int8_t* __restrict__ dst, const MT* __restrict__ src, unsigned nmat, unsigned rows, unsigned cols,
+                 unsigned rt_count, unsigned kt_count, int planes) {
+  __shared__ uint32_t tile[32][D + 1];
+  const unsigned rho = blockIdx.x, kt = blockIdx.y;
+  const unsigned ktotal = nmat * cols;
+  for (unsigned e = threadIdx.x; e < 32 * D; e += 128) {
+    const unsigned q = e / D, w = e % D, k = kt * 32 + q;
+    uint32_t v = 0;
+    if (k < ktotal && rho < rows) v = src[(((size_t)(k / cols) * rows + rho) * cols + k % cols) * D + w];
+    tile[q][w] = v;
+  }
+  __syncthreads();
+  const unsigned j = threadIdx.x & 63, h = threadIdx.x >> 6;
+  union { int8_t b[16]; uint4 v; } outp[4];
+#pragma unroll
+  for (int b = 0; b < 16; b++) {
+    int8_t d[4];
+    signed_digits(tile[16 * h + b][j], planes, d);
+#pragma unroll
+    for (int i = 0; i < 4; i++) outp[i].b[b] = d[i];
+  }
+  const unsigned rt = rho / 32, lane = (h << 5) | (rho & 31);
+  for (int i = 0; i < planes; i++) {
+    const size_t t = (((size_t)j * planes + i) * rt_count + rt) * kt_count + kt;
+    *reinterpret_cast<uint4*>(dst + t * 1024 + lane * 16) = outp[i].v;
+  }
+}
+
+hipError_t launch_pack_matrix_i8(int8_t* dst, const void* src, bool src_u16, size_t nmat, size_t rows, size_t cols,
+                                 size_t rt_count, size_t kt_count, int planes, hipStream_t s) {
+  dim3 g((unsigned)(rt_count * 32), (unsigned)kt_count);
+  if (src_u16)
+    hipLaunchKernelGGL(k_pack_matrix_i8<uint16_t>, g, dim3(128), 0, s, dst, static_cast<const uint16_t*>(src), (unsigned)nmat,
+                       (unsigned)rows, (unsigned)cols, (unsigned)rt_count, (unsigned)kt_count, planes);
+  else
+    hipLaunchKernelGGL(k_pack_matrix_i8<uint32_t>, g, dim3(128), 0, s, dst, static_cast<const uint32_t*>(src), (unsigned)nmat,
+                       (unsigned)rows, (unsigned)cols, (unsigned)rt_count, (unsigned)kt_count, planes);
+  return hipGetLastError();
+}
+
+// ---- vectors -> B-operand tiles.  Block = (k tile kt, k half h, group of 8 sets): the 16 polynomials
+// V_s[kt*32 + 16h .. +15] of its 8 sets (8 x 4 KiB, 16-byte loads) go through LDS; thread (s, j) then emits 16 bytes
+// per digit plane i' into column n = i'*NS + s: the 8 sets of a group are 8 neighbouring lanes, i.e. one 128-byte
+// line per (slot, plane).
+constexpr int PV_SETS = 8;
+constexpr int PV_PITCH = 16 * D + 4;     // words per set in LDS (16-byte aligned rows, 2-way bank conflicts at most)
+
+__global__ void __launch_bounds__(256)
+k_pack_vectors_i8(int8_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t set_stride, unsigned ktotal,
+                  unsigned kt_count, unsigned nt_count, int planes, unsigned ns) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[PV_SETS * PV_PITCH];
+  const unsigned kt = blockIdx.x, h = blockIdx.y, s0 = blockIdx.z * PV_SETS;
+  const unsigned k0 = kt * 32 + 16 * h;
+  for (unsigned e = threadIdx.x; e < PV_SETS * 16 * D / 4; e += 256) {       // quads
+    const unsigned sset = e / (16 * D / 4), wq = e % (16 * D / 4), k = k0 + wq / (D / 4);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (k < ktotal) v = *reinterpret_cast<const uint4*>(src + (size_t)(s0 + sset) * set_stride + (size_t)k0 * D + wq * 4);
+    *reinterpret_cast<uint4*>(&lds[sset * PV_PITCH + wq * 4]) = v;
+  }
+  __syncthreads();
+  for (unsigned e = threadIdx.x; e < PV_SETS * D; e += 256) {
+    const unsigned sset = e % PV_SETS, j = e / PV_SETS;
+    union { int8_t b[16]; uint4 v; } outp[4];
+#pragma unroll
+    for (int b = 0; b < 16; b++) {
+      int8_t d[4];
+      signed_digits(lds[sset * PV_PITCH + b * D + j], planes, d);
+#pragma unroll
+      for (int i = 0; i < 4; i++) outp[i].b[b] = d[i];
+    }
+    for (int i = 0; i < planes; i++) {
+      const unsigned n = i * ns + s0 + sset, nt = n / 32, lane = (h << 5) | (n % 32);
+      const size_t t = ((size_t)j * kt_count + kt) * nt_count + nt;
+      *reinterpret_cast<uint4*>(dst + t * 1024 + lane * 16) = outp[i].v;
+    }
+  }
+}
+
+hipError_t launch_pack_vectors_i8(int ns, int8_t* dst, const uint32_t* src, size_t set_stride, size_t ktotal, size_t kt_count,
+                                  size_t nt_count, int planes, hipStream_t s) {
+  if (ns % PV_SETS || (set_stride % 4)) return hipErrorInvalidValue;
+  dim3 g((unsigned)kt_count, 2, (unsigned)(ns / PV_SETS));
+  hipLaunchKernelGGL(k_pack_vectors_i8, g, dim3(256), 0, s, dst, src, set_stride, (unsigned)ktotal, (unsigned)kt_count,
+                     (unsigned)nt_count, planes, (unsigned)ns);
+  return hipGetLastError();
+}
+
+// ---- the GEMM.  Block = 4 waves; wave w owns ONE row tile (32 rows) of one (slot j, plane i) and all NT column tiles:
+// NT accumulator tiles of 16 registers.  K is walked in stages of KS k-tiles.  A operands (KS KiB per wave and stage,
+// streamed once from HBM with non-temporal 16-byte loads) sit in a 3-deep register ring: two stages are in flight
+// behind the one being multiplied.  B operands (KS*NT KiB per block and stage, shared by the 4 waves) come from L2
+// through a double-buffered LDS stage.  Blocks are numbered so that all blocks of one slot j (every plane, every row
+// group: they walk the same B operand stream) run on ONE XCD at the same time: the first pulls a B tile from
+// HBM/MALL, the others hit that XCD's L2.
+constexpr int G8_KS = 4;
+
+template <int NT>
+__global__ void __launch_bounds__(256)
+k_gemm_i8(int32_t* __restrict__ Dout, const int8_t* __restrict__ M8, const int8_t* __restrict__ V8, unsigned planes,
+          unsigned rt_count, unsigned kt_count, unsigned blocks_per_j) {
+  __shared__ u32x4_t ldsB[2][G8_KS * NT * 64];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  // XCD x = blockIdx.x % 8 takes slots j = x, x+8, ...; within a slot: (plane i, row group)
+  const unsigned x = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const unsigned j = x + 8 * (seq / blocks_per_j), sub = seq % blocks_per_j;
+  const unsigned rgroups = blocks_per_j / planes;
+  const unsigned i = sub / rgroups, rt = (sub % rgroups) * 4 + w;
+  const unsigned ji = j * planes + i;
+  const bool live = rt < rt_count;                 // whole wave; dead waves still help with the B loads and barriers
+  const u32x4_t* A = reinterpret_cast<const u32x4_t*>(M8) + ((size_t)ji * rt_count + min(rt, rt_count - 1)) * kt_count * 64 + lane;
+  const u32x4_t* B = reinterpret_cast<const u32x4_t*>(V8) + (size_t)j * kt_count * NT * 64;
+  constexpr int BQ = G8_KS * NT * 64;              // B quads per stage
+  constexpr int BPT = BQ / 256;                    // per thread (= NT)
+  static_assert(BQ % 256 == 0, "a stage's B operands are a whole number of quads per thread");
+
+  i32x16_t acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; n++)
+#pragma unroll
+    for (int g = 0; g < 16; g++) acc[n][g] = 0;
+
+  const unsigned nstages = kt_count / G8_KS;       // kt_count is padded to a multiple of 3 * G8_KS
+  u32x4_t a0[G8_KS], a1[G8_KS], a2[G8_KS];
+  u32x4_t bNxt[BPT];
+  auto loadA = [&](unsigned st, u32x4_t (&dst)[G8_KS]) {
+#pragma unroll
+    for (int s = 0; s < G8_KS; s++)
+      dst[s] = __builtin_nontemporal_load(A + ((size_t)st * G8_KS + s) * 64);
+  };
+  auto loadB = [&](unsigned st) {
+#pragma unroll
+    for (int q = 0; q < BPT; q++) bNxt[q] = B[(size_t)st * BQ + t + q * 256];
+  };
+  auto parkB = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < BPT; q++) ldsB[buf][t + q * 256] = bNxt[q];
+  };
+  // one stage: multiply stage st (A operands in `cur`, B operands in LDS buffer st & 1) while stage st+1's B operands
+  // and stage st+2's A operands (into `nxt`, the ring slot stage st-1 used) are fetched
+  auto step = [&](unsigned st, u32x4_t (&cur)[G8_KS], u32x4_t (&nxt)[G8_KS]) {
+    const int buf = st & 1;
+    if (st + 1 < nstages) loadB(st + 1);           // issued before the A loads: waiting for it leaves those in flight
+    if (st + 2 < nstages) loadA(st + 2, nxt);
+#pragma unroll
+    for (int s = 0; s < G8_KS; s++) {
+      const i32x4_t af = {(int)cur[s].x, (int)cur[s].y, (int)cur[s].z, (int)cur[s].w};
+#pragma unroll
+      for (int n = 0; n < NT; n++) {
+        const u32x4_t bq = ldsB[buf][(s * NT + n) * 64 + lane];
+        const i32x4_t bf = {(int)bq.x, (int)bq.y, (int)bq.z, (int)bq.w};
+        acc[n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[n], 0, 0, 0);
+      }
+    }
+    if (st + 1 < nstages) parkB(buf ^ 1);
+    __syncthreads();
+  };
+  loadB(0);
+  loadA(0, a0);
+  if (nstages > 1) loadA(1, a1);
+  parkB(0);
+  __syncthreads();
+  for (unsigned st = 0; st < nstages; st += 3) {   // nstages is a multiple of 3 (kt_count is padded to 12 k-tiles)
+    step(st, a0, a2);
+    step(st + 1, a1, a0);
+    step(st + 2, a2, a1);
+  }
+  // D[ji][row][n]: lane holds column (lane & 31) of tile n, rows (g&3) + 8*(g>>2) + 4*(lane>>5)
+  if (live) {
+    constexpr unsigned ncols = NT * 32;
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+      for (int g = 0; g < 16; g++) {
+        const unsigned row = rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
+        Dout[((size_t)ji * rt_count * 32 + row) * ncols + n * 32 + (lane & 31)] = acc[n][g];
+      }
+  }
+}
+
+hipError_t launch_gemm_i8(int32_t* Dout, const int8_t* M8, const int8_t* V8, int planes, size_t rt_count, size_t kt_count,
+                          size_t nt, hipStream_t s) {
+  const unsigned blocks_per_j = (unsigned)(planes * ((rt_count + 3) / 4));
+  dim3 g((unsigned)(D * blocks_per_j));            // D = 64 slots = 8 per XCD
+  switch (nt) {
+    case 1: hipLaunchKernelGGL((k_gemm_i8<1>), g, dim3(256), 0, s, Dout, M8, V8, (unsigned)planes, (unsigned)rt_count, (unsigned)kt_count, blocks_per_j); break;
+    case 2: hipLaunchKernelGGL((k_gemm_i8<2>), g, dim3(256), 0, s, Dout, M8, V8, (unsigned)planes, (unsigned)rt_count, (unsigned)kt_count, blocks_per_j); break;
+    case 4: hipLaunchKernelGGL((k_gemm_i8<4>), g, dim3(256), 0, s, Dout, M8, V8, (unsigned)planes, (unsigned)rt_count, (unsigned)kt_count, blocks_per_j); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// ---- epilogue: out_s[rho][j] = sum_{i,i'} 256^(i+i') D[j][i][rho][i'*NS + s] mod p, one thread per (rho, s), j = blockIdx.y
+__global__ void __launch_bounds__(256)
+k_gemm_i8_epilogue(uint32_t* __restrict__ out, size_t out_set_stride, const int32_t* __restrict__ Dm, unsigned rows,
+                   unsigned rt_count, unsigned ns, unsigned ncols, int planes_m, int planes_v, uint32_t p) {
+  const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * ns) return;
+  const unsigned s = idx % ns, rho = idx / ns, j = blockIdx.y;
+  // powers of 256 mod p
+  uint32_t pw[8];
+  pw[0] = 1 % p;
+  for (int t = 1; t < 8; t++) pw[t] = (uint32_t)(((uint64_t)pw[t - 1] * 256) % p);
+  uint64_t acc = 0;
+  for (int i = 0; i < planes_m; i++)
+    for (int k = 0; k < planes_v; k++) {
+      const int32_t d = Dm[(((size_t)j * planes_m + i) * rt_count * 32 + rho) * ncols + k * ns + s];
+      const int64_t dm = (int64_t)d % (int64_t)p;                  // in (-p, p)
+      const uint32_t u = (uint32_t)(dm < 0 ? dm + p : dm);
+      acc += (uint64_t)u * pw[i + k];                               // < 16 * 2^60: no overflow
+    }
+  out[(size_t)s * out_set_stride + (size_t)rho * D + j] = (uint32_t)(acc % p);
+}
+
+hipError_t launch_gemm_i8_epilogue(uint32_t* out_plane, size_t out_set_stride, const int32_t* Dm, size_t rows, size_t rt_count,
+                                   size_t ns, size_t ncols, int planes_m, int planes_v, uint32_t p, hipStream_t s) {
+  dim3 g((unsigned)((rows * ns + 255) / 256), (unsigned)D);
+  hipLaunchKernelGGL(k_gemm_i8_epilogue, g, dim3(256), 0, s, out_plane, out_set_stride, Dm, (unsigned)rows, (unsigned)rt_count,
+                     (unsigned)ns, (unsigned)ncols, planes_m, planes_v, p);
+  return hipGetLastError();
+}
+
+}  // namespace lab

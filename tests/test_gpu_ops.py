@@ -324,3 +324,56 @@ def test_axpy_commit_batched_all_kernels(nb, nterms, length, compact):
             want = co.poly_add(q, want, co.polymul(q, G[b, m], Cm[m, rho]))
         assert np.array_equal(got[b, rho], want)
     ctx.close()
+
+
+@pytest.mark.parametrize("ns", [8, 16, 32])
+@pytest.mark.parametrize("nmat,rows,cols", [(3, 40, 37), (2, 64, 64), (1, 100, 200), (5, 31, 7)])
+@pytest.mark.parametrize("compact", [False, True])
+def test_matvec_sum_mfma_digit_basis(ns, nmat, rows, cols, compact):
+    # the batched outer commitment as exact int8 GEMMs on the matrix cores (signed base-256 digit planes, int32
+    # accumulation, recombination mod each limb prime): bit-identical to lab_matvec_sum set by set, and to the oracle
+    # on sample rows; ragged rows / k (padding to 32-row and 128-k tiles), u32 and u16 source limbs (4 and 2 planes)
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    q = Q_REF33
+    ctx = lab.Context(q, 0)
+    bound = 1625
+    ctx.enable_digit_basis(5000, bound)
+    rng = np.random.default_rng(ns + rows)
+    M = rp(rng, q, nmat, rows, cols)
+    V = rng.integers(0, bound, size=(ns, nmat, cols, D), dtype=np.uint64)
+    hM = ctx.vec(nmat * rows * cols, digit=True, compact=compact).load(M)
+    hV = ctx.vec(ns * nmat * cols, digit=True).load(V)
+    M8 = lab.Mat8(ctx, hM, nmat, rows, cols)
+    assert M8.nbytes > 0
+    got = lab.matvec_sum_mfma(ctx, M8, hV, ns).store().reshape(ns, rows, D)
+    for b in range(ns):
+        one = lab.matvec_sum(ctx, hM, hV, nmat, rows, cols, v_off=b * nmat * cols).store()
+        assert np.array_equal(got[b], one), (b,)
+    for b, r_ in ((0, 0), (ns - 1, rows - 1)):
+        want = np.zeros(D, np.uint64)
+        for m in range(nmat):
+            want = co.poly_add(q, want, co.inner_product(q, M[m, r_], V[b, m]))
+        assert np.array_equal(got[b, r_], want)
+    M8.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("q", ALL_Q)
+def test_matvec_sum_mfma_main_basis_full_residues(contexts, q):
+    # operands in the context's main basis with full-range residues (every byte value, -128 included, occurs in the
+    # digit planes of both operands)
+    import labrador_snark_amd as lab
+    ctx = contexts(q)
+    rng = np.random.default_rng(5)
+    ns, nmat, rows, cols = 8, 2, 70, 150
+    M = rp(rng, q, nmat, rows, cols)
+    V = rp(rng, q, ns, nmat, cols)
+    M[0, :3] = q - 1
+    V[1] = q - 1
+    hM, hV = ctx.vec_from(M), ctx.vec_from(V)
+    M8 = lab.Mat8(ctx, hM, nmat, rows, cols)
+    got = lab.matvec_sum_mfma(ctx, M8, hV, ns).store().reshape(ns, rows, D)
+    for b in range(ns):
+        assert np.array_equal(got[b], lab.matvec_sum(ctx, hM, hV, nmat, rows, cols, v_off=b * nmat * cols).store())
+    M8.close()
