@@ -119,6 +119,10 @@ def main():
     ap.add_argument("--batch", type=int, default=8,
                     help="independent proofs per step and GPU; they share the common reference string, which is then "
                          "streamed from HBM once per batch (1 = one proof per call)")
+    ap.add_argument("--step3", choices=["auto", "valu", "mfma"], default="auto",
+                    help="outer commitment sum_ik B_ik t_i^(k): 64-bit multiply-add kernels (B as RNS residues) or exact "
+                         "int8 GEMMs on the matrix cores (B packed as signed byte planes, up to 32 proofs per pass over B); "
+                         "auto = mfma when --batch > 8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-compact-crs", action="store_true", help="keep B, C, D in the main RNS basis (12 B/coefficient at the 33-bit q)")
@@ -172,6 +176,9 @@ def main():
                            alpha=dev64(tape["alpha"]), beta=dev64(tape["beta"]), c=dev64(tape["c"])))
     # B, C, D are only ever multiplied by decomposition digits: keep them in the digit basis (u16 small limb)
     crs = lab.ResidentCRS(ctx, k, compact=not args.no_compact_crs).fill_synthetic(1000 + 10 * rank)
+    use_mfma = args.step3 == "mfma" or (args.step3 == "auto" and nbatch > 8)
+    if use_mfma:
+        crs.pack_mfma(drop_B=True)     # one-time, like the CRS expansion: outside every timed region
     torch.cuda.synchronize()
 
     def step():
@@ -218,7 +225,8 @@ def main():
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
-                if rec.get("workload_key") == [q, n, r, kappa, ctx.nlimbs, bool(crs.compact), nbatch]:
+                if rec.get("workload_key") == [q, n, r, kappa, ctx.nlimbs, bool(crs.compact), nbatch] and \
+                        rec.get("step3", "valu") == ("mfma" if use_mfma else "valu"):
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -233,14 +241,20 @@ def main():
                                    % (n, r, kappa, q, ctx.nlimbs, nbatch),
                        "q": q, "n": n, "r": r, "kappa": kappa, "t1": k.T_1, "t2": k.T_2, "b1": k.B_1, "b2": k.B_2,
                        "nlimbs": ctx.nlimbs, "crs_basis": ("digit basis %s, u16 last limb" % getattr(ctx, "digit_primes", None))
-                       if crs.compact else "main basis", "proofs_per_step_per_gpu": nbatch, "parallelism": "%d independent proofs per gpu x %d gpus" % (nbatch, world)},
+                       if crs.compact else "main basis", "proofs_per_step_per_gpu": nbatch,
+                       "step3": "int8 MFMA GEMMs (signed base-256 digit planes, int32 accumulation, exact)" if use_mfma
+                       else "64-bit multiply-add kernels", "parallelism": "%d independent proofs per gpu x %d gpus" % (nbatch, world)},
             "ms_per_proof": elapsed / (args.steps * nbatch) * 1e3,
             "proofs_per_s": value, "witness_Rq_elems_per_s": value * n * r,
             "ring_products_per_proof": sum(counts.values()),
             "checksum_u1_u2": int(chk.item()),
-            "roofline": {"bound": "hbm", "kernel": "lab::%s — the u32 limbs of the outer commitment sum_ik B_ik t_i^(k) "
-                                                   "(src/proofgen.rs:101-132) for the %d proofs of a step; the u16 limb runs as a "
-                                                   "second launch of the same kernel template" % (step3_kernel, nbatch),
+            "roofline": {"bound": "hbm", "kernel": ("lab::%s — one 30-bit limb (4 digit planes) of the outer commitment "
+                                                    "sum_ik B_ik t_i^(k) (src/proofgen.rs:101-132) for the %d proofs of a step, "
+                                                    "one launch per limb; the 257 limb (2 planes) is a smaller launch of the "
+                                                    "same template" if use_mfma else
+                                                    "lab::%s — the u32 limbs of the outer commitment sum_ik B_ik t_i^(k) "
+                                                    "(src/proofgen.rs:101-132) for the %d proofs of a step; the u16 limb runs as a "
+                                                    "second launch of the same kernel template") % (step3_kernel, nbatch),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "launches": launches, "avg_launch_ms": per_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1),

@@ -73,6 +73,7 @@ typedef enum {
 
 typedef struct lab_ctx lab_ctx;
 typedef struct lab_vec lab_vec;
+typedef struct lab_mat8 lab_mat8;   /* matrices packed for the matrix cores (lab_mat8_pack) */
 
 typedef struct {
   uint64_t q;
@@ -201,7 +202,6 @@ int lab_gram(lab_ctx *ctx, lab_vec *out, size_t out_off, const lab_vec *P, size_
  *   out[out_off + s*rows + rho] = sum_{m,c} M[m][rho][c] * V_s[m*cols + c]
  * as exact int8 GEMMs (v_mfma_i32_32x32x32_i8, int32 accumulation: nmat*cols must stay below 2^17) followed by a
  * recombination mod each limb prime.  Bit-identical to lab_matvec_sum. */
-typedef struct lab_mat8 lab_mat8;
 int lab_mat8_pack(lab_ctx *ctx, const lab_vec *M, size_t m_off, size_t nmat, size_t rows, size_t cols, lab_mat8 **out);
 int lab_mat8_destroy(lab_mat8 *m);
 size_t lab_mat8_bytes(const lab_mat8 *m);
@@ -272,6 +272,9 @@ typedef struct {
   const uint64_t *alpha;   /* [64]  fetch_alpha, K = 1     (src/verification.rs:441-447) */
   const uint64_t *beta;    /* [64]  fetch_beta             (src/verification.rs:449-456) */
   const uint64_t *c;       /* [r][64] fetch_challenge      (src/verification.rs:460-489) */
+  const struct lab_mat8 *B8; /* optional: the B matrices packed for the matrix cores (lab_mat8_pack(B, b_off, r*t1, kappa1,
+                              * kappa)); when set, step 3 of lab_prove_core[_batch] runs as int8 GEMMs over up to 32 proofs
+                              * per pass and B itself may be NULL (lab_verify_core still needs B) */
 } lab_prove_input;
 
 /* The computed fields of `Transcript` (src/structs.rs:192-209); pi_i_all, psi, omega, alpha, beta, c are the tape.

@@ -94,12 +94,12 @@ hipError_t launch_matmul_t(HatView out, ConstHatView A, ConstHatView S, size_t r
 // ---- mfma_kernels.hip: exact int8 GEMM formulation of the batched outer commitment
 hipError_t launch_pack_matrix_i8(int8_t* dst, const void* src, bool src_u16, size_t nmat, size_t rows, size_t cols,
                                  size_t rt_count, size_t kt_count, int planes, hipStream_t s);
-hipError_t launch_pack_vectors_i8(int ns, int8_t* dst, const uint32_t* src, size_t set_stride, size_t ktotal, size_t kt_count,
-                                  size_t nt_count, int planes, hipStream_t s);
+hipError_t launch_pack_vectors_i8(int ns, int ns_valid, int8_t* dst, const uint32_t* src, size_t set_stride, size_t ktotal,
+                                  size_t kt_count, size_t nt_count, int planes, hipStream_t s);
 hipError_t launch_gemm_i8(int32_t* Dout, const int8_t* M8, const int8_t* V8, int planes, size_t rt_count, size_t kt_count,
                           size_t nt, hipStream_t s);
 hipError_t launch_gemm_i8_epilogue(uint32_t* out_plane, size_t out_set_stride, const int32_t* Dm, size_t rows, size_t rt_count,
-                                   size_t ns, size_t ncols, int planes_m, int planes_v, uint32_t p, hipStream_t s);
+                                   size_t ns, size_t ns_valid, size_t ncols, int planes_m, int planes_v, uint32_t p, hipStream_t s);
 // out[i*r + k] = sum_x P[x*r+i] * S[x*r+k]
 hipError_t launch_gram(HatView out, ConstHatView P, ConstHatView S, size_t n, size_t r, int nlimbs,
                        const LimbTable* tabs, hipStream_t s);

@@ -37,10 +37,11 @@ size_t mfma_scratch_bytes(const lab_mat8* m, int ns) {
   return Carver::padded(v8) + Carver::padded(dm);
 }
 
-// out_s[rho] (s < ns, hat elements at out.base + s*out_set_stride) = sum_k M[rho][k] V_s[k], V_s at V.base + s*v_set_stride;
-// `scratch` holds mfma_scratch_bytes(m, ns)
+// out_s[rho] (s < ns_valid, hat elements at out.base + s*out_set_stride) = sum_k M[rho][k] V_s[k], V_s at V.base + s*v_set_stride;
+// ns in {8,16,32} is the padded set count the GEMM runs with; `scratch` holds mfma_scratch_bytes(m, ns).
+// When the measurement hook is on, the GEMM launches of the 4-plane (u32) limbs are bracketed by events.
 int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_mat8* m, ConstHatView V, size_t v_set_stride, int ns,
-                     void* scratch) {
+                     int ns_valid, void* scratch) {
   const uint32_t* primes = m->basis ? c->dg_primes : c->primes;
   const size_t ktotal = m->nmat * m->cols;
   Carver cv(scratch);
@@ -56,9 +57,25 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
     const int pl = m->planes[l];
     size_t nt = nt_for(ns, pl);
     if (nt == 3) nt = 4;                       // the GEMM is instantiated for 1, 2, 4 column tiles
-    LAB_HIP(c, launch_pack_vectors_i8(ns, v8, V.base + (size_t)l * V.plane_stride, v_set_stride, ktotal, m->kt_count, nt, pl, c->stream));
+    LAB_HIP(c, launch_pack_vectors_i8(ns, ns_valid, v8, V.base + (size_t)l * V.plane_stride, v_set_stride, ktotal, m->kt_count, nt, pl,
+                                      c->stream));
+    const bool prof = c->prof_on && pl == 4;
+    if (prof && c->prof_used == c->prof_events.size()) {
+      hipEvent_t a, b;
+      LAB_HIP(c, hipEventCreate(&a));
+      LAB_HIP(c, hipEventCreate(&b));
+      c->prof_events.emplace_back(a, b);
+    }
+    if (prof) LAB_HIP(c, hipEventRecord(c->prof_events[c->prof_used].first, c->stream));
     LAB_HIP(c, launch_gemm_i8(dm, m->d[l], v8, pl, m->rt_count, m->kt_count, nt, c->stream));
-    LAB_HIP(c, launch_gemm_i8_epilogue(out.base + (size_t)l * out.plane_stride, out_set_stride, dm, m->rows, m->rt_count, ns,
+    if (prof) {
+      LAB_HIP(c, hipEventRecord(c->prof_events[c->prof_used++].second, c->stream));
+      c->prof_kernel = nt == 4 ? "k_gemm_i8<4>" : nt == 2 ? "k_gemm_i8<2>" : "k_gemm_i8<1>";
+      // matrix digit planes once, the B-operand tiles once per 128-row block group (from L2), the int32 results
+      c->prof_bytes += (double)D * pl * m->rt_count * m->kt_count * 1024 + (double)D * m->kt_count * nt * 1024 +
+                       (double)D * pl * m->rt_count * 32 * nt * 32 * 4;
+    }
+    LAB_HIP(c, launch_gemm_i8_epilogue(out.base + (size_t)l * out.plane_stride, out_set_stride, dm, m->rows, m->rt_count, ns, ns_valid,
                                        nt * 32, pl, pl, primes[l], c->stream));
   }
   return LAB_OK;
@@ -120,6 +137,13 @@ extern "C" int lab_mat8_destroy(lab_mat8* m) {
 
 extern "C" size_t lab_mat8_bytes(const lab_mat8* m) { return m ? m->bytes : 0; }
 
+namespace lab {
+bool mat8_matches(const lab_mat8* m, int basis, size_t nmat, size_t rows, size_t cols) {
+  return m && m->basis == basis && m->nmat == nmat && m->rows == rows && m->cols == cols;
+}
+int mat8_basis(const lab_mat8* m) { return m->basis; }
+}  // namespace lab
+
 extern "C" int lab_matvec_sum_mfma(lab_ctx* c, lab_vec* out, size_t out_off, const lab_mat8* m, const lab_vec* V, size_t v_off, int ns) {
   if (!c || !m) return LAB_ERR_ARG;
   if (ns != 8 && ns != 16 && ns != 32) return fail(c, LAB_ERR_ARG, "lab_matvec_sum_mfma: ns must be 8, 16 or 32");
@@ -130,5 +154,5 @@ extern "C" int lab_matvec_sum_mfma(lab_ctx* c, lab_vec* out, size_t out_off, con
     return fail(c, LAB_ERR_ARG, "lab_matvec_sum_mfma: V and out must be plain vectors in the packed matrix's basis");
   LAB_HIP(c, hipSetDevice(c->device));
   if ((rc = ensure_scratch(c, mfma_scratch_bytes(m, ns)))) return rc;
-  return matvec_mfma_impl(c, out->view(out_off), m->rows * D, m, V->view(v_off), m->nmat * m->cols * D, ns, c->scratch);
+  return matvec_mfma_impl(c, out->view(out_off), m->rows * D, m, V->view(v_off), m->nmat * m->cols * D, ns, ns, c->scratch);
 }

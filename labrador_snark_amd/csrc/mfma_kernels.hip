@@ -90,14 +90,15 @@ constexpr int PV_PITCH = 16 * D + 4;     // words per set in LDS (16-byte aligne
 
 __global__ void __launch_bounds__(256)
 k_pack_vectors_i8(int8_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t set_stride, unsigned ktotal,
-                  unsigned kt_count, unsigned nt_count, int planes, unsigned ns) {
+                  unsigned kt_count, unsigned nt_count, int planes, unsigned ns, unsigned ns_valid) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[PV_SETS * PV_PITCH];
   const unsigned kt = blockIdx.x, h = blockIdx.y, s0 = blockIdx.z * PV_SETS;
   const unsigned k0 = kt * 32 + 16 * h;
   for (unsigned e = threadIdx.x; e < PV_SETS * 16 * D / 4; e += 256) {       // quads
     const unsigned sset = e / (16 * D / 4), wq = e % (16 * D / 4), k = k0 + wq / (D / 4);
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (k < ktotal) v = *reinterpret_cast<const uint4*>(src + (size_t)(s0 + sset) * set_stride + (size_t)k0 * D + wq * 4);
+    if (k < ktotal && s0 + sset < ns_valid)   // sets past ns_valid are padding: zero columns, never read
+      v = *reinterpret_cast<const uint4*>(src + (size_t)(s0 + sset) * set_stride + (size_t)k0 * D + wq * 4);
     *reinterpret_cast<uint4*>(&lds[sset * PV_PITCH + wq * 4]) = v;
   }
   __syncthreads();
@@ -119,12 +120,12 @@ k_pack_vectors_i8(int8_t* __restrict__ dst, const uint32_t* __restrict__ src, si
   }
 }
 
-hipError_t launch_pack_vectors_i8(int ns, int8_t* dst, const uint32_t* src, size_t set_stride, size_t ktotal, size_t kt_count,
-                                  size_t nt_count, int planes, hipStream_t s) {
+hipError_t launch_pack_vectors_i8(int ns, int ns_valid, int8_t* dst, const uint32_t* src, size_t set_stride, size_t ktotal,
+                                  size_t kt_count, size_t nt_count, int planes, hipStream_t s) {
   if (ns % PV_SETS || (set_stride % 4)) return hipErrorInvalidValue;
   dim3 g((unsigned)kt_count, 2, (unsigned)(ns / PV_SETS));
   hipLaunchKernelGGL(k_pack_vectors_i8, g, dim3(256), 0, s, dst, src, set_stride, (unsigned)ktotal, (unsigned)kt_count,
-                     (unsigned)nt_count, planes, (unsigned)ns);
+                     (unsigned)nt_count, planes, (unsigned)ns, (unsigned)ns_valid);
   return hipGetLastError();
 }
 
@@ -236,10 +237,11 @@ hipError_t launch_gemm_i8(int32_t* Dout, const int8_t* M8, const int8_t* V8, int
 // ---- epilogue: out_s[rho][j] = sum_{i,i'} 256^(i+i') D[j][i][rho][i'*NS + s] mod p, one thread per (rho, s), j = blockIdx.y
 __global__ void __launch_bounds__(256)
 k_gemm_i8_epilogue(uint32_t* __restrict__ out, size_t out_set_stride, const int32_t* __restrict__ Dm, unsigned rows,
-                   unsigned rt_count, unsigned ns, unsigned ncols, int planes_m, int planes_v, uint32_t p) {
+                   unsigned rt_count, unsigned ns, unsigned ns_valid, unsigned ncols, int planes_m, int planes_v, uint32_t p) {
   const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * ns) return;
   const unsigned s = idx % ns, rho = idx / ns, j = blockIdx.y;
+  if (s >= ns_valid) return;
   // powers of 256 mod p
   uint32_t pw[8];
   pw[0] = 1 % p;
@@ -256,10 +258,10 @@ k_gemm_i8_epilogue(uint32_t* __restrict__ out, size_t out_set_stride, const int3
 }
 
 hipError_t launch_gemm_i8_epilogue(uint32_t* out_plane, size_t out_set_stride, const int32_t* Dm, size_t rows, size_t rt_count,
-                                   size_t ns, size_t ncols, int planes_m, int planes_v, uint32_t p, hipStream_t s) {
+                                   size_t ns, size_t ns_valid, size_t ncols, int planes_m, int planes_v, uint32_t p, hipStream_t s) {
   dim3 g((unsigned)((rows * ns + 255) / 256), (unsigned)D);
   hipLaunchKernelGGL(k_gemm_i8_epilogue, g, dim3(256), 0, s, out_plane, out_set_stride, Dm, (unsigned)rows, (unsigned)rt_count,
-                     (unsigned)ns, (unsigned)ncols, planes_m, planes_v, p);
+                     (unsigned)ns, (unsigned)ns_valid, (unsigned)ncols, planes_m, planes_v, p);
   return hipGetLastError();
 }
 

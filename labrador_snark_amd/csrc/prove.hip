@@ -80,7 +80,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     if (!x->S || !x->phi || !x->a || !x->Pi || !x->omega || !x->alpha || !x->beta || !x->c)
       return fail(c, LAB_ERR_ARG, "lab_prove_core: null input array");
     if (x->n != n || x->r != r || x->kappa != kappa || x->kappa1 != k1 || x->kappa2 != k2 || x->t1 != t1 || x->t2 != t2 ||
-        x->b1 != in->b1 || x->b2 != in->b2 || x->beta_bound != in->beta_bound || x->A != in->A || x->B != in->B ||
+        x->b1 != in->b1 || x->b2 != in->b2 || x->beta_bound != in->beta_bound || x->A != in->A || x->B != in->B || x->B8 != in->B8 ||
         x->C != in->C || x->Dm != in->Dm || x->a_off != in->a_off || x->b_off != in->b_off || x->c_off != in->c_off ||
         x->d_off != in->d_off)
       return fail(c, LAB_ERR_ARG, "lab_prove_core_batch: all proofs of a batch must share dimensions, constants and the CRS");
@@ -89,12 +89,17 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   const size_t nr = n * r, rk = r * kappa, rr = r * r;
   int rc;
   if ((rc = check_range(c, in->A, in->a_off, kappa * n, "lab_prove_core(A)"))) return rc;
-  if ((rc = check_range(c, in->B, in->b_off, r * (size_t)t1 * k1 * kappa, "lab_prove_core(B)"))) return rc;
+  // step 3 runs on the matrix cores when the B matrices were packed for them (lab_mat8_pack); B itself may then be absent
+  const lab_mat8* b8 = in->B8;
+  if (!b8 && !in->B) return fail(c, LAB_ERR_ARG, "lab_prove_core: neither B nor B8 given");
+  if (in->B && (rc = check_range(c, in->B, in->b_off, r * (size_t)t1 * k1 * kappa, "lab_prove_core(B)"))) return rc;
   if ((rc = check_range(c, in->C, in->c_off, pairs * (size_t)t2 * k2, "lab_prove_core(C)"))) return rc;
   if ((rc = check_range(c, in->Dm, in->d_off, pairs * (size_t)t1 * k2, "lab_prove_core(D)"))) return rc;
   // B, C, D may live in the context's digit basis (lab_ctx_enable_digit_basis): steps 3, 4, 9 then run in it
-  const int bdig = in->B->basis;
-  if (in->C->basis != bdig || in->Dm->basis != bdig) return fail(c, LAB_ERR_ARG, "lab_prove_core: B, C, D must share one RNS basis");
+  const int bdig = in->C->basis;
+  if ((in->B && in->B->basis != bdig) || in->Dm->basis != bdig) return fail(c, LAB_ERR_ARG, "lab_prove_core: B, C, D must share one RNS basis");
+  if (b8 && !mat8_matches(b8, bdig, r * (size_t)t1, k1, kappa))
+    return fail(c, LAB_ERR_ARG, "lab_prove_core: B8 was not packed from r*t1 matrices of kappa1 x kappa elements in the basis of C, D");
   if (in->A->basis != 0 || in->A->compact) return fail(c, LAB_ERR_ARG, "lab_prove_core: A must be a main-basis vector");
   // exactness of every transform-domain reduction (see header comment)
   const u128 qm1 = c->q - 1;
@@ -150,8 +155,13 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
              Staging::need(x->Pi, r * 256 * n * D) + Staging::need(x->omega, 256 * 8) + Staging::need(x->alpha, D * 8) +
              Staging::need(x->beta, D * 8) + Staging::need(x->c, r * D * 8);
   }
+  // int8-MFMA step 3: padded set count of the largest group and its scratch (B-operand tiles + int32 results)
+  const int mf_ns = np > 16 ? 32 : np > 8 ? 16 : 8;
+  const size_t mf_bytes = b8 ? mfma_scratch_bytes(b8, mf_ns) + 4096 : 0;
+  bytes += mf_bytes;
   if ((rc = ensure_scratch(c, bytes + (1 << 16)))) return rc;
   Carver cv(c->scratch);
+  char* mf_scratch = b8 ? cv.take<char>(mf_bytes) : nullptr;
   uint32_t* hat_base = cv.take<uint32_t>((size_t)L * hat_words);
   uint32_t* hatd_base = cv.take<uint32_t>((size_t)Ld * hatd_words);
   // from_hat scratch: a dense [L][count][64] buffer (its plane stride is count*64, not the arena's)
@@ -220,7 +230,13 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   }
 
   // ================= step 3 (:101-132) for the whole batch: lhs_j = sum_{i,k} B_ik t_{j,i}^(k); B streamed once per group
-  for (size_t j0 = 0; j0 < np;) {
+  for (size_t j0 = 0; b8 && j0 < np;) {   // matrix cores: up to 32 proofs per pass over B, result written in place
+    const size_t left = np - j0;
+    const int ns = left > 16 ? 32 : left > 8 ? 16 : 8, valid = (int)(left < (size_t)ns ? left : (size_t)ns);
+    if ((rc = matvec_mfma_impl(c, HD(j0, hlhs), perd * D, b8, HD(j0, hTdec), perd * D, ns, valid, mf_scratch))) return rc;
+    j0 += valid;
+  }
+  for (size_t j0 = 0; !b8 && j0 < np;) {
     int g = 1;
     while (g < 8 && j0 + 2 * (size_t)g <= np) g *= 2;
     if (g == 1) {

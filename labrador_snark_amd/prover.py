@@ -82,9 +82,23 @@ class ResidentCRS:
         self.A.load(A); self.B.load(B); self.C.load(Cm); self.Dm.load(Dm)
         return self
 
+    def pack_mfma(self, drop_B=False):
+        """Re-stores the B matrices for the matrix cores (lab_mat8_pack): step 3 of prove_core[_batch] then runs as exact
+        int8 GEMMs over up to 32 proofs per pass over B.  drop_B=True frees the original B (the verifier and
+        single-proof VALU path need it; a prover-only service does not)."""
+        from .api import Mat8
+        k = self.constants
+        self.B8 = Mat8(self.ctx, self.B, k.R * k.T_1, k.KAPPA_1, k.KAPPA)
+        if drop_B:
+            self.ctx.synchronize()
+            self.B.close()
+            self.B = None
+        return self
+
     def close(self):
-        for v in (self.A, self.B, self.C, self.Dm):
-            v.close()
+        for v in (self.A, self.B, self.C, self.Dm, getattr(self, "B8", None)):
+            if v is not None:
+                v.close()
 
 
 class CRS:
@@ -210,7 +224,8 @@ def _prove_io(ctx, k, witness, st, crs, tape, device_outputs):
 
     pin.S, pin.phi, pin.a = p64(witness), p64(st.phi), p64(st.a)
     pin.b_prime = st.b_prime
-    pin.A, pin.B, pin.C, pin.Dm = crs.A._h, crs.B._h, crs.C._h, crs.Dm._h
+    pin.A, pin.B, pin.C, pin.Dm = crs.A._h, (crs.B._h if crs.B is not None else None), crs.C._h, crs.Dm._h
+    pin.B8 = crs.B8._h if getattr(crs, "B8", None) is not None else None
     pin.a_off = pin.b_off = pin.c_off = pin.d_off = 0
     Pi = tape["Pi"]
     if isinstance(Pi, np.ndarray):
@@ -283,7 +298,8 @@ def verify_core(ctx, k, st, b_poly, crs, T, tape=None):
     pin.S = None
     pin.phi, pin.a = p64(st.phi), p64(st.a)
     pin.b_prime = st.b_prime
-    pin.A, pin.B, pin.C, pin.Dm = crs.A._h, crs.B._h, crs.C._h, crs.Dm._h
+    pin.A, pin.B, pin.C, pin.Dm = crs.A._h, (crs.B._h if crs.B is not None else None), crs.C._h, crs.Dm._h
+    pin.B8 = crs.B8._h if getattr(crs, "B8", None) is not None else None
     pin.a_off = pin.b_off = pin.c_off = pin.d_off = 0
     Pi = tape["Pi"]
     if isinstance(Pi, np.ndarray):

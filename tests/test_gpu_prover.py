@@ -208,3 +208,33 @@ def test_prove_core_batch_equals_separate_proofs(nb, kappa1, compact):
     assert np.array_equal(Ts2[0].u_1, Ts[0].u_1)
     crs.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("nb,kappa1", [(1, 20), (5, 20), (9, 64), (20, 40), (33, 20)])
+@pytest.mark.parametrize("compact", [False, True])
+def test_prove_core_batch_on_matrix_cores(nb, kappa1, compact):
+    # step 3 as exact int8 GEMMs (B packed with lab_mat8_pack, up to 32 proofs per pass, groups padded to 8/16/32
+    # sets): transcripts bit-identical to the VALU path and the oracle; B itself can be dropped afterwards
+    import labrador_snark_amd as lab
+    q, n, r, kappa = Q_REF33, 4, 8, 64
+    ctx = lab.Context(q, 0)
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
+    crs = lab.ResidentCRS(ctx, k, compact=compact).fill_synthetic(1000)
+    ws, sts, tapes = [], [], []
+    want0 = None
+    for j in range(nb):
+        case, (S, phi, a, tape) = cases.oracle_case(p, seed=300 + j)
+        ws.append(S); sts.append(lab.State(phi, a, case.b_prime)); tapes.append(tape)
+        if j == 0:
+            want0 = case.prove()
+    ref = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes)
+    crs.pack_mfma(drop_B=True)
+    assert crs.B is None and crs.B8.nbytes > 0
+    got = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes)
+    for j in range(nb):
+        for f in ("t_i_all", "g_mat", "h_mat", "u_1", "u_2", "z", "b_prime_prime", "projection_int", "projection"):
+            assert np.array_equal(getattr(got[j], f), getattr(ref[j], f)), (j, f)
+    assert np.array_equal(got[0].u_1, want0["u1"]) and np.array_equal(got[0].u_2, want0["u2"])
+    crs.close()
+    ctx.close()
