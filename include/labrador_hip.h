@@ -275,6 +275,7 @@ typedef struct {
   const struct lab_mat8 *B8; /* optional: the B matrices packed for the matrix cores (lab_mat8_pack(B, b_off, r*t1, kappa1,
                               * kappa)); when set, step 3 of lab_prove_core[_batch] runs as int8 GEMMs over up to 32 proofs
                               * per pass and B itself may be NULL (lab_verify_core still needs B) */
+  const struct lab_mat8 *A8; /* optional: lab_mat8_pack(A, a_off, 1, kappa, n): step 1 (t_i = A s_i) as int8 GEMMs */
 } lab_prove_input;
 
 /* The computed fields of `Transcript` (src/structs.rs:192-209); pi_i_all, psi, omega, alpha, beta, c are the tape.

@@ -94,12 +94,19 @@ hipError_t launch_matmul_t(HatView out, ConstHatView A, ConstHatView S, size_t r
 // ---- mfma_kernels.hip: exact int8 GEMM formulation of the batched outer commitment
 hipError_t launch_pack_matrix_i8(int8_t* dst, const void* src, bool src_u16, size_t nmat, size_t rows, size_t cols,
                                  size_t rt_count, size_t kt_count, int planes, hipStream_t s);
-hipError_t launch_pack_vectors_i8(int ns, int ns_valid, int8_t* dst, const uint32_t* src, size_t set_stride, size_t ktotal,
-                                  size_t kt_count, size_t nt_count, int planes, hipStream_t s);
-hipError_t launch_gemm_i8(int32_t* Dout, const int8_t* M8, const int8_t* V8, int planes, size_t rt_count, size_t kt_count,
-                          size_t nt, hipStream_t s);
-hipError_t launch_gemm_i8_epilogue(uint32_t* out_plane, size_t out_set_stride, const int32_t* Dm, size_t rows, size_t rt_count,
-                                   size_t ns, size_t ns_valid, size_t ncols, int planes_m, int planes_v, uint32_t p, hipStream_t s);
+hipError_t launch_pack_vectors_i8(int ns, int ns_valid, int8_t* dst, const uint32_t* src, size_t set_stride, size_t k_stride,
+                                  size_t ktotal, size_t kt_count, size_t nt_count, int planes, size_t njobs, size_t src_job_stride,
+                                  size_t dst_job_stride, hipStream_t s);
+struct Gemm8Args {
+  uint32_t* out;             // this limb's plane: out + job*out_job_stride + s*out_set_stride + row*64 + j
+  size_t out_set_stride, out_job_stride;
+  const int8_t* M8;
+  const int8_t* V8;          // + job*v8_job_stride (bytes)
+  size_t v8_job_stride;
+  unsigned planes, rt_count, kt_count, rgroups /* row groups per slot */, njobs, rows, ns, ns_valid;
+  uint32_t p;
+};
+hipError_t launch_gemm_i8(const Gemm8Args& a, size_t nt, hipStream_t s);
 // out[i*r + k] = sum_x P[x*r+i] * S[x*r+k]
 hipError_t launch_gram(HatView out, ConstHatView P, ConstHatView S, size_t n, size_t r, int nlimbs,
                        const LimbTable* tabs, hipStream_t s);

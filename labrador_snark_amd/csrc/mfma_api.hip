@@ -20,46 +20,48 @@ namespace lab {
 int mfma_planes(uint32_t p) {   // digits d_i in [-128,127] (the last one unrestricted within i8) covering [0, p)
   int bits = 0;
   while (bits < 32 && ((uint64_t)1 << bits) < p) bits++;   // p - 1 < 2^bits
-  return (bits + 1 + 7) / 8;
+  const int pl = (bits + 1 + 7) / 8;
+  return pl == 3 ? 4 : pl;                                  // the GEMM block holds 4 / planes row tiles
 }
 
 // column tiles for ns sets whose residues need `planes_v` digit planes
-static size_t nt_for(int ns, int planes_v) { return ((size_t)ns * planes_v + 31) / 32; }
-
-size_t mfma_scratch_bytes(const lab_mat8* m, int ns) {
-  size_t v8 = 0, dm = 0;
-  for (int l = 0; l < m->nlimbs; l++) {
-    size_t nt = nt_for(ns, m->planes[l]);
-    if (nt == 3) nt = 4;
-    v8 = std::max(v8, (size_t)D * m->kt_count * nt * 1024);
-    dm = std::max(dm, (size_t)D * m->planes[l] * m->rt_count * 32 * nt * 32 * 4);
-  }
-  return Carver::padded(v8) + Carver::padded(dm);
+static size_t nt_for(int ns, int planes_v) {
+  const size_t nt = ((size_t)ns * planes_v + 31) / 32;
+  return nt == 3 ? 4 : nt;                                  // the GEMM is instantiated for 1, 2, 4 column tiles
 }
 
-// out_s[rho] (s < ns_valid, hat elements at out.base + s*out_set_stride) = sum_k M[rho][k] V_s[k], V_s at V.base + s*v_set_stride;
-// ns in {8,16,32} is the padded set count the GEMM runs with; `scratch` holds mfma_scratch_bytes(m, ns).
-// When the measurement hook is on, the GEMM launches of the 4-plane (u32) limbs are bracketed by events.
+static size_t v8_job_bytes(const lab_mat8* m, int ns) {
+  size_t v8 = 0;
+  for (int l = 0; l < m->nlimbs; l++) v8 = std::max(v8, (size_t)D * m->kt_count * nt_for(ns, m->planes[l]) * 1024);
+  return Carver::padded(v8);
+}
+
+size_t mfma_scratch_bytes(const lab_mat8* m, int ns, size_t njobs) { return v8_job_bytes(m, ns) * njobs; }
+
+// For every job b < njobs: out_s[rho] (s < ns_valid; hat elements at out.base + b*out_job_stride + s*out_set_stride)
+//   = sum_k M[rho][k] V_s[k],  V_s[k] at V.base + b*v_job_stride + s*v_set_stride + k*v_k_stride
+// (v_k_stride = 64 words for vectors stored set by set).  ns in {8,16,32} is the padded set count the GEMM runs with;
+// `scratch` holds mfma_scratch_bytes(m, ns, njobs).  One pack + one GEMM launch per limb; the jobs share the matrix
+// stream through L2.  When the measurement hook is on, the single-job GEMM launches of the 4-plane limbs (the outer
+// commitment) are bracketed by events.
 int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_mat8* m, ConstHatView V, size_t v_set_stride, int ns,
-                     int ns_valid, void* scratch) {
+                     int ns_valid, void* scratch, size_t v_k_stride, size_t njobs, size_t out_job_stride, size_t v_job_stride) {
   const uint32_t* primes = m->basis ? c->dg_primes : c->primes;
   const size_t ktotal = m->nmat * m->cols;
-  Carver cv(scratch);
-  size_t v8max = 0;
-  for (int l = 0; l < m->nlimbs; l++) {
-    size_t nt = nt_for(ns, m->planes[l]);
-    if (nt == 3) nt = 4;
-    v8max = std::max(v8max, (size_t)D * m->kt_count * nt * 1024);
-  }
-  int8_t* v8 = cv.take<int8_t>(v8max);
-  int32_t* dm = reinterpret_cast<int32_t*>(cv.base + cv.off);
+  int8_t* v8 = static_cast<int8_t*>(scratch);
+  const size_t v8_stride = v8_job_bytes(m, ns);
   for (int l = 0; l < m->nlimbs; l++) {
     const int pl = m->planes[l];
-    size_t nt = nt_for(ns, pl);
-    if (nt == 3) nt = 4;                       // the GEMM is instantiated for 1, 2, 4 column tiles
-    LAB_HIP(c, launch_pack_vectors_i8(ns, ns_valid, v8, V.base + (size_t)l * V.plane_stride, v_set_stride, ktotal, m->kt_count, nt, pl,
-                                      c->stream));
-    const bool prof = c->prof_on && pl == 4;
+    const size_t nt = nt_for(ns, pl);
+    LAB_HIP(c, launch_pack_vectors_i8(ns, ns_valid, v8, V.base + (size_t)l * V.plane_stride, v_set_stride, v_k_stride, ktotal,
+                                      m->kt_count, nt, pl, njobs, v_job_stride, v8_stride, c->stream));
+    Gemm8Args g;
+    g.out = out.base + (size_t)l * out.plane_stride; g.out_set_stride = out_set_stride; g.out_job_stride = out_job_stride;
+    g.M8 = m->d[l]; g.V8 = v8; g.v8_job_stride = v8_stride;
+    g.planes = (unsigned)pl; g.rt_count = (unsigned)m->rt_count; g.kt_count = (unsigned)m->kt_count;
+    g.rgroups = (unsigned)((m->rt_count + 4 / pl - 1) / (4 / pl)); g.njobs = (unsigned)njobs; g.rows = (unsigned)m->rows;
+    g.ns = (unsigned)ns; g.ns_valid = (unsigned)ns_valid; g.p = primes[l];
+    const bool prof = c->prof_on && pl == 4 && njobs == 1 && v_k_stride == (size_t)D;
     if (prof && c->prof_used == c->prof_events.size()) {
       hipEvent_t a, b;
       LAB_HIP(c, hipEventCreate(&a));
@@ -67,16 +69,14 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
       c->prof_events.emplace_back(a, b);
     }
     if (prof) LAB_HIP(c, hipEventRecord(c->prof_events[c->prof_used].first, c->stream));
-    LAB_HIP(c, launch_gemm_i8(dm, m->d[l], v8, pl, m->rt_count, m->kt_count, nt, c->stream));
+    LAB_HIP(c, launch_gemm_i8(g, nt, c->stream));
     if (prof) {
       LAB_HIP(c, hipEventRecord(c->prof_events[c->prof_used++].second, c->stream));
       c->prof_kernel = nt == 4 ? "k_gemm_i8<4>" : nt == 2 ? "k_gemm_i8<2>" : "k_gemm_i8<1>";
-      // matrix digit planes once, the B-operand tiles once per 128-row block group (from L2), the int32 results
+      // the matrix digit planes once, the B-operand tiles once per 32-row block (from L2), the residues out
       c->prof_bytes += (double)D * pl * m->rt_count * m->kt_count * 1024 + (double)D * m->kt_count * nt * 1024 +
-                       (double)D * pl * m->rt_count * 32 * nt * 32 * 4;
+                       (double)ns_valid * m->rows * D * 4;
     }
-    LAB_HIP(c, launch_gemm_i8_epilogue(out.base + (size_t)l * out.plane_stride, out_set_stride, dm, m->rows, m->rt_count, ns, ns_valid,
-                                       nt * 32, pl, pl, primes[l], c->stream));
   }
   return LAB_OK;
 }
@@ -153,6 +153,6 @@ extern "C" int lab_matvec_sum_mfma(lab_ctx* c, lab_vec* out, size_t out_off, con
   if (V->basis != m->basis || out->basis != m->basis || V->compact || out->compact)
     return fail(c, LAB_ERR_ARG, "lab_matvec_sum_mfma: V and out must be plain vectors in the packed matrix's basis");
   LAB_HIP(c, hipSetDevice(c->device));
-  if ((rc = ensure_scratch(c, mfma_scratch_bytes(m, ns)))) return rc;
-  return matvec_mfma_impl(c, out->view(out_off), m->rows * D, m, V->view(v_off), m->nmat * m->cols * D, ns, ns, c->scratch);
+  if ((rc = ensure_scratch(c, mfma_scratch_bytes(m, ns, 1)))) return rc;
+  return matvec_mfma_impl(c, out->view(out_off), m->rows * D, m, V->view(v_off), m->nmat * m->cols * D, ns, ns, c->scratch, D, 1, 0, 0);
 }

@@ -89,16 +89,20 @@ constexpr int PV_SETS = 8;
 constexpr int PV_PITCH = 16 * D + 4;     // words per set in LDS (16-byte aligned rows, 2-way bank conflicts at most)
 
 __global__ void __launch_bounds__(256)
-k_pack_vectors_i8(int8_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t set_stride, unsigned ktotal,
-                  unsigned kt_count, unsigned nt_count, int planes, unsigned ns, unsigned ns_valid) {
+k_pack_vectors_i8(int8_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t set_stride, size_t k_stride, unsigned ktotal,
+                  unsigned kt_count, unsigned nt_count, int planes, unsigned ns, unsigned ns_valid, size_t src_job_stride,
+                  size_t dst_job_stride) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[PV_SETS * PV_PITCH];
-  const unsigned kt = blockIdx.x, h = blockIdx.y, s0 = blockIdx.z * PV_SETS;
+  const unsigned groups = ns / PV_SETS, job = blockIdx.z / groups;
+  const unsigned kt = blockIdx.x, h = blockIdx.y, s0 = (blockIdx.z % groups) * PV_SETS;
+  src += (size_t)job * src_job_stride;
+  dst += (size_t)job * dst_job_stride;
   const unsigned k0 = kt * 32 + 16 * h;
   for (unsigned e = threadIdx.x; e < PV_SETS * 16 * D / 4; e += 256) {       // quads
     const unsigned sset = e / (16 * D / 4), wq = e % (16 * D / 4), k = k0 + wq / (D / 4);
     uint4 v = make_uint4(0, 0, 0, 0);
     if (k < ktotal && s0 + sset < ns_valid)   // sets past ns_valid are padding: zero columns, never read
-      v = *reinterpret_cast<const uint4*>(src + (size_t)(s0 + sset) * set_stride + (size_t)k0 * D + wq * 4);
+      v = *reinterpret_cast<const uint4*>(src + (size_t)(s0 + sset) * set_stride + (size_t)k * k_stride + (wq % (D / 4)) * 4);
     *reinterpret_cast<uint4*>(&lds[sset * PV_PITCH + wq * 4]) = v;
   }
   __syncthreads();
@@ -120,39 +124,50 @@ k_pack_vectors_i8(int8_t* __restrict__ dst, const uint32_t* __restrict__ src, si
   }
 }
 
-hipError_t launch_pack_vectors_i8(int ns, int ns_valid, int8_t* dst, const uint32_t* src, size_t set_stride, size_t ktotal,
-                                  size_t kt_count, size_t nt_count, int planes, hipStream_t s) {
-  if (ns % PV_SETS || (set_stride % 4)) return hipErrorInvalidValue;
-  dim3 g((unsigned)kt_count, 2, (unsigned)(ns / PV_SETS));
-  hipLaunchKernelGGL(k_pack_vectors_i8, g, dim3(256), 0, s, dst, src, set_stride, (unsigned)ktotal, (unsigned)kt_count,
-                     (unsigned)nt_count, planes, (unsigned)ns, (unsigned)ns_valid);
+// V_s[k] = src + s*set_stride + k*k_stride (words): k_stride = 64 for vectors stored set by set, r*64 for the columns of
+// an [n][r] witness matrix
+hipError_t launch_pack_vectors_i8(int ns, int ns_valid, int8_t* dst, const uint32_t* src, size_t set_stride, size_t k_stride,
+                                  size_t ktotal, size_t kt_count, size_t nt_count, int planes, size_t njobs, size_t src_job_stride,
+                                  size_t dst_job_stride, hipStream_t s) {
+  if (ns % PV_SETS || (set_stride % 4) || (k_stride % 4) || (src_job_stride % 4) || njobs * (ns / PV_SETS) > 65535) return hipErrorInvalidValue;
+  dim3 g((unsigned)kt_count, 2, (unsigned)(njobs * (ns / PV_SETS)));
+  hipLaunchKernelGGL(k_pack_vectors_i8, g, dim3(256), 0, s, dst, src, set_stride, k_stride, (unsigned)ktotal, (unsigned)kt_count,
+                     (unsigned)nt_count, planes, (unsigned)ns, (unsigned)ns_valid, src_job_stride, dst_job_stride);
   return hipGetLastError();
 }
 
-// ---- the GEMM.  Block = 4 waves; wave w owns ONE row tile (32 rows) of one (slot j, plane i) and all NT column tiles:
-// NT accumulator tiles of 16 registers.  K is walked in stages of KS k-tiles.  A operands (KS KiB per wave and stage,
-// streamed once from HBM with non-temporal 16-byte loads) sit in a 3-deep register ring: two stages are in flight
-// behind the one being multiplied.  B operands (KS*NT KiB per block and stage, shared by the 4 waves) come from L2
-// through a double-buffered LDS stage.  Blocks are numbered so that all blocks of one slot j (every plane, every row
-// group: they walk the same B operand stream) run on ONE XCD at the same time: the first pulls a B tile from
-// HBM/MALL, the others hit that XCD's L2.
+// ---- the GEMM, recombination fused.  Block = 4 waves = (digit plane i) x (row tile): with 4 planes the block owns
+// ONE 32-row tile of one slot j and its four waves hold the four digit planes of the matrix; with 2 planes two row
+// tiles.  Each wave multiplies its A plane with all NT column tiles (NT accumulator tiles of 16 registers).  K is
+// walked in stages of KS k-tiles.  A operands (KS KiB per wave and stage, streamed once from HBM with non-temporal
+// 16-byte loads) sit in a 3-deep register ring: two stages are in flight behind the one being multiplied.  B operands
+// (KS*NT KiB per block and stage, shared by the 4 waves) come from L2 through a double-buffered LDS stage.  At the end
+// the waves park their int32 tiles in LDS and the block writes out_s[row][j] = sum_{i,i'} 256^(i+i') D_i[row][(i',s)]
+// mod p directly: no int32 matrix ever goes to memory.
+// Blocks are numbered so that all blocks that walk the same operand streams run on ONE XCD at the same time: XCD
+// x = blockIdx.x % 8 takes slots j = x, x+8, ...; within a slot the job index (a "job" = one set of NS vectors with its
+// own B operand stream, e.g. one proof's witness columns against the shared matrix A) runs fastest, then the row
+// group — so the first block pulls an operand tile from HBM/MALL and its neighbours hit that XCD's L2.
 constexpr int G8_KS = 4;
+
 
 template <int NT>
 __global__ void __launch_bounds__(256)
-k_gemm_i8(int32_t* __restrict__ Dout, const int8_t* __restrict__ M8, const int8_t* __restrict__ V8, unsigned planes,
-          unsigned rt_count, unsigned kt_count, unsigned blocks_per_j) {
-  __shared__ u32x4_t ldsB[2][G8_KS * NT * 64];
+k_gemm_i8(const Gemm8Args a) {
+  // B staging during the K loop (2 x KS*NT KiB), the four waves' int32 tiles afterwards (4 x NT*4 KiB)
+  __shared__ u32x4_t lds[4 * NT * 16 * 64 / 4];
+  static_assert(2 * G8_KS * NT * 64 <= 4 * NT * 16 * 64 / 4, "the B stage fits the recombination buffer");
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  // XCD x = blockIdx.x % 8 takes slots j = x, x+8, ...; within a slot: (plane i, row group)
+  const unsigned planes = a.planes, rt_count = a.rt_count, kt_count = a.kt_count;
   const unsigned x = blockIdx.x & 7, seq = blockIdx.x >> 3;
-  const unsigned j = x + 8 * (seq / blocks_per_j), sub = seq % blocks_per_j;
-  const unsigned rgroups = blocks_per_j / planes;
-  const unsigned i = sub / rgroups, rt = (sub % rgroups) * 4 + w;
+  const unsigned per_j = a.rgroups * a.njobs;
+  const unsigned j = x + 8 * (seq / per_j), sub = seq % per_j;
+  const unsigned job = sub % a.njobs, rg = sub / a.njobs;
+  const unsigned tiles_per_block = 4 / planes;     // row tiles per block
+  const unsigned i = w % planes, rtl = w / planes, rt = rg * tiles_per_block + rtl;
   const unsigned ji = j * planes + i;
-  const bool live = rt < rt_count;                 // whole wave; dead waves still help with the B loads and barriers
-  const u32x4_t* A = reinterpret_cast<const u32x4_t*>(M8) + ((size_t)ji * rt_count + min(rt, rt_count - 1)) * kt_count * 64 + lane;
-  const u32x4_t* B = reinterpret_cast<const u32x4_t*>(V8) + (size_t)j * kt_count * NT * 64;
+  const u32x4_t* A = reinterpret_cast<const u32x4_t*>(a.M8) + ((size_t)ji * rt_count + min(rt, rt_count - 1)) * kt_count * 64 + lane;
+  const u32x4_t* B = reinterpret_cast<const u32x4_t*>(a.V8 + (size_t)job * a.v8_job_stride) + (size_t)j * kt_count * NT * 64;
   constexpr int BQ = G8_KS * NT * 64;              // B quads per stage
   constexpr int BPT = BQ / 256;                    // per thread (= NT)
   static_assert(BQ % 256 == 0, "a stage's B operands are a whole number of quads per thread");
@@ -168,8 +183,7 @@ k_gemm_i8(int32_t* __restrict__ Dout, const int8_t* __restrict__ M8, const int8_
   u32x4_t bNxt[BPT];
   auto loadA = [&](unsigned st, u32x4_t (&dst)[G8_KS]) {
 #pragma unroll
-    for (int s = 0; s < G8_KS; s++)
-      dst[s] = __builtin_nontemporal_load(A + ((size_t)st * G8_KS + s) * 64);
+    for (int s = 0; s < G8_KS; s++) dst[s] = __builtin_nontemporal_load(A + ((size_t)st * G8_KS + s) * 64);
   };
   auto loadB = [&](unsigned st) {
 #pragma unroll
@@ -177,7 +191,7 @@ k_gemm_i8(int32_t* __restrict__ Dout, const int8_t* __restrict__ M8, const int8_
   };
   auto parkB = [&](int buf) {
 #pragma unroll
-    for (int q = 0; q < BPT; q++) ldsB[buf][t + q * 256] = bNxt[q];
+    for (int q = 0; q < BPT; q++) lds[buf * BQ + t + q * 256] = bNxt[q];
   };
   // one stage: multiply stage st (A operands in `cur`, B operands in LDS buffer st & 1) while stage st+1's B operands
   // and stage st+2's A operands (into `nxt`, the ring slot stage st-1 used) are fetched
@@ -190,7 +204,7 @@ k_gemm_i8(int32_t* __restrict__ Dout, const int8_t* __restrict__ M8, const int8_
       const i32x4_t af = {(int)cur[s].x, (int)cur[s].y, (int)cur[s].z, (int)cur[s].w};
 #pragma unroll
       for (int n = 0; n < NT; n++) {
-        const u32x4_t bq = ldsB[buf][(s * NT + n) * 64 + lane];
+        const u32x4_t bq = lds[buf * BQ + (s * NT + n) * 64 + lane];
         const i32x4_t bf = {(int)bq.x, (int)bq.y, (int)bq.z, (int)bq.w};
         acc[n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[n], 0, 0, 0);
       }
@@ -208,60 +222,56 @@ k_gemm_i8(int32_t* __restrict__ Dout, const int8_t* __restrict__ M8, const int8_
     step(st + 1, a1, a0);
     step(st + 2, a2, a1);
   }
-  // D[ji][row][n]: lane holds column (lane & 31) of tile n, rows (g&3) + 8*(g>>2) + 4*(lane>>5)
-  if (live) {
-    constexpr unsigned ncols = NT * 32;
+  // ---- recombination.  Wave w parks tile n, register g, lane l at dl[((w*NT + n)*16 + g)*64 + l]; element (row, col)
+  // of a 32x32 tile sits in register g = (row & 3) | ((row >> 3) << 2) of lane ((row >> 2) & 1) * 32 + col.
+  int32_t* dl = reinterpret_cast<int32_t*>(lds);
 #pragma unroll
-    for (int n = 0; n < NT; n++)
+  for (int n = 0; n < NT; n++)
 #pragma unroll
-      for (int g = 0; g < 16; g++) {
-        const unsigned row = rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
-        Dout[((size_t)ji * rt_count * 32 + row) * ncols + n * 32 + (lane & 31)] = acc[n][g];
+    for (int g = 0; g < 16; g++) dl[((w * NT + n) * 16 + g) * 64 + lane] = acc[n][g];
+  __syncthreads();
+  // c_t = sum_{i+i'=t} D_i[row][(i',s)] (|c_t| < 2^33), then Horner in 256 with a division-free reduction per step
+  const uint32_t p = a.p;
+  const double inv_p = 1.0 / (double)p;
+  auto modp = [&](int64_t v) -> int64_t {        // |v| < 2^40: floor(v / p) from one double multiply is off by at most 1
+    const int64_t q = (int64_t)__builtin_floor((double)v * inv_p);
+    int64_t r = v - q * (int64_t)p;
+    r += r < 0 ? (int64_t)p : 0;
+    r -= r >= (int64_t)p ? (int64_t)p : 0;
+    return r;
+  };
+  const unsigned ns = a.ns;
+  uint32_t* out = a.out + (size_t)job * a.out_job_stride;
+  for (unsigned o = t; o < tiles_per_block * 32 * ns; o += 256) {
+    const unsigned s = o % ns, row = (o / ns) % 32, tl = o / (ns * 32);
+    const unsigned grow = (rg * tiles_per_block + tl) * 32 + row;
+    if (s >= a.ns_valid || grow >= a.rows) continue;
+    const unsigned g = (row & 3) | ((row >> 3) << 2), lh = ((row >> 2) & 1) * 32;
+    int64_t ct[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (unsigned pi = 0; pi < 4; pi++)
+#pragma unroll
+      for (unsigned pv = 0; pv < 4; pv++) {
+        if (pi < planes && pv < planes) {
+          const unsigned n = pv * ns + s;
+          ct[pi + pv] += dl[(((tl * planes + pi) * NT + n / 32) * 16 + g) * 64 + lh + (n % 32)];
+        }
       }
+    int64_t r = 0;
+#pragma unroll
+    for (int e = 6; e >= 0; e--) r = modp(r * 256 + modp(ct[e]));
+    out[(size_t)s * a.out_set_stride + (size_t)grow * D + j] = (uint32_t)r;
   }
 }
 
-hipError_t launch_gemm_i8(int32_t* Dout, const int8_t* M8, const int8_t* V8, int planes, size_t rt_count, size_t kt_count,
-                          size_t nt, hipStream_t s) {
-  const unsigned blocks_per_j = (unsigned)(planes * ((rt_count + 3) / 4));
-  dim3 g((unsigned)(D * blocks_per_j));            // D = 64 slots = 8 per XCD
+hipError_t launch_gemm_i8(const Gemm8Args& a, size_t nt, hipStream_t s) {
+  dim3 g((unsigned)(D * a.rgroups * a.njobs));     // D = 64 slots = 8 per XCD
   switch (nt) {
-    case 1: hipLaunchKernelGGL((k_gemm_i8<1>), g, dim3(256), 0, s, Dout, M8, V8, (unsigned)planes, (unsigned)rt_count, (unsigned)kt_count, blocks_per_j); break;
-    case 2: hipLaunchKernelGGL((k_gemm_i8<2>), g, dim3(256), 0, s, Dout, M8, V8, (unsigned)planes, (unsigned)rt_count, (unsigned)kt_count, blocks_per_j); break;
-    case 4: hipLaunchKernelGGL((k_gemm_i8<4>), g, dim3(256), 0, s, Dout, M8, V8, (unsigned)planes, (unsigned)rt_count, (unsigned)kt_count, blocks_per_j); break;
+    case 1: hipLaunchKernelGGL((k_gemm_i8<1>), g, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((k_gemm_i8<2>), g, dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((k_gemm_i8<4>), g, dim3(256), 0, s, a); break;
     default: return hipErrorInvalidValue;
   }
-  return hipGetLastError();
-}
-
-// ---- epilogue: out_s[rho][j] = sum_{i,i'} 256^(i+i') D[j][i][rho][i'*NS + s] mod p, one thread per (rho, s), j = blockIdx.y
-__global__ void __launch_bounds__(256)
-k_gemm_i8_epilogue(uint32_t* __restrict__ out, size_t out_set_stride, const int32_t* __restrict__ Dm, unsigned rows,
-                   unsigned rt_count, unsigned ns, unsigned ns_valid, unsigned ncols, int planes_m, int planes_v, uint32_t p) {
-  const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= rows * ns) return;
-  const unsigned s = idx % ns, rho = idx / ns, j = blockIdx.y;
-  if (s >= ns_valid) return;
-  // powers of 256 mod p
-  uint32_t pw[8];
-  pw[0] = 1 % p;
-  for (int t = 1; t < 8; t++) pw[t] = (uint32_t)(((uint64_t)pw[t - 1] * 256) % p);
-  uint64_t acc = 0;
-  for (int i = 0; i < planes_m; i++)
-    for (int k = 0; k < planes_v; k++) {
-      const int32_t d = Dm[(((size_t)j * planes_m + i) * rt_count * 32 + rho) * ncols + k * ns + s];
-      const int64_t dm = (int64_t)d % (int64_t)p;                  // in (-p, p)
-      const uint32_t u = (uint32_t)(dm < 0 ? dm + p : dm);
-      acc += (uint64_t)u * pw[i + k];                               // < 16 * 2^60: no overflow
-    }
-  out[(size_t)s * out_set_stride + (size_t)rho * D + j] = (uint32_t)(acc % p);
-}
-
-hipError_t launch_gemm_i8_epilogue(uint32_t* out_plane, size_t out_set_stride, const int32_t* Dm, size_t rows, size_t rt_count,
-                                   size_t ns, size_t ns_valid, size_t ncols, int planes_m, int planes_v, uint32_t p, hipStream_t s) {
-  dim3 g((unsigned)((rows * ns + 255) / 256), (unsigned)D);
-  hipLaunchKernelGGL(k_gemm_i8_epilogue, g, dim3(256), 0, s, out_plane, out_set_stride, Dm, (unsigned)rows, (unsigned)rt_count,
-                     (unsigned)ns, (unsigned)ns_valid, (unsigned)ncols, planes_m, planes_v, p);
   return hipGetLastError();
 }
 

@@ -80,7 +80,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     if (!x->S || !x->phi || !x->a || !x->Pi || !x->omega || !x->alpha || !x->beta || !x->c)
       return fail(c, LAB_ERR_ARG, "lab_prove_core: null input array");
     if (x->n != n || x->r != r || x->kappa != kappa || x->kappa1 != k1 || x->kappa2 != k2 || x->t1 != t1 || x->t2 != t2 ||
-        x->b1 != in->b1 || x->b2 != in->b2 || x->beta_bound != in->beta_bound || x->A != in->A || x->B != in->B || x->B8 != in->B8 ||
+        x->b1 != in->b1 || x->b2 != in->b2 || x->beta_bound != in->beta_bound || x->A != in->A || x->B != in->B || x->B8 != in->B8 || x->A8 != in->A8 ||
         x->C != in->C || x->Dm != in->Dm || x->a_off != in->a_off || x->b_off != in->b_off || x->c_off != in->c_off ||
         x->d_off != in->d_off)
       return fail(c, LAB_ERR_ARG, "lab_prove_core_batch: all proofs of a batch must share dimensions, constants and the CRS");
@@ -98,6 +98,9 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   // B, C, D may live in the context's digit basis (lab_ctx_enable_digit_basis): steps 3, 4, 9 then run in it
   const int bdig = in->C->basis;
   if ((in->B && in->B->basis != bdig) || in->Dm->basis != bdig) return fail(c, LAB_ERR_ARG, "lab_prove_core: B, C, D must share one RNS basis");
+  const lab_mat8* a8 = in->A8;
+  if (a8 && !mat8_matches(a8, 0, 1, kappa, n))
+    return fail(c, LAB_ERR_ARG, "lab_prove_core: A8 was not packed from the kappa x n matrix A in the main basis");
   if (b8 && !mat8_matches(b8, bdig, r * (size_t)t1, k1, kappa))
     return fail(c, LAB_ERR_ARG, "lab_prove_core: B8 was not packed from r*t1 matrices of kappa1 x kappa elements in the basis of C, D");
   if (in->A->basis != 0 || in->A->compact) return fail(c, LAB_ERR_ARG, "lab_prove_core: A must be a main-basis vector");
@@ -157,11 +160,13 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   }
   // int8-MFMA step 3: padded set count of the largest group and its scratch (B-operand tiles + int32 results)
   const int mf_ns = np > 16 ? 32 : np > 8 ? 16 : 8;
-  const size_t mf_bytes = b8 ? mfma_scratch_bytes(b8, mf_ns) + 4096 : 0;
+  size_t mf_bytes = b8 ? mfma_scratch_bytes(b8, mf_ns, 1) + 4096 : 0;
+  const int a8_ns = r <= 8 ? 8 : r <= 16 ? 16 : 32;       // witness columns per Ajtai GEMM pass
+  if (a8 && mfma_scratch_bytes(a8, a8_ns, np) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(a8, a8_ns, np) + 4096;
   bytes += mf_bytes;
   if ((rc = ensure_scratch(c, bytes + (1 << 16)))) return rc;
   Carver cv(c->scratch);
-  char* mf_scratch = b8 ? cv.take<char>(mf_bytes) : nullptr;
+  char* mf_scratch = mf_bytes ? cv.take<char>(mf_bytes) : nullptr;
   uint32_t* hat_base = cv.take<uint32_t>((size_t)L * hat_words);
   uint32_t* hatd_base = cv.take<uint32_t>((size_t)Ld * hatd_words);
   // from_hat scratch: a dense [L][count][64] buffer (its plane stride is count*64, not the arena's)
@@ -208,7 +213,14 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   }
   // ================= step 1 (src/proofgen.rs:41-49): t_i = A s_i for every column of every proof; A is shared, so the
   // whole batch is one (kappa x n)(n x np*r) product (falls back to one launch per proof for shapes it does not take)
-  {
+  if (a8) {   // matrix cores: per proof, its r witness columns as the vector sets (element x of column i at S[x][i])
+    // one launch per limb and 32 columns: the proofs are the kernel's jobs and share the A stream through L2
+    for (size_t i0 = 0; i0 < r; i0 += 32) {
+      const int valid = (int)(r - i0 < 32 ? r - i0 : 32);
+      if ((rc = matvec_mfma_impl(c, HV(0, hT + i0 * kappa), kappa * D, a8, HV(0, hS + i0), D, a8_ns, valid, mf_scratch, r * D, np,
+                                 per * D, per * D))) return rc;
+    }
+  } else {
     hipError_t e = launch_matmul_bcast(HV(0, hT), kappa * D, per * D, in->A->view(in->a_off), HV(0, hS), D, r * D, per * D, np,
                                        kappa, n, r, L, tabs, s);
     if (e == hipErrorNotSupported) {
@@ -233,7 +245,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   for (size_t j0 = 0; b8 && j0 < np;) {   // matrix cores: up to 32 proofs per pass over B, result written in place
     const size_t left = np - j0;
     const int ns = left > 16 ? 32 : left > 8 ? 16 : 8, valid = (int)(left < (size_t)ns ? left : (size_t)ns);
-    if ((rc = matvec_mfma_impl(c, HD(j0, hlhs), perd * D, b8, HD(j0, hTdec), perd * D, ns, valid, mf_scratch))) return rc;
+    if ((rc = matvec_mfma_impl(c, HD(j0, hlhs), perd * D, b8, HD(j0, hTdec), perd * D, ns, valid, mf_scratch, D, 1, 0, 0))) return rc;
     j0 += valid;
   }
   for (size_t j0 = 0; !b8 && j0 < np;) {

@@ -89,6 +89,7 @@ class ResidentCRS:
         from .api import Mat8
         k = self.constants
         self.B8 = Mat8(self.ctx, self.B, k.R * k.T_1, k.KAPPA_1, k.KAPPA)
+        self.A8 = Mat8(self.ctx, self.A, 1, k.KAPPA, k.N)
         if drop_B:
             self.ctx.synchronize()
             self.B.close()
@@ -96,7 +97,7 @@ class ResidentCRS:
         return self
 
     def close(self):
-        for v in (self.A, self.B, self.C, self.Dm, getattr(self, "B8", None)):
+        for v in (self.A, self.B, self.C, self.Dm, getattr(self, "B8", None), getattr(self, "A8", None)):
             if v is not None:
                 v.close()
 
@@ -226,6 +227,7 @@ def _prove_io(ctx, k, witness, st, crs, tape, device_outputs):
     pin.b_prime = st.b_prime
     pin.A, pin.B, pin.C, pin.Dm = crs.A._h, (crs.B._h if crs.B is not None else None), crs.C._h, crs.Dm._h
     pin.B8 = crs.B8._h if getattr(crs, "B8", None) is not None else None
+    pin.A8 = crs.A8._h if getattr(crs, "A8", None) is not None else None
     pin.a_off = pin.b_off = pin.c_off = pin.d_off = 0
     Pi = tape["Pi"]
     if isinstance(Pi, np.ndarray):
@@ -300,6 +302,7 @@ def verify_core(ctx, k, st, b_poly, crs, T, tape=None):
     pin.b_prime = st.b_prime
     pin.A, pin.B, pin.C, pin.Dm = crs.A._h, (crs.B._h if crs.B is not None else None), crs.C._h, crs.Dm._h
     pin.B8 = crs.B8._h if getattr(crs, "B8", None) is not None else None
+    pin.A8 = crs.A8._h if getattr(crs, "A8", None) is not None else None
     pin.a_off = pin.b_off = pin.c_off = pin.d_off = 0
     Pi = tape["Pi"]
     if isinstance(Pi, np.ndarray):
