@@ -107,6 +107,7 @@ static bool build_limb_table(uint32_t p, LimbTable* t) {
   t->r2 = (uint32_t)((u128)t->r1 * t->r1 % p);
   t->q_hi_mul = t->r1;
   t->q_hi_mul_sh = shoup(t->r1, p);
+  t->inv_p = 1.0 / (double)p;
   // primitive 128th root of unity: psi^64 == -1
   uint64_t psi = 0;
   for (uint64_t g = 2; g < 2000; g++) {
@@ -148,6 +149,8 @@ static void build_crt_table(uint64_t q, int nlimbs, const uint32_t* primes, CrtT
     }
   }
   t->m_mod_q = (uint64_t)(M % q);
+  t->inv_q = 1.0 / (double)q;
+  for (int a = 0; a < nlimbs; a++) t->inv_p[a] = 1.0 / (double)primes[a];
   u128 h = (M - 1) / 2;
   for (int a = 0; a < nlimbs; a++) {
     t->half_digits[a] = (uint32_t)(h % primes[a]);

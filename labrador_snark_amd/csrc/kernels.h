@@ -36,6 +36,9 @@ struct CrtTable {
   uint64_t m_mod_q;
   // half-modulus test in mixed radix: M/2 digits (floor), for the sign decision
   uint32_t half_digits[MAX_LIMBS];
+  // reciprocals for the division-free reductions (mod_u64)
+  double inv_q;
+  double inv_p[MAX_LIMBS];
 };
 
 // ---- ntt_kernels.hip

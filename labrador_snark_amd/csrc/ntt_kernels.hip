@@ -42,6 +42,22 @@ hipError_t launch_ntt(bool forward, ConstHatView src, HatView dst, size_t count,
 }
 
 // coefficient u64 in [0,q) -> residue mod each limb prime (q < 2^40, so x = hi*2^32 + lo with hi < 2^8).
+// Division-free: hi*2^32 mod p by a Shoup multiplication with the tabulated 2^32 mod p; lo mod p by conditional
+// subtractions when p > 2^29 (lo < 2^32 < 8p), by mod_u64 for the small limb of the digit basis.
+__device__ __forceinline__ uint32_t reduce_u40(uint64_t v, const LimbTable& tb) {
+  const uint32_t p = tb.p, lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  if (p > (1u << 29)) {
+    uint32_t b = lo;
+    b = min(b, b - 4 * p);   // wraps (and is discarded by min) unless b >= 4p; 4p < 2^32 as p < 2^30
+    b = min(b, b - 2 * p);
+    b = min(b, b - p);
+    if (hi == 0) return b;
+    const uint32_t a = mul_shoup_lazy(hi, tb.q_hi_mul, tb.q_hi_mul_sh, p);   // [0, 2p)
+    return csub(csub(a + b, 2 * p), p);                                      // a + b < 3p < 2^32
+  }
+  return (uint32_t)mod_u64(v, p, tb.inv_p);
+}
+
 __global__ void __launch_bounds__(256)
 k_reduce_u64(const uint64_t* __restrict__ coeffs, uint32_t* __restrict__ dst, size_t dst_ps, size_t nwords,
              int nlimbs, const LimbTable* __restrict__ tabs) {
@@ -50,12 +66,8 @@ k_reduce_u64(const uint64_t* __restrict__ coeffs, uint32_t* __restrict__ dst, si
   for (; i < nwords; i += stride) {
     // nwords is a multiple of 64, so the pair (i, i+1) is always in range
     const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(coeffs + i);
-    for (int l = 0; l < nlimbs; l++) {
-      const uint32_t p = tabs[l].p, r1 = tabs[l].r1;
-      uint32_t a = (uint32_t)(((v.x >> 32) * r1 + (uint32_t)v.x) % p);
-      uint32_t b = (uint32_t)(((v.y >> 32) * r1 + (uint32_t)v.y) % p);
-      *reinterpret_cast<uint2*>(dst + (size_t)l * dst_ps + i) = make_uint2(a, b);
-    }
+    for (int l = 0; l < nlimbs; l++)
+      *reinterpret_cast<uint2*>(dst + (size_t)l * dst_ps + i) = make_uint2(reduce_u40(v.x, tabs[l]), reduce_u40(v.y, tabs[l]));
   }
 }
 
@@ -70,22 +82,24 @@ hipError_t launch_reduce_u64(const uint64_t* coeffs, HatView dst, size_t count, 
   return hipGetLastError();
 }
 
-__device__ __forceinline__ uint64_t mulmod_q(uint32_t d, uint64_t c, uint64_t q) {
-  // d < 2^30, c < q < 2^40: split c so every intermediate fits 64 bits
-  uint64_t chi = c >> 20, clo = c & 0xFFFFF;
-  uint64_t t = ((uint64_t)d * chi) % q;
-  t = (t << 20) % q;
-  return (t + (uint64_t)d * clo) % q;
+__device__ __forceinline__ uint64_t mulmod_q(uint32_t d, uint64_t c, uint64_t q, double inv_q) {
+  // d < 2^30, c < q < 2^40: the product fits 64 bits when q < 2^34, else c is split at bit 20
+  if (q < (1ull << 34)) return mod_u64((uint64_t)d * c, q, inv_q);
+  const uint64_t chi = c >> 20, clo = c & 0xFFFFF;
+  uint64_t t = mod_u64((uint64_t)d * chi, q, inv_q);
+  t = mod_u64(t << 20, q, inv_q);
+  return mod_u64(t + (uint64_t)d * clo, q, inv_q);
 }
 
 // hat residues (already inverse-transformed, canonical) -> signed CRT -> mod q.
 // The integer being reconstructed is the exact negacyclic result; it lies in
-// (-M/2, M/2), which lab_ctx guarantees through max_len.
+// (-M/2, M/2), which lab_ctx guarantees through max_len.  No integer divisions: see mod_u64.
 __global__ void __launch_bounds__(256)
 k_crt_to_u64(const uint32_t* __restrict__ src, size_t src_ps, uint64_t* __restrict__ coeffs, size_t nwords,
              const CrtTable* __restrict__ crt) {
   const int L = crt->nlimbs;
   const uint64_t q = crt->q;
+  const double inv_q = crt->inv_q;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < nwords; i += stride) {
@@ -98,7 +112,8 @@ k_crt_to_u64(const uint32_t* __restrict__ src, size_t src_ps, uint64_t* __restri
       const uint32_t p = crt->p[a];
       uint32_t t = r[a];
       for (int b = 0; b < a; b++) {
-        uint32_t db = d[b] % p;                       // digits of other limbs may exceed p by < 2^30/p
+        // digits of the other limbs are < 2^30: below 2p for the 30-bit primes, anything for a small last prime
+        const uint32_t db = p > (1u << 29) ? csub(d[b], p) : (uint32_t)mod_u64(d[b], p, crt->inv_p[a]);
         uint32_t diff = t >= db ? t - db : t + p - db;
         t = csub(mul_shoup_lazy(diff, crt->ginv[a][b][0], crt->ginv[a][b][1], p), p);
       }
@@ -109,8 +124,11 @@ k_crt_to_u64(const uint32_t* __restrict__ src, size_t src_ps, uint64_t* __restri
     for (int a = L - 1; a >= 0; a--) {
       if (d[a] != crt->half_digits[a]) { neg = d[a] > crt->half_digits[a]; break; }
     }
-    uint64_t acc = d[0] % q;
-    for (int a = 1; a < L; a++) acc = (acc + mulmod_q(d[a], crt->prefix_mod_q[a], q)) % q;
+    uint64_t acc = d[0] < q ? d[0] : mod_u64(d[0], q, inv_q);
+    for (int a = 1; a < L; a++) {
+      acc += mulmod_q(d[a], crt->prefix_mod_q[a], q, inv_q);
+      acc -= acc >= q ? q : 0;
+    }
     if (neg) acc = acc >= crt->m_mod_q ? acc - crt->m_mod_q : acc + q - crt->m_mod_q;
     coeffs[i] = acc;
   }

@@ -29,14 +29,24 @@ k_decompose(uint64_t* __restrict__ out, const uint64_t* __restrict__ in, size_t 
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const uint64_t half = (base / 2) % q;  // `val > b/2` compares with mod_positive(b/2, Q) (algebraic.rs:293-297)
+  const double inv_base = 1.0 / (double)base;
+  const bool small_q = base > q;         // only then do the reference's `% Q` after `% base` do anything
   for (; i < nwords; i += stride) {
     uint64_t v = in[i];
     for (int k = 0; k < exp; k++) {
       uint64_t r = 0;
       if (v != 0) {
-        uint64_t r0 = (v % base) % q;
-        r = r0 > half ? ((base - r0) % base) % q : r0;
-        v = (submod(v, r, q) / base) % q;
+        // r0 = (v % base) % q ; r = r0 > half ? ((base - r0) % base) % q : r0 ; v = ((v - r mod q) / base) % q
+        // v < q < 2^40 and base >= 2: quotients by `base` through mod_u64/div_u64 (no integer division)
+        uint64_t r0 = mod_u64(v, base, inv_base);
+        if (small_q) r0 %= q;
+        r = r0;
+        if (r0 > half) {
+          r = base - r0;                  // 0 < r0 < base here, so (base - r0) % base == base - r0
+          if (small_q) r %= q;
+        }
+        v = div_u64(submod(v, r, q), base, inv_base);
+        if (small_q) v %= q;
       }
       const size_t e = i / D;
       out[(((e / group) * exp + k) * group + e % group) * D + i % D] = r;

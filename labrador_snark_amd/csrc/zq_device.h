@@ -33,7 +33,8 @@ struct LimbTable {
   uint32_t pad[3];
   uint32_t q_hi_mul;     // 2^32 mod p, used to fold 64-bit coefficients: x = hi*2^32+lo
   uint32_t q_hi_mul_sh;  // Shoup companion of q_hi_mul
-  uint32_t pad2[6];
+  double inv_p;          // 1.0 / p for the division-free reductions (mod_u64)
+  uint32_t pad2[4];
   // twiddles: index m+i of stage m (m = 1,2,4,...,32), psi^brv(m+i); [k][0]=w, [k][1]=floor(w*2^32/p)
   uint32_t fwd[D][2];
   uint32_t inv[D][2];    // inverse twiddles for Gentleman-Sande, same indexing
@@ -41,6 +42,24 @@ struct LimbTable {
   uint32_t scale_lo[4][2];
   uint32_t scale_hi[4][2];
 };
+
+// x mod m without an integer division: the quotient estimate from one double multiply is off by a few units at most
+// (exactly: by less than 2 + x * 2^-52 / m), the remainder is then fixed up in exact 64-bit arithmetic.  m < 2^62.
+__device__ __forceinline__ uint64_t mod_u64(uint64_t x, uint64_t m, double inv_m) {
+  const uint64_t qh = (uint64_t)((double)x * inv_m);
+  int64_t r = (int64_t)(x - qh * m);
+  while (r < 0) r += (int64_t)m;
+  while (r >= (int64_t)m) r -= (int64_t)m;
+  return (uint64_t)r;
+}
+// floor(x / m) the same way
+__device__ __forceinline__ uint64_t div_u64(uint64_t x, uint64_t m, double inv_m) {
+  uint64_t qh = (uint64_t)((double)x * inv_m);
+  int64_t r = (int64_t)(x - qh * m);
+  while (r < 0) { r += (int64_t)m; qh--; }
+  while (r >= (int64_t)m) { r -= (int64_t)m; qh++; }
+  return qh;
+}
 
 __device__ __forceinline__ uint32_t csub(uint32_t x, uint32_t m) {  // x in [0,2m) -> [0,m)
   return min(x, x - m);
