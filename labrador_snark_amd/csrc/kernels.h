@@ -24,6 +24,13 @@ struct ConstHatView {
   ConstHatView(const HatView& v) : base(v.base), plane_stride(v.plane_stride) {}
 };
 
+// Per-job operands of a launch that serves several independent proofs ("jobs") at once: coefficient-domain arrays are
+// separate allocations (often the caller's), so their device pointers travel by value in the kernel arguments;
+// transform-domain operands live in one arena per basis and are addressed with a job stride (words inside a plane).
+constexpr int MAX_JOBS = 64;
+struct JobPtrs { void* p[MAX_JOBS]; };
+struct JobU64 { uint64_t v[MAX_JOBS]; };
+
 // CRT constants for hat -> coefficient conversion (device resident).
 struct CrtTable {
   uint64_t q;
@@ -42,25 +49,32 @@ struct CrtTable {
 };
 
 // ---- ntt_kernels.hip
+// njobs > 1: job b works on src + b*src_js / dst + b*dst_js (word strides inside a plane)
 hipError_t launch_ntt(bool forward, ConstHatView src, HatView dst, size_t count, int nlimbs, const LimbTable* tabs,
-                      int escale, hipStream_t s);
+                      int escale, hipStream_t s, size_t njobs = 1, size_t src_js = 0, size_t dst_js = 0);
 hipError_t launch_reduce_u64(const uint64_t* coeffs, HatView dst, size_t count, int nlimbs, const LimbTable* tabs,
                              hipStream_t s);
+hipError_t launch_reduce_u64_jobs(const JobPtrs& coeffs, HatView dst, size_t dst_js, size_t count, int nlimbs,
+                                  const LimbTable* tabs, size_t njobs, hipStream_t s);
 hipError_t launch_crt_to_u64(ConstHatView src, uint64_t* coeffs, size_t count, const CrtTable* crt, hipStream_t s);
+hipError_t launch_crt_to_u64_jobs(ConstHatView src, size_t src_js, const JobPtrs& coeffs, size_t count, const CrtTable* crt,
+                                  size_t njobs, hipStream_t s);
 hipError_t launch_synth_fill_u64(uint64_t* coeffs, size_t count, uint64_t seed, uint64_t first_elem, uint64_t bound,
                                  hipStream_t s);
 
 // ---- linalg_kernels.hip
 enum PointwiseOp { PW_MUL = 0, PW_ADD = 1, PW_SUB = 2, PW_MUL_KEEP_SCALE = 3 };
 // out[k] = a[k] (op) b[k] for k < count; PW_MUL returns plain (e=0) products, PW_MUL_KEEP_SCALE leaves the 2^-32 factor.
+// (njobs > 1: job b works on operand + b*<its job stride>, word strides inside a plane — here and below)
 hipError_t launch_pointwise(PointwiseOp op, HatView out, ConstHatView a, ConstHatView b, size_t count, int nlimbs,
-                            const LimbTable* tabs, hipStream_t s);
+                            const LimbTable* tabs, hipStream_t s, size_t njobs = 1, size_t out_js = 0, size_t a_js = 0,
+                            size_t b_js = 0);
 // partial[(m*rows + rho)] = <M[m][rho][:], V[m][:]>   (hat elements, plain scale)
 hipError_t launch_matvec_partial(HatView partial, ConstHatView M, ConstHatView V, size_t nmat, size_t rows,
-                                 size_t cols, int nlimbs, const LimbTable* tabs, hipStream_t s);
+                                 size_t cols, int nlimbs, const LimbTable* tabs, hipStream_t s, size_t njobs = 1, size_t js = 0);
 // out[rho] = sum_{m<nterms} partial[m*rows + rho]
 hipError_t launch_sum_terms(HatView out, ConstHatView partial, size_t nterms, size_t rows, int nlimbs,
-                            const LimbTable* tabs, hipStream_t s);
+                            const LimbTable* tabs, hipStream_t s, size_t njobs = 1, size_t out_js = 0, size_t partial_js = 0);
 const char* matvec_kernel_name();
 // single-limb variants whose matrix residues are stored as u16 (compact last limb of the digit basis)
 hipError_t launch_matvec_partial_u16(uint32_t* partial_plane, const uint16_t* M, const uint32_t* V_plane, size_t nmat,
@@ -116,18 +130,29 @@ hipError_t launch_gram(HatView out, ConstHatView P, ConstHatView S, size_t n, si
 // tiled Gram: partial[chunk][i][k], gram_num_chunks(n) chunks, to be summed with launch_sum_terms(rows = r*r)
 size_t gram_num_chunks(size_t n);
 hipError_t launch_gram_tiled(HatView partial, ConstHatView P, ConstHatView S, size_t n, size_t r, int nlimbs,
-                             const LimbTable* tabs, hipStream_t s);
+                             const LimbTable* tabs, hipStream_t s, size_t njobs = 1, size_t js = 0);
 // partial[chunk*len + rho] = sum_{m in chunk} G[m] * C[m*len + rho]; axpy_num_chunks(nterms) chunks
 size_t axpy_num_chunks(size_t nterms);
 hipError_t launch_axpy_partial(HatView partial, ConstHatView G, ConstHatView C, size_t nterms, size_t len, int nlimbs,
                                const LimbTable* tabs, hipStream_t s);
 hipError_t launch_poly_by_vec(HatView out, ConstHatView poly, ConstHatView v, size_t len, int nlimbs,
-                              const LimbTable* tabs, hipStream_t s);
+                              const LimbTable* tabs, hipStream_t s, size_t njobs = 1, size_t js = 0);
 
 // ---- proof_kernels.hip (coefficient domain, residues mod q as u64)
 hipError_t launch_decompose(uint64_t* out, const uint64_t* in, size_t count, uint64_t q, uint64_t base, int exp,
                             size_t group, hipStream_t s);
 hipError_t launch_gather_upper(uint64_t* out, const uint64_t* in, size_t r, hipStream_t s);
+// the same kernels serving njobs independent proofs per launch (per-job pointers by value, see JobPtrs)
+hipError_t launch_decompose_jobs(const JobPtrs& out, const JobPtrs& in, size_t count, uint64_t q, uint64_t base, int exp,
+                                 size_t group, size_t njobs, hipStream_t s);
+hipError_t launch_gather_upper_jobs(const JobPtrs& out, const JobPtrs& in, size_t r, size_t njobs, hipStream_t s);
+hipError_t launch_lift_i64_jobs(const JobPtrs& out, const JobPtrs& in, size_t n, uint64_t q, size_t njobs, hipStream_t s);
+hipError_t launch_coef_elementwise_jobs(const JobPtrs& out, const JobPtrs& a, const JobPtrs& b, size_t count, uint64_t q,
+                                        const JobU64& s1, int mode, size_t njobs, hipStream_t s);
+hipError_t launch_symmetrize_half_jobs(const JobPtrs& H, const JobPtrs& X, size_t r, uint64_t q, uint64_t inv2, size_t njobs,
+                                       hipStream_t s);
+hipError_t launch_pi_fused_jobs(const JobPtrs& proj, const JobPtrs& W, const JobPtrs& Pi, const JobPtrs& S, const JobPtrs& omega,
+                                size_t n, size_t r, uint64_t q, size_t njobs, hipStream_t s);
 hipError_t launch_lift_i64(uint64_t* out, const int64_t* in, size_t n, uint64_t q, hipStream_t s);
 hipError_t launch_norm_sq(uint64_t* lo, uint64_t* hi, const uint64_t* in, size_t count, hipStream_t s);
 // mode 0: s1*a ; 1: s1*a + b ; 2: a + b ; 3: sigma_inv(a)

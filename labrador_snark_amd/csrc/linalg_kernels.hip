@@ -18,12 +18,14 @@ namespace lab {
 template <int OP>
 __global__ void __launch_bounds__(256)
 k_pointwise(uint32_t* __restrict__ out, size_t out_ps, const uint32_t* __restrict__ a, size_t a_ps,
-            const uint32_t* __restrict__ b, size_t b_ps, size_t nquads, const LimbTable* __restrict__ tabs) {
-  const int limb = blockIdx.y;
+            const uint32_t* __restrict__ b, size_t b_ps, size_t nquads, const LimbTable* __restrict__ tabs, unsigned nlimbs,
+            size_t out_js, size_t a_js, size_t b_js) {
+  const int limb = blockIdx.y % nlimbs;
+  const size_t job = blockIdx.y / nlimbs;
   const uint32_t p = tabs[limb].p, pinv = tabs[limb].pinv, r2 = tabs[limb].r2;
-  const uint4* A = reinterpret_cast<const uint4*>(a + (size_t)limb * a_ps);
-  const uint4* B = reinterpret_cast<const uint4*>(b + (size_t)limb * b_ps);
-  uint4* O = reinterpret_cast<uint4*>(out + (size_t)limb * out_ps);
+  const uint4* A = reinterpret_cast<const uint4*>(a + (size_t)limb * a_ps + job * a_js);
+  const uint4* B = reinterpret_cast<const uint4*>(b + (size_t)limb * b_ps + job * b_js);
+  uint4* O = reinterpret_cast<uint4*>(out + (size_t)limb * out_ps + job * out_js);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < nquads; i += stride) {
@@ -48,15 +50,15 @@ k_pointwise(uint32_t* __restrict__ out, size_t out_ps, const uint32_t* __restric
 }
 
 hipError_t launch_pointwise(PointwiseOp op, HatView out, ConstHatView a, ConstHatView b, size_t count, int nlimbs,
-                            const LimbTable* tabs, hipStream_t s) {
-  if (count == 0) return hipSuccess;
+                            const LimbTable* tabs, hipStream_t s, size_t njobs, size_t out_js, size_t a_js, size_t b_js) {
+  if (count == 0 || njobs == 0) return hipSuccess;
   size_t nquads = count * D / 4;
   unsigned blocks = (unsigned)((nquads + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  dim3 grid(blocks, (unsigned)nlimbs);
+  dim3 grid(blocks, (unsigned)(nlimbs * njobs));
 #define LAUNCH_PW(OPV)                                                                                              \
   hipLaunchKernelGGL(k_pointwise<OPV>, grid, dim3(256), 0, s, out.base, out.plane_stride, a.base, a.plane_stride, \
-                     b.base, b.plane_stride, nquads, tabs)
+                     b.base, b.plane_stride, nquads, tabs, (unsigned)nlimbs, out_js, a_js, b_js)
   switch (op) {
     case PW_MUL: LAUNCH_PW(PW_MUL); break;
     case PW_ADD: LAUNCH_PW(PW_ADD); break;
@@ -122,12 +124,16 @@ template <typename MT, int NB>
 __global__ void __launch_bounds__(64 * MV_WAVES)
 k_matvec_partial(uint32_t* __restrict__ partial, size_t partial_ps, size_t partial_bs, const MT* __restrict__ M, size_t m_ps,
                  const uint32_t* __restrict__ V, size_t v_ps, size_t v_bs, unsigned rows, unsigned cols,
-                 const LimbTable* __restrict__ tabs) {
+                 const LimbTable* __restrict__ tabs, unsigned nlimbs, size_t js) {
   typedef typename Quad<MT>::raw mraw;
   constexpr int ROWS = NB >= 4 ? 2 : MV_ROWS;     // keep the accumulator file at <= 64 x u64 per lane
   constexpr int GROUP = NB >= 4 ? 2 : 4;          // chunks whose loads are issued together
   __shared__ uint32_t red[MV_WAVES][ROWS * NB][D];
-  const int limb = blockIdx.z;
+  const int limb = blockIdx.z % nlimbs;
+  {  // independent jobs (own matrix, vector and output, all `js` words apart inside a plane)
+    const size_t job = blockIdx.z / nlimbs;
+    partial += job * js; M += job * js; V += job * js;
+  }
   const unsigned mat = blockIdx.y;
   const unsigned row0 = blockIdx.x * ROWS;
   const uint32_t p = tabs[limb].p, p2 = tabs[limb].p2, pinv = tabs[limb].pinv, r2 = tabs[limb].r2;
@@ -948,8 +954,9 @@ hipError_t launch_axpy_bcast_u16(int nb, uint32_t* partial_plane, size_t partial
 template <typename MT>
 static hipError_t launch_matvec_nb(int nb, uint32_t* partial, size_t partial_ps, size_t partial_bs, const MT* M, size_t m_ps,
                                    const uint32_t* V, size_t v_ps, size_t v_bs, size_t nmat, size_t rows, size_t cols,
-                                   int nlimbs, const LimbTable* tabs, hipStream_t s) {
-  if (nmat == 0 || rows == 0 || nlimbs == 0) return hipSuccess;
+                                   int nlimbs, const LimbTable* tabs, hipStream_t s, size_t njobs = 1, size_t js = 0) {
+  if (nmat == 0 || rows == 0 || nlimbs == 0 || njobs == 0) return hipSuccess;
+  if (njobs > 1 && nb != 1) return hipErrorInvalidValue;   // jobs are served by the single-set kernel only
   if (nb > 1 && rows >= (size_t)BC_ROWS / 2 && (v_bs % 4) == 0 && cols % BC_COLS == 0 &&
       (uint64_t)(64 * cols + 2) * 256 < (1ull << 32) && v_bs * 8 < (1ull << 32)) {  // ... tiles by LDS-DMA
     dim3 g((unsigned)((rows + BC_ROWS - 1) / BC_ROWS), (unsigned)nmat, (unsigned)nlimbs);
@@ -997,10 +1004,10 @@ static hipError_t launch_matvec_nb(int nb, uint32_t* partial, size_t partial_ps,
   }
   if (sizeof(MT) == 4) set_last_matvec_kernel(nb == 1 ? "k_matvec_partial<unsigned int, 1>" : nb == 2 ? "k_matvec_partial<unsigned int, 2>" : nb == 4 ? "k_matvec_partial<unsigned int, 4>" : "k_matvec_partial<unsigned int, 8>");
   const unsigned rpb = nb >= 4 ? 2 : MV_ROWS;
-  dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)nmat, (unsigned)nlimbs), block(64 * MV_WAVES);
+  dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)nmat, (unsigned)(nlimbs * njobs)), block(64 * MV_WAVES);
 #define LAB_MV(NBV)                                                                                                  \
   hipLaunchKernelGGL((k_matvec_partial<MT, NBV>), grid, block, 0, s, partial, partial_ps, partial_bs, M, m_ps, V, v_ps, \
-                     v_bs, (unsigned)rows, (unsigned)cols, tabs)
+                     v_bs, (unsigned)rows, (unsigned)cols, tabs, (unsigned)nlimbs, js)
   switch (nb) {
     case 1: LAB_MV(1); break;
     case 2: LAB_MV(2); break;
@@ -1019,9 +1026,9 @@ const char* matvec_kernel_name() { return g_last_matvec_kernel; }
 static void set_last_matvec_kernel(const char* n) { g_last_matvec_kernel = n; }
 
 hipError_t launch_matvec_partial(HatView partial, ConstHatView M, ConstHatView V, size_t nmat, size_t rows,
-                                 size_t cols, int nlimbs, const LimbTable* tabs, hipStream_t s) {
+                                 size_t cols, int nlimbs, const LimbTable* tabs, hipStream_t s, size_t njobs, size_t js) {
   return launch_matvec_nb<uint32_t>(1, partial.base, partial.plane_stride, 0, M.base, M.plane_stride, V.base,
-                                    V.plane_stride, 0, nmat, rows, cols, nlimbs, tabs, s);
+                                    V.plane_stride, 0, nmat, rows, cols, nlimbs, tabs, s, njobs, js);
 }
 
 // one limb whose matrix residues are stored as u16 (`tab` = that limb's table; partial/V already offset to its plane)
@@ -1046,10 +1053,13 @@ hipError_t launch_matvec_partial_batched_u16(int nb, uint32_t* partial_plane, si
 // out[rho][j] = sum_m partial[m][rho][j] mod p
 __global__ void __launch_bounds__(256)
 k_sum_terms(uint32_t* __restrict__ out, size_t out_ps, const uint32_t* __restrict__ partial, size_t partial_ps,
-            unsigned nterms, size_t row_words, const LimbTable* __restrict__ tabs) {
-  const int limb = blockIdx.y;
+            unsigned nterms, size_t row_words, const LimbTable* __restrict__ tabs, unsigned nlimbs, size_t out_js,
+            size_t partial_js) {
+  const int limb = blockIdx.y % nlimbs;
+  const size_t job = blockIdx.y / nlimbs;
   const uint32_t p = tabs[limb].p;
-  const uint32_t* P = partial + (size_t)limb * partial_ps;
+  const uint32_t* P = partial + (size_t)limb * partial_ps + job * partial_js;
+  out += job * out_js;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < row_words; i += stride) {
@@ -1068,13 +1078,13 @@ k_sum_terms(uint32_t* __restrict__ out, size_t out_ps, const uint32_t* __restric
 }
 
 hipError_t launch_sum_terms(HatView out, ConstHatView partial, size_t nterms, size_t rows, int nlimbs,
-                            const LimbTable* tabs, hipStream_t s) {
-  if (rows == 0) return hipSuccess;
+                            const LimbTable* tabs, hipStream_t s, size_t njobs, size_t out_js, size_t partial_js) {
+  if (rows == 0 || njobs == 0) return hipSuccess;
   size_t row_words = rows * D;
   unsigned blocks = (unsigned)((row_words + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_sum_terms, dim3(blocks, (unsigned)nlimbs), dim3(256), 0, s, out.base, out.plane_stride,
-                     partial.base, partial.plane_stride, (unsigned)nterms, row_words, tabs);
+  hipLaunchKernelGGL(k_sum_terms, dim3(blocks, (unsigned)(nlimbs * njobs)), dim3(256), 0, s, out.base, out.plane_stride,
+                     partial.base, partial.plane_stride, (unsigned)nterms, row_words, tabs, (unsigned)nlimbs, out_js, partial_js);
   return hipGetLastError();
 }
 
@@ -1364,12 +1374,14 @@ hipError_t launch_pack_u16(uint16_t* dst, const uint32_t* src, size_t count, boo
 // out[k] = poly * v[k]  (poly_by_poly_vec, src/util.rs:289-296); plain products
 __global__ void __launch_bounds__(256)
 k_poly_by_vec(uint32_t* __restrict__ out, size_t out_ps, const uint32_t* __restrict__ poly, size_t poly_ps,
-              const uint32_t* __restrict__ v, size_t v_ps, size_t nquads, const LimbTable* __restrict__ tabs) {
-  const int limb = blockIdx.y;
+              const uint32_t* __restrict__ v, size_t v_ps, size_t nquads, const LimbTable* __restrict__ tabs, unsigned nlimbs,
+              size_t js) {
+  const int limb = blockIdx.y % nlimbs;
+  const size_t job = blockIdx.y / nlimbs;
   const uint32_t p = tabs[limb].p, pinv = tabs[limb].pinv, r2 = tabs[limb].r2;
-  const uint4* Pq = reinterpret_cast<const uint4*>(poly + (size_t)limb * poly_ps);
-  const uint4* Vq = reinterpret_cast<const uint4*>(v + (size_t)limb * v_ps);
-  uint4* O = reinterpret_cast<uint4*>(out + (size_t)limb * out_ps);
+  const uint4* Pq = reinterpret_cast<const uint4*>(poly + (size_t)limb * poly_ps + job * js);
+  const uint4* Vq = reinterpret_cast<const uint4*>(v + (size_t)limb * v_ps + job * js);
+  uint4* O = reinterpret_cast<uint4*>(out + (size_t)limb * out_ps + job * js);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < nquads; i += stride) {
@@ -1384,13 +1396,13 @@ k_poly_by_vec(uint32_t* __restrict__ out, size_t out_ps, const uint32_t* __restr
 }
 
 hipError_t launch_poly_by_vec(HatView out, ConstHatView poly, ConstHatView v, size_t len, int nlimbs,
-                              const LimbTable* tabs, hipStream_t s) {
-  if (len == 0) return hipSuccess;
+                              const LimbTable* tabs, hipStream_t s, size_t njobs, size_t js) {
+  if (len == 0 || njobs == 0) return hipSuccess;
   size_t nquads = len * D / 4;
   unsigned blocks = (unsigned)((nquads + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_poly_by_vec, dim3(blocks, (unsigned)nlimbs), dim3(256), 0, s, out.base, out.plane_stride,
-                     poly.base, poly.plane_stride, v.base, v.plane_stride, nquads, tabs);
+  hipLaunchKernelGGL(k_poly_by_vec, dim3(blocks, (unsigned)(nlimbs * njobs)), dim3(256), 0, s, out.base, out.plane_stride,
+                     poly.base, poly.plane_stride, v.base, v.plane_stride, nquads, tabs, (unsigned)nlimbs, js);
   return hipGetLastError();
 }
 
@@ -1407,8 +1419,10 @@ constexpr int GR_CHUNK = 64;
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3)))
 k_gram_tiled(uint32_t* __restrict__ partial, size_t partial_ps, const uint32_t* __restrict__ P, size_t p_ps,
              const uint32_t* __restrict__ S, size_t s_ps, unsigned n, unsigned r, unsigned nchunks,
-             const LimbTable* __restrict__ tabs) {
-  const unsigned limb = blockIdx.z / nchunks, chunk = blockIdx.z % nchunks;
+             const LimbTable* __restrict__ tabs, unsigned nlimbs, size_t js) {
+  const unsigned limb = (blockIdx.z / nchunks) % nlimbs, chunk = blockIdx.z % nchunks;
+  const size_t job = blockIdx.z / (nchunks * nlimbs);
+  partial += job * js; P += job * js; S += job * js;
   const uint32_t p = tabs[limb].p, p2 = tabs[limb].p2, pinv = tabs[limb].pinv, r2 = tabs[limb].r2;
   const int j = threadIdx.x;
   const unsigned i0 = blockIdx.x * MM_RT;
@@ -1480,14 +1494,14 @@ k_gram_tiled(uint32_t* __restrict__ partial, size_t partial_ps, const uint32_t* 
 size_t gram_num_chunks(size_t n) { return (n + GR_CHUNK - 1) / GR_CHUNK; }
 
 hipError_t launch_gram_tiled(HatView partial, ConstHatView P, ConstHatView S, size_t n, size_t r, int nlimbs,
-                             const LimbTable* tabs, hipStream_t s) {
-  if (r == 0 || n == 0) return hipSuccess;
+                             const LimbTable* tabs, hipStream_t s, size_t njobs, size_t js) {
+  if (r == 0 || n == 0 || njobs == 0) return hipSuccess;
   const unsigned nchunks = (unsigned)gram_num_chunks(n);
   unsigned kgroups = (unsigned)((r + MM_CT - 1) / MM_CT);
   unsigned wy = kgroups < 4 ? kgroups : 4;
-  dim3 grid((unsigned)((r + MM_RT - 1) / MM_RT), (kgroups + wy - 1) / wy, (unsigned)nlimbs * nchunks);
+  dim3 grid((unsigned)((r + MM_RT - 1) / MM_RT), (kgroups + wy - 1) / wy, (unsigned)(nlimbs * nchunks * njobs));
   hipLaunchKernelGGL(k_gram_tiled, grid, dim3(64, wy), 0, s, partial.base, partial.plane_stride, P.base,
-                     P.plane_stride, S.base, S.plane_stride, (unsigned)n, (unsigned)r, nchunks, tabs);
+                     P.plane_stride, S.base, S.plane_stride, (unsigned)n, (unsigned)r, nchunks, tabs, (unsigned)nlimbs, js);
   return hipGetLastError();
 }
 

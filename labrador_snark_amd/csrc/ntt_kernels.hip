@@ -16,28 +16,28 @@ namespace lab {
 template <bool FWD>
 __global__ void __launch_bounds__(64)
 k_ntt64(const uint32_t* __restrict__ src, size_t src_ps, uint32_t* __restrict__ dst, size_t dst_ps, size_t count,
-        const LimbTable* __restrict__ tabs, int escale) {
+        const LimbTable* __restrict__ tabs, int escale, size_t src_js, size_t dst_js) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[TILE_WORDS];
   const int limb = blockIdx.y;
   const LimbTable* tab = tabs + limb;
   const size_t base = (size_t)blockIdx.x * 64;
   const int lane = threadIdx.x;
   uint32_t x[D];
-  tile_load_u32(x, src + (size_t)limb * src_ps, base, count, lds, lane);
+  tile_load_u32(x, src + (size_t)limb * src_ps + (size_t)blockIdx.z * src_js, base, count, lds, lane);
   if (FWD) ntt64_forward(x, tab); else ntt64_inverse(x, tab, escale);
-  tile_store_u32(x, dst + (size_t)limb * dst_ps, base, count, lds, lane);
+  tile_store_u32(x, dst + (size_t)limb * dst_ps + (size_t)blockIdx.z * dst_js, base, count, lds, lane);
 }
 
 hipError_t launch_ntt(bool forward, ConstHatView src, HatView dst, size_t count, int nlimbs, const LimbTable* tabs,
-                      int escale, hipStream_t s) {
-  if (count == 0) return hipSuccess;
-  dim3 grid((unsigned)((count + 63) / 64), (unsigned)nlimbs);
+                      int escale, hipStream_t s, size_t njobs, size_t src_js, size_t dst_js) {
+  if (count == 0 || njobs == 0) return hipSuccess;
+  dim3 grid((unsigned)((count + 63) / 64), (unsigned)nlimbs, (unsigned)njobs);
   if (forward)
     hipLaunchKernelGGL(k_ntt64<true>, grid, dim3(64), 0, s, src.base, src.plane_stride, dst.base, dst.plane_stride,
-                       count, tabs, escale);
+                       count, tabs, escale, src_js, dst_js);
   else
     hipLaunchKernelGGL(k_ntt64<false>, grid, dim3(64), 0, s, src.base, src.plane_stride, dst.base, dst.plane_stride,
-                       count, tabs, escale);
+                       count, tabs, escale, src_js, dst_js);
   return hipGetLastError();
 }
 
@@ -59,8 +59,10 @@ __device__ __forceinline__ uint32_t reduce_u40(uint64_t v, const LimbTable& tb) 
 }
 
 __global__ void __launch_bounds__(256)
-k_reduce_u64(const uint64_t* __restrict__ coeffs, uint32_t* __restrict__ dst, size_t dst_ps, size_t nwords,
-             int nlimbs, const LimbTable* __restrict__ tabs) {
+k_reduce_u64(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, size_t nwords,
+             int nlimbs, const LimbTable* __restrict__ tabs, size_t dst_js) {
+  const uint64_t* __restrict__ coeffs = static_cast<const uint64_t*>(src.p[blockIdx.y]);
+  dst += (size_t)blockIdx.y * dst_js;
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
   const size_t stride = (size_t)gridDim.x * blockDim.x * 2;
   for (; i < nwords; i += stride) {
@@ -71,15 +73,22 @@ k_reduce_u64(const uint64_t* __restrict__ coeffs, uint32_t* __restrict__ dst, si
   }
 }
 
-hipError_t launch_reduce_u64(const uint64_t* coeffs, HatView dst, size_t count, int nlimbs, const LimbTable* tabs,
-                             hipStream_t s) {
-  if (count == 0) return hipSuccess;
+hipError_t launch_reduce_u64_jobs(const JobPtrs& coeffs, HatView dst, size_t dst_js, size_t count, int nlimbs,
+                                  const LimbTable* tabs, size_t njobs, hipStream_t s) {
+  if (count == 0 || njobs == 0) return hipSuccess;
   size_t nwords = count * D;
   unsigned blocks = (unsigned)((nwords / 2 + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_reduce_u64, dim3(blocks), dim3(256), 0, s, coeffs, dst.base, dst.plane_stride, nwords, nlimbs,
-                     tabs);
+  hipLaunchKernelGGL(k_reduce_u64, dim3(blocks, (unsigned)njobs), dim3(256), 0, s, coeffs, dst.base, dst.plane_stride, nwords,
+                     nlimbs, tabs, dst_js);
   return hipGetLastError();
+}
+
+hipError_t launch_reduce_u64(const uint64_t* coeffs, HatView dst, size_t count, int nlimbs, const LimbTable* tabs,
+                             hipStream_t s) {
+  JobPtrs t;
+  t.p[0] = const_cast<uint64_t*>(coeffs);
+  return launch_reduce_u64_jobs(t, dst, 0, count, nlimbs, tabs, 1, s);
 }
 
 __device__ __forceinline__ uint64_t mulmod_q(uint32_t d, uint64_t c, uint64_t q, double inv_q) {
@@ -95,8 +104,10 @@ __device__ __forceinline__ uint64_t mulmod_q(uint32_t d, uint64_t c, uint64_t q,
 // The integer being reconstructed is the exact negacyclic result; it lies in
 // (-M/2, M/2), which lab_ctx guarantees through max_len.  No integer divisions: see mod_u64.
 __global__ void __launch_bounds__(256)
-k_crt_to_u64(const uint32_t* __restrict__ src, size_t src_ps, uint64_t* __restrict__ coeffs, size_t nwords,
-             const CrtTable* __restrict__ crt) {
+k_crt_to_u64(const uint32_t* __restrict__ src, size_t src_ps, const JobPtrs dstp, size_t nwords,
+             const CrtTable* __restrict__ crt, size_t src_js) {
+  uint64_t* __restrict__ coeffs = static_cast<uint64_t*>(dstp.p[blockIdx.y]);
+  src += (size_t)blockIdx.y * src_js;
   const int L = crt->nlimbs;
   const uint64_t q = crt->q;
   const double inv_q = crt->inv_q;
@@ -134,13 +145,21 @@ k_crt_to_u64(const uint32_t* __restrict__ src, size_t src_ps, uint64_t* __restri
   }
 }
 
-hipError_t launch_crt_to_u64(ConstHatView src, uint64_t* coeffs, size_t count, const CrtTable* crt, hipStream_t s) {
-  if (count == 0) return hipSuccess;
+hipError_t launch_crt_to_u64_jobs(ConstHatView src, size_t src_js, const JobPtrs& coeffs, size_t count, const CrtTable* crt,
+                                  size_t njobs, hipStream_t s) {
+  if (count == 0 || njobs == 0) return hipSuccess;
   size_t nwords = count * D;
   unsigned blocks = (unsigned)((nwords + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(k_crt_to_u64, dim3(blocks), dim3(256), 0, s, src.base, src.plane_stride, coeffs, nwords, crt);
+  hipLaunchKernelGGL(k_crt_to_u64, dim3(blocks, (unsigned)njobs), dim3(256), 0, s, src.base, src.plane_stride, coeffs, nwords, crt,
+                     src_js);
   return hipGetLastError();
+}
+
+hipError_t launch_crt_to_u64(ConstHatView src, uint64_t* coeffs, size_t count, const CrtTable* crt, hipStream_t s) {
+  JobPtrs t;
+  t.p[0] = coeffs;
+  return launch_crt_to_u64_jobs(src, 0, t, count, crt, 1, s);
 }
 
 __global__ void __launch_bounds__(256)

@@ -24,8 +24,9 @@ __device__ __forceinline__ uint64_t submod(uint64_t a, uint64_t b, uint64_t q) {
 // group = count gives the reference's [exp][count] layout, group = 1 gives
 // [count][exp], group = kappa gives [i][k][rho] for the t_i decomposition.
 __global__ void __launch_bounds__(256)
-k_decompose(uint64_t* __restrict__ out, const uint64_t* __restrict__ in, size_t nwords, uint64_t q, uint64_t base,
-            int exp, size_t group) {
+k_decompose(const JobPtrs outp, const JobPtrs inp, size_t nwords, uint64_t q, uint64_t base, int exp, size_t group) {
+  uint64_t* __restrict__ out = static_cast<uint64_t*>(outp.p[blockIdx.y]);
+  const uint64_t* __restrict__ in = static_cast<const uint64_t*>(inp.p[blockIdx.y]);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const uint64_t half = (base / 2) % q;  // `val > b/2` compares with mod_positive(b/2, Q) (algebraic.rs:293-297)
@@ -54,14 +55,22 @@ k_decompose(uint64_t* __restrict__ out, const uint64_t* __restrict__ in, size_t 
   }
 }
 
-hipError_t launch_decompose(uint64_t* out, const uint64_t* in, size_t count, uint64_t q, uint64_t base, int exp,
-                            size_t group, hipStream_t s) {
-  if (count == 0 || exp == 0) return hipSuccess;
+hipError_t launch_decompose_jobs(const JobPtrs& out, const JobPtrs& in, size_t count, uint64_t q, uint64_t base, int exp,
+                                 size_t group, size_t njobs, hipStream_t s) {
+  if (count == 0 || exp == 0 || njobs == 0) return hipSuccess;
   size_t nwords = count * D;
   unsigned blocks = (unsigned)((nwords + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_decompose, dim3(blocks), dim3(256), 0, s, out, in, nwords, q, base, exp, group);
+  hipLaunchKernelGGL(k_decompose, dim3(blocks, (unsigned)njobs), dim3(256), 0, s, out, in, nwords, q, base, exp, group);
   return hipGetLastError();
+}
+
+hipError_t launch_decompose(uint64_t* out, const uint64_t* in, size_t count, uint64_t q, uint64_t base, int exp,
+                            size_t group, hipStream_t s) {
+  JobPtrs o, i;
+  o.p[0] = out;
+  i.p[0] = const_cast<uint64_t*>(in);
+  return launch_decompose_jobs(o, i, count, q, base, exp, group, 1, s);
 }
 
 // ---- poly_norm (src/util.rs:195-202): exact sum of squares of the RAW residues
@@ -100,8 +109,11 @@ hipError_t launch_norm_sq(uint64_t* lo, uint64_t* hi, const uint64_t* in, size_t
 // mode 2: out = a + b
 // mode 3: out = sigma_inv(a) per polynomial (src/util.rs:118-137)
 __global__ void __launch_bounds__(256)
-k_coef_elementwise(uint64_t* __restrict__ out, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b,
-                   size_t nwords, uint64_t q, uint64_t s1, int mode) {
+k_coef_elementwise(const JobPtrs outp, const JobPtrs ap, const JobPtrs bp, size_t nwords, uint64_t q, const JobU64 s1v, int mode) {
+  uint64_t* __restrict__ out = static_cast<uint64_t*>(outp.p[blockIdx.y]);
+  const uint64_t* __restrict__ a = static_cast<const uint64_t*>(ap.p[blockIdx.y]);
+  const uint64_t* __restrict__ b = static_cast<const uint64_t*>(bp.p[blockIdx.y]);
+  const uint64_t s1 = s1v.v[blockIdx.y];
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < nwords; i += stride) {
@@ -118,19 +130,29 @@ k_coef_elementwise(uint64_t* __restrict__ out, const uint64_t* __restrict__ a, c
   }
 }
 
-hipError_t launch_coef_elementwise(uint64_t* out, const uint64_t* a, const uint64_t* b, size_t count, uint64_t q,
-                                   uint64_t s1, int mode, hipStream_t s) {
-  if (count == 0) return hipSuccess;
+hipError_t launch_coef_elementwise_jobs(const JobPtrs& out, const JobPtrs& a, const JobPtrs& b, size_t count, uint64_t q,
+                                        const JobU64& s1, int mode, size_t njobs, hipStream_t s) {
+  if (count == 0 || njobs == 0) return hipSuccess;
   size_t nwords = count * D;
   unsigned blocks = (unsigned)((nwords + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_coef_elementwise, dim3(blocks), dim3(256), 0, s, out, a, b, nwords, q, s1, mode);
+  hipLaunchKernelGGL(k_coef_elementwise, dim3(blocks, (unsigned)njobs), dim3(256), 0, s, out, a, b, nwords, q, s1, mode);
   return hipGetLastError();
+}
+
+hipError_t launch_coef_elementwise(uint64_t* out, const uint64_t* a, const uint64_t* b, size_t count, uint64_t q,
+                                   uint64_t s1, int mode, hipStream_t s) {
+  JobPtrs o, pa, pb;
+  JobU64 sv;
+  o.p[0] = out; pa.p[0] = const_cast<uint64_t*>(a); pb.p[0] = const_cast<uint64_t*>(b); sv.v[0] = s1;
+  return launch_coef_elementwise_jobs(o, pa, pb, count, q, sv, mode, 1, s);
 }
 
 // H[i][k] = inv2 * (X[i][k] + X[k][i])   (src/proofgen.rs:334-350), X: [r][r][64]
 __global__ void __launch_bounds__(256)
-k_symmetrize_half(uint64_t* __restrict__ H, const uint64_t* __restrict__ X, unsigned r, uint64_t q, uint64_t inv2) {
+k_symmetrize_half(const JobPtrs Hp, const JobPtrs Xp, unsigned r, uint64_t q, uint64_t inv2) {
+  uint64_t* __restrict__ H = static_cast<uint64_t*>(Hp.p[blockIdx.y]);
+  const uint64_t* __restrict__ X = static_cast<const uint64_t*>(Xp.p[blockIdx.y]);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t n = (size_t)r * r * D;
   if (i >= n) return;
@@ -139,16 +161,25 @@ k_symmetrize_half(uint64_t* __restrict__ H, const uint64_t* __restrict__ X, unsi
   H[i] = mulmod40(s, inv2, q);
 }
 
-hipError_t launch_symmetrize_half(uint64_t* H, const uint64_t* X, size_t r, uint64_t q, uint64_t inv2, hipStream_t s) {
-  if (r == 0) return hipSuccess;
+hipError_t launch_symmetrize_half_jobs(const JobPtrs& H, const JobPtrs& X, size_t r, uint64_t q, uint64_t inv2, size_t njobs,
+                                       hipStream_t s) {
+  if (r == 0 || njobs == 0) return hipSuccess;
   size_t n = r * r * D;
-  hipLaunchKernelGGL(k_symmetrize_half, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, H, X, (unsigned)r, q, inv2);
+  hipLaunchKernelGGL(k_symmetrize_half, dim3((unsigned)((n + 255) / 256), (unsigned)njobs), dim3(256), 0, s, H, X, (unsigned)r, q, inv2);
   return hipGetLastError();
+}
+
+hipError_t launch_symmetrize_half(uint64_t* H, const uint64_t* X, size_t r, uint64_t q, uint64_t inv2, hipStream_t s) {
+  JobPtrs h, x;
+  h.p[0] = H; x.p[0] = const_cast<uint64_t*>(X);
+  return launch_symmetrize_half_jobs(h, x, r, q, inv2, 1, s);
 }
 
 // upper triangle (i <= j) of an [r][r][64] array in pair order i*r - i(i-1)/2 + (j-i) (src/structs.rs:101-106)
 __global__ void __launch_bounds__(256)
-k_gather_upper(uint64_t* __restrict__ out, const uint64_t* __restrict__ in, unsigned r) {
+k_gather_upper(const JobPtrs outp, const JobPtrs inp, unsigned r) {
+  uint64_t* __restrict__ out = static_cast<uint64_t*>(outp.p[blockIdx.y]);
+  const uint64_t* __restrict__ in = static_cast<const uint64_t*>(inp.p[blockIdx.y]);
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t n = (size_t)r * r * D;
   if (idx >= n) return;
@@ -158,15 +189,23 @@ k_gather_upper(uint64_t* __restrict__ out, const uint64_t* __restrict__ in, unsi
   out[pair * D + c] = in[idx];
 }
 
-hipError_t launch_gather_upper(uint64_t* out, const uint64_t* in, size_t r, hipStream_t s) {
-  if (r == 0) return hipSuccess;
+hipError_t launch_gather_upper_jobs(const JobPtrs& out, const JobPtrs& in, size_t r, size_t njobs, hipStream_t s) {
+  if (r == 0 || njobs == 0) return hipSuccess;
   size_t n = r * r * D;
-  hipLaunchKernelGGL(k_gather_upper, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, in, (unsigned)r);
+  hipLaunchKernelGGL(k_gather_upper, dim3((unsigned)((n + 255) / 256), (unsigned)njobs), dim3(256), 0, s, out, in, (unsigned)r);
   return hipGetLastError();
 }
 
+hipError_t launch_gather_upper(uint64_t* out, const uint64_t* in, size_t r, hipStream_t s) {
+  JobPtrs o, i;
+  o.p[0] = out; i.p[0] = const_cast<uint64_t*>(in);
+  return launch_gather_upper_jobs(o, i, r, 1, s);
+}
+
 // proj[m] mod q (Zq::lift, src/proofgen.rs:186)
-__global__ void k_lift_i64(uint64_t* __restrict__ out, const int64_t* __restrict__ in, unsigned n, uint64_t q) {
+__global__ void k_lift_i64(const JobPtrs outp, const JobPtrs inp, unsigned n, uint64_t q) {
+  uint64_t* __restrict__ out = static_cast<uint64_t*>(outp.p[blockIdx.y]);
+  const int64_t* __restrict__ in = static_cast<const int64_t*>(inp.p[blockIdx.y]);
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int64_t v = in[i];
@@ -174,10 +213,16 @@ __global__ void k_lift_i64(uint64_t* __restrict__ out, const int64_t* __restrict
   out[i] = v < 0 ? (m == 0 ? 0 : q - m) : m;
 }
 
-hipError_t launch_lift_i64(uint64_t* out, const int64_t* in, size_t n, uint64_t q, hipStream_t s) {
-  if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_lift_i64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, in, (unsigned)n, q);
+hipError_t launch_lift_i64_jobs(const JobPtrs& out, const JobPtrs& in, size_t n, uint64_t q, size_t njobs, hipStream_t s) {
+  if (n == 0 || njobs == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_lift_i64, dim3((unsigned)((n + 255) / 256), (unsigned)njobs), dim3(256), 0, s, out, in, (unsigned)n, q);
   return hipGetLastError();
+}
+
+hipError_t launch_lift_i64(uint64_t* out, const int64_t* in, size_t n, uint64_t q, hipStream_t s) {
+  JobPtrs o, i;
+  o.p[0] = out; i.p[0] = const_cast<int64_t*>(in);
+  return launch_lift_i64_jobs(o, i, n, q, 1, s);
 }
 
 // ---- JL projection (src/proofgen.rs:429-456, src/util.rs:511-526):
@@ -369,8 +414,13 @@ __device__ __forceinline__ int wave_sum_to_lane63(int x) {
 // Every product is (entry in {-1,0,1}) x (20-bit half of a value < 2^40), and every sum of them stays below 2^31
 // (row part: 16 columns x 64 lanes x 2^20; column part: 256 rows x 2^20), so all accumulation is v_mad_i32_i24.
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
-k_pi_fused(unsigned long long* __restrict__ proj, uint64_t* __restrict__ W, const int8_t* __restrict__ Pi,
-           const uint64_t* __restrict__ S, const uint64_t* __restrict__ omega, unsigned n, unsigned r, uint64_t q) {
+k_pi_fused(const JobPtrs projp, const JobPtrs Wp, const JobPtrs Pip, const JobPtrs Sp, const JobPtrs omegap, unsigned n,
+           unsigned r, uint64_t q) {
+  unsigned long long* __restrict__ proj = static_cast<unsigned long long*>(projp.p[blockIdx.z]);
+  uint64_t* __restrict__ W = static_cast<uint64_t*>(Wp.p[blockIdx.z]);
+  const int8_t* __restrict__ Pi = static_cast<const int8_t*>(Pip.p[blockIdx.z]);
+  const uint64_t* __restrict__ S = static_cast<const uint64_t*>(Sp.p[blockIdx.z]);
+  const uint64_t* __restrict__ omega = static_cast<const uint64_t*>(omegap.p[blockIdx.z]);
   constexpr int GR = 4;                      // rows per load group
   __shared__ int om_lo[256], om_hi[256];
   __shared__ long long rowsum[4][256];
@@ -450,13 +500,21 @@ k_pi_fused(unsigned long long* __restrict__ proj, uint64_t* __restrict__ W, cons
   }
 }
 
+hipError_t launch_pi_fused_jobs(const JobPtrs& proj /*zeroed*/, const JobPtrs& W, const JobPtrs& Pi, const JobPtrs& S,
+                                const JobPtrs& omega, size_t n, size_t r, uint64_t q, size_t njobs, hipStream_t s) {
+  if (n == 0 || r == 0 || njobs == 0) return hipSuccess;
+  const size_t cols = n * D;
+  hipLaunchKernelGGL(k_pi_fused, dim3((unsigned)((cols + 4095) / 4096), (unsigned)r, (unsigned)njobs), dim3(256), 0, s, proj, W, Pi, S,
+                     omega, (unsigned)n, (unsigned)r, q);
+  return hipGetLastError();
+}
+
 hipError_t launch_pi_fused(int64_t* proj /*zeroed*/, uint64_t* W, const int8_t* Pi, const uint64_t* S,
                            const uint64_t* omega, size_t n, size_t r, uint64_t q, hipStream_t s) {
-  if (n == 0 || r == 0) return hipSuccess;
-  const size_t cols = n * D;
-  hipLaunchKernelGGL(k_pi_fused, dim3((unsigned)((cols + 4095) / 4096), (unsigned)r), dim3(256), 0, s,
-                     reinterpret_cast<unsigned long long*>(proj), W, Pi, S, omega, (unsigned)n, (unsigned)r, q);
-  return hipGetLastError();
+  JobPtrs p, w, pi, sp, om;
+  p.p[0] = proj; w.p[0] = W; pi.p[0] = const_cast<int8_t*>(Pi); sp.p[0] = const_cast<uint64_t*>(S);
+  om.p[0] = const_cast<uint64_t*>(omega);
+  return launch_pi_fused_jobs(p, w, pi, sp, om, n, r, q, 1, s);
 }
 
 }  // namespace lab

@@ -20,6 +20,7 @@ typedef unsigned __int128 u128;
 namespace lab {
 int axpy_commit_impl(lab_ctx* c, HatView out, ConstHatView G, ConstHatView C, size_t nterms, size_t len, HatView partial);
 int inner_product_impl(lab_ctx* c, HatView out, ConstHatView v1, ConstHatView v2, size_t len, HatView partial);
+size_t inner_product_splits(size_t len);
 }
 
 namespace {
@@ -67,6 +68,16 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if (!ins || !outs) return fail(c, LAB_ERR_ARG, "lab_prove_core: null argument");
   for (size_t j = 0; j < np; j++)
     if (!ins[j] || !outs[j]) return fail(c, LAB_ERR_ARG, "lab_prove_core: null argument");
+  if (np > (size_t)MAX_JOBS) {   // the per-proof kernels serve up to MAX_JOBS proofs per launch
+    int first = LAB_OK;
+    for (size_t j0 = 0; j0 < np; j0 += MAX_JOBS) {
+      const size_t m = np - j0 < (size_t)MAX_JOBS ? np - j0 : (size_t)MAX_JOBS;
+      const int e = prove_batch_impl(c, m, ins + j0, outs + j0, status ? status + j0 : nullptr);
+      if (e != LAB_OK && first == LAB_OK) first = e;
+      if (e != LAB_OK && e != LAB_ERR_JL_REJECTED && e != LAB_ERR_BPP_CHECK) return e;
+    }
+    return first;
+  }
   const lab_prove_input* in = ins[0];
   const size_t n = in->n, r = in->r, kappa = in->kappa, k1 = in->kappa1, k2 = in->kappa2;
   const int t1 = in->t1, t2 = in->t2;
@@ -150,7 +161,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
                             pairs /*cHup*/ + pairs * t1 /*cHdec*/ + k1 /*cu1*/ + k2 /*cu2*/ + n /*cz*/ + 1 /*cbpp*/ +
                             2 /*cab*/;
   size_t bytes = Carver::padded((size_t)L * hat_words * 4) + Carver::padded((size_t)Ld * hatd_words * 4) +
-                 Carver::padded((size_t)L * tmp_elems * D * 4) +
+                 Carver::padded(np * (size_t)L * tmp_elems * D * 4) +
                  np * (coef_elems * (D * 8) + 32 * 256 /*alignment padding of the carves*/ + 3 * 4096 /*proj*/);
   for (size_t j = 0; j < np; j++) {
     const lab_prove_input* x = ins[j];
@@ -170,13 +181,14 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   uint32_t* hat_base = cv.take<uint32_t>((size_t)L * hat_words);
   uint32_t* hatd_base = cv.take<uint32_t>((size_t)Ld * hatd_words);
   // from_hat scratch: a dense [L][count][64] buffer (its plane stride is count*64, not the arena's)
-  uint32_t* dense_tmp = cv.take<uint32_t>((size_t)L * tmp_elems * D);
+  uint32_t* dense_tmp = cv.take<uint32_t>(np * (size_t)L * tmp_elems * D);   // job j: + j * L*tmp_elems*64 words
   auto HV = [&](size_t j, size_t off) { return HatView{hat_base + (j * per + off) * D, hat_words}; };
   auto HD = [&](size_t j, size_t off) { return HatView{hatd_base + (j * perd + off) * D, hatd_words}; };
   auto CO = [&](size_t elems) { return cv.take<uint64_t>(elems * D); };
   // results the caller wants in device memory are produced in place (no staging copy)
   auto OUT = [&](uint64_t* user, size_t elems) { return (user && is_device_pointer(user)) ? user : CO(elems); };
   std::vector<Job> jobs(np);
+  int64_t* proj_all = cv.take<int64_t>(np * 256);   // contiguous: one memset for the batch
   Staging st(c, &cv);  // inputs only (no pending outputs are registered on it)
   for (size_t j = 0; j < np; j++) {
     Job& J = jobs[j];
@@ -186,7 +198,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     J.cW = CO(nr); J.cphipp = CO(nr); J.capp = CO(rr); J.cphif = CO(nr); J.cX = CO(rr); J.cH = OUT(o->h_mat, rr);
     J.cHup = CO(pairs); J.cHdec = CO(pairs * t1); J.cu1 = OUT(o->u_1, k1); J.cu2 = OUT(o->u_2, k2); J.cz = OUT(o->z, n);
     J.cbpp = CO(1); J.cab = CO(2);
-    J.dproj_int = cv.take<int64_t>(256);
+    J.dproj_int = proj_all + j * 256;
     J.dproj = cv.take<uint64_t>(256);
     if ((rc = st.in(x->S, nr * D, &J.dS))) return rc;
     if ((rc = st.in(x->phi, nr * D, &J.dphi))) return rc;
@@ -201,16 +213,59 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   const LimbTable* tabs = c->d_tabs;
   const uint64_t q = c->q;
 
-  // ================= phase A, per proof: transforms, steps 1-2, digits of t
-  for (size_t j = 0; j < np; j++) {
-    Job& J = jobs[j];
-    if ((rc = to_hat(c, J.dS, HV(j, hS), nr))) return rc;
-    if ((rc = to_hat(c, J.dphi, HV(j, hphi), nr))) return rc;
-    LAB_HIP(c, hipMemcpyAsync(J.cab, J.dalpha, D * 8, hipMemcpyDeviceToDevice, s));
-    LAB_HIP(c, hipMemcpyAsync(J.cab + D, J.dbeta, D * 8, hipMemcpyDeviceToDevice, s));
-    if ((rc = to_hat(c, J.cab, HV(j, hab), 2))) return rc;
-    if ((rc = to_hat(c, J.dc, HV(j, hc), r))) return rc;
-  }
+  // Every per-proof kernel below is launched ONCE for all np proofs (a "job" grid dimension): transform-domain operands
+  // are addressed with the arena's job stride, coefficient arrays through per-job pointers passed by value.
+  const size_t js = per * D, jsd = perd * D;                       // job strides (words inside a plane) of the two arenas
+  const size_t tmp_js = (size_t)L * tmp_elems * D;                 // per-job slice of the from_hat scratch
+  auto JP = [&](auto member) {
+    JobPtrs t;
+    for (size_t j = 0; j < np; j++) t.p[j] = const_cast<void*>(static_cast<const void*>(jobs[j].*member));
+    return t;
+  };
+  // `darena`: the offset lives in the second arena (operands of the digit reductions, in the basis `bdig` of B/C/D)
+  auto to_hat_jobs = [&](const JobPtrs& src, size_t off, size_t count, bool darena) -> int {
+    const int basis = darena ? bdig : 0;
+    HatView dst = darena ? HD(0, off) : HV(0, off);
+    const size_t st = darena ? jsd : js;
+    LAB_HIP(c, launch_reduce_u64_jobs(src, dst, st, count, basis_nlimbs(c, basis), basis_tabs(c, basis), np, s));
+    LAB_HIP(c, launch_ntt(true, dst, dst, count, basis_nlimbs(c, basis), basis_tabs(c, basis), 0, s, np, st, st));
+    return LAB_OK;
+  };
+  auto from_hat_jobs = [&](size_t off, size_t count, const JobPtrs& dst, bool darena) -> int {
+    const int basis = darena ? bdig : 0;
+    HatView src = darena ? HD(0, off) : HV(0, off);
+    HatView t{dense_tmp, count * D};
+    LAB_HIP(c, launch_ntt(false, src, t, count, basis_nlimbs(c, basis), basis_tabs(c, basis), 0, s, np, darena ? jsd : js, tmp_js));
+    LAB_HIP(c, launch_crt_to_u64_jobs(t, tmp_js, dst, count, basis_crt(c, basis), np, s));
+    return LAB_OK;
+  };
+  auto gram_jobs = [&](size_t out_off, size_t p_off, size_t s_off) -> int {   // out[i][k] = sum_x P[x][i] S[x][k]
+    const size_t chunks = gram_num_chunks(n);
+    if (chunks == 1) {
+      LAB_HIP(c, launch_gram_tiled(HV(0, out_off), HV(0, p_off), HV(0, s_off), n, r, L, tabs, s, np, js));
+    } else {
+      LAB_HIP(c, launch_gram_tiled(HV(0, hpart), HV(0, p_off), HV(0, s_off), n, r, L, tabs, s, np, js));
+      LAB_HIP(c, launch_sum_terms(HV(0, out_off), HV(0, hpart), chunks, rr, L, tabs, s, np, js, js));
+    }
+    return LAB_OK;
+  };
+  auto inner_product_jobs = [&](size_t out_off, size_t a_off, size_t b_off, size_t len) -> int {
+    const size_t k = inner_product_splits(len);
+    if (k == 1) {
+      LAB_HIP(c, launch_matvec_partial(HV(0, out_off), HV(0, a_off), HV(0, b_off), 1, 1, len, L, tabs, s, np, js));
+    } else {
+      LAB_HIP(c, launch_matvec_partial(HV(0, hpart), HV(0, a_off), HV(0, b_off), k, 1, len / k, L, tabs, s, np, js));
+      LAB_HIP(c, launch_sum_terms(HV(0, out_off), HV(0, hpart), k, 1, L, tabs, s, np, js, js));
+    }
+    return LAB_OK;
+  };
+
+  // ================= phase A: transforms
+  if ((rc = to_hat_jobs(JP(&Job::dS), hS, nr, false))) return rc;
+  if ((rc = to_hat_jobs(JP(&Job::dphi), hphi, nr, false))) return rc;
+  if ((rc = to_hat_jobs(JP(&Job::dalpha), hab, 1, false))) return rc;
+  if ((rc = to_hat_jobs(JP(&Job::dbeta), hab + 1, 1, false))) return rc;
+  if ((rc = to_hat_jobs(JP(&Job::dc), hc, r, false))) return rc;
   // ================= step 1 (src/proofgen.rs:41-49): t_i = A s_i for every column of every proof; A is shared, so the
   // whole batch is one (kappa x n)(n x np*r) product (falls back to one launch per proof for shapes it does not take)
   if (a8) {   // matrix cores: per proof, its r witness columns as the vector sets (element x of column i at S[x][i])
@@ -230,16 +285,13 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
       LAB_HIP(c, e);
     }
   }
-  for (size_t j = 0; j < np; j++) {
-    Job& J = jobs[j];
-    if ((rc = from_hat(c, HV(j, hT), rk, dense_tmp, J.cT))) return rc;
-    // step 2 (:59-70): G = S^T S
-    if ((rc = gram_impl(c, HV(j, hG), HV(j, hS), HV(j, hS), n, r, HV(j, hpart)))) return rc;
-    if ((rc = from_hat(c, HV(j, hG), rr, dense_tmp, J.cG))) return rc;
-    // digits of t in [i][k][rho] order, into the basis of B
-    LAB_HIP(c, launch_decompose(J.cTdec, J.cT, rk, q, (uint64_t)in->b1, t1, kappa, s));
-    if ((rc = to_hat(c, J.cTdec, HD(j, hTdec), rk * t1, bdig))) return rc;
-  }
+  if ((rc = from_hat_jobs(hT, rk, JP(&Job::cT), false))) return rc;
+  // step 2 (:59-70): G = S^T S
+  if ((rc = gram_jobs(hG, hS, hS))) return rc;
+  if ((rc = from_hat_jobs(hG, rr, JP(&Job::cG), false))) return rc;
+  // digits of t in [i][k][rho] order, into the basis of B
+  LAB_HIP(c, launch_decompose_jobs(JP(&Job::cTdec), JP(&Job::cT), rk, q, (uint64_t)in->b1, t1, kappa, np, s));
+  if ((rc = to_hat_jobs(JP(&Job::cTdec), hTdec, rk * t1, true))) return rc;
 
   // ================= step 3 (:101-132) for the whole batch: lhs_j = sum_{i,k} B_ik t_{j,i}^(k); B streamed once per group
   for (size_t j0 = 0; b8 && j0 < np;) {   // matrix cores: up to 32 proofs per pass over B, result written in place
@@ -275,75 +327,66 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   };
 
   // ================= step 4 (:137-148): rhs = sum_{i<=j,k} g_ij^(k) C_ijk ; u_1 = lhs + rhs (:153)
-  for (size_t j = 0; j < np; j++) {
-    Job& J = jobs[j];
-    LAB_HIP(c, launch_gather_upper(J.cGup, J.cG, r, s));
-    LAB_HIP(c, launch_decompose(J.cGdec, J.cGup, pairs, q, (uint64_t)in->b2, t2, 1, s));  // [pair][k]
-    if ((rc = to_hat(c, J.cGdec, HD(j, hGdec), pairs * t2, bdig))) return rc;
-  }
+  LAB_HIP(c, launch_gather_upper_jobs(JP(&Job::cGup), JP(&Job::cG), r, np, s));
+  LAB_HIP(c, launch_decompose_jobs(JP(&Job::cGdec), JP(&Job::cGup), pairs, q, (uint64_t)in->b2, t2, 1, np, s));  // [pair][k]
+  if ((rc = to_hat_jobs(JP(&Job::cGdec), hGdec, pairs * t2, true))) return rc;
   if ((rc = for_groups([&](size_t j0, int g) {   // C streamed once per group
         return axpy_commit_batched_any(c, g, HD(j0, hrhs), perd * D, HD(j0, hGdec), perd * D, in->C, in->c_off, pairs * t2, k2,
                                        HD(j0, hpartd), perd * D);
       }))) return rc;
+  LAB_HIP(c, launch_pointwise(PW_ADD, HD(0, hlhs), HD(0, hlhs), HD(0, hrhs), k1, Ld, tabsd, s, np, jsd, jsd, jsd));
+  if ((rc = from_hat_jobs(hlhs, k1, JP(&Job::cu1), true))) return rc;
 
-  // ================= per proof: u_1, steps 5-8, digits of H
-  for (size_t j = 0; j < np; j++) {
-    Job& J = jobs[j];
-    const lab_prove_input* x = ins[j];
-    LAB_HIP(c, launch_pointwise(PW_ADD, HD(j, hlhs), HD(j, hlhs), HD(j, hrhs), k1, Ld, tabsd, s));
-    if ((rc = from_hat(c, HD(j, hlhs), k1, dense_tmp, J.cu1, bdig))) return rc;
+  // ================= step 5 (:161-186, 429-456): JL projection over the integers
+  // (one pass over Pi also produces W, the Pi part of phi'' used in step 6)
+  LAB_HIP(c, hipMemsetAsync(proj_all, 0, np * 256 * 8, s));
+  LAB_HIP(c, launch_pi_fused_jobs(JP(&Job::dproj_int), JP(&Job::cW), JP(&Job::dPi), JP(&Job::dS), JP(&Job::domega), n, r, q, np, s));
+  LAB_HIP(c, launch_lift_i64_jobs(JP(&Job::dproj), JP(&Job::dproj_int), 256, q, np, s));
 
-    // step 5 (:161-186, 429-456): JL projection over the integers
-    // (one pass over Pi also produces W, the Pi part of phi'' used in step 6)
-    LAB_HIP(c, hipMemsetAsync(J.dproj_int, 0, 256 * 8, s));
-    LAB_HIP(c, launch_pi_fused(J.dproj_int, J.cW, J.dPi, J.dS, J.domega, n, r, q, s));
-    LAB_HIP(c, launch_lift_i64(J.dproj, J.dproj_int, 256, q, s));
-
-    // step 6 (:205-289): a'' = psi a', phi'' = psi phi' + sum_m omega_m sigma_inv(pi^(m)), b''
-    const uint64_t psi = x->psi % q;
-    LAB_HIP(c, launch_coef_elementwise(J.capp, J.da, nullptr, rr, q, psi, 0, s));
-    LAB_HIP(c, launch_coef_elementwise(J.cphipp, J.dphi, J.cW, nr, q, psi, 1, s));
-    if ((rc = to_hat(c, J.capp, HV(j, happ), rr))) return rc;
-    if ((rc = to_hat(c, J.cphipp, HV(j, hphipp), nr))) return rc;
-    if ((rc = to_hat(c, J.cG, HV(j, hGc), rr))) return rc;
-    if ((rc = inner_product_impl(c, HV(j, hbpp), HV(j, happ), HV(j, hGc), rr, HV(j, hpart)))) return rc;
-    if ((rc = inner_product_impl(c, HV(j, hbpp + 1), HV(j, hphipp), HV(j, hS), nr, HV(j, hpart)))) return rc;
-    LAB_HIP(c, launch_pointwise(PW_ADD, HV(j, hbpp), HV(j, hbpp), HV(j, hbpp + 1), 1, L, tabs, s));
-    if ((rc = from_hat(c, HV(j, hbpp), 1, dense_tmp, J.cbpp))) return rc;
-
-    // step 7 (:301-314): phi_i = alpha phi^(F)_i + beta phi''_i  (layout [n][r] like phi')
-    LAB_HIP(c, launch_poly_by_vec(HV(j, hphif), HV(j, hab), HV(j, hphi), nr, L, tabs, s));
-    LAB_HIP(c, launch_poly_by_vec(HV(j, hbphi), HV(j, hab + 1), HV(j, hphipp), nr, L, tabs, s));
-    LAB_HIP(c, launch_pointwise(PW_ADD, HV(j, hphif), HV(j, hphif), HV(j, hbphi), nr, L, tabs, s));
-    if (!c->direct) {  // canonicalise before the next product (see header comment)
-      if ((rc = from_hat(c, HV(j, hphif), nr, dense_tmp, J.cphif))) return rc;
-      if ((rc = to_hat(c, J.cphif, HV(j, hphif), nr))) return rc;
-    }
-
-    // step 8 (:320-358): H = 2^-1 (Phi^T S + S^T Phi)
-    if ((rc = gram_impl(c, HV(j, hX), HV(j, hphif), HV(j, hS), n, r, HV(j, hpart)))) return rc;
-    if ((rc = from_hat(c, HV(j, hX), rr, dense_tmp, J.cX))) return rc;
-    LAB_HIP(c, launch_symmetrize_half(J.cH, J.cX, r, q, inv2_mod(q), s));
-
-    // digits of the upper triangle of H for step 9
-    LAB_HIP(c, launch_gather_upper(J.cHup, J.cH, r, s));
-    LAB_HIP(c, launch_decompose(J.cHdec, J.cHup, pairs, q, (uint64_t)in->b1, t1, 1, s));
-    if ((rc = to_hat(c, J.cHdec, HD(j, hHdec), pairs * t1, bdig))) return rc;
+  // ================= step 6 (:205-289): a'' = psi a', phi'' = psi phi' + sum_m omega_m sigma_inv(pi^(m)), b''
+  {
+    JobU64 psi;
+    JobPtrs none;
+    for (size_t j = 0; j < np; j++) { psi.v[j] = ins[j]->psi % q; none.p[j] = nullptr; }
+    LAB_HIP(c, launch_coef_elementwise_jobs(JP(&Job::capp), JP(&Job::da), none, rr, q, psi, 0, np, s));
+    LAB_HIP(c, launch_coef_elementwise_jobs(JP(&Job::cphipp), JP(&Job::dphi), JP(&Job::cW), nr, q, psi, 1, np, s));
   }
+  if ((rc = to_hat_jobs(JP(&Job::capp), happ, rr, false))) return rc;
+  if ((rc = to_hat_jobs(JP(&Job::cphipp), hphipp, nr, false))) return rc;
+  if ((rc = to_hat_jobs(JP(&Job::cG), hGc, rr, false))) return rc;
+  if ((rc = inner_product_jobs(hbpp, happ, hGc, rr))) return rc;
+  if ((rc = inner_product_jobs(hbpp + 1, hphipp, hS, nr))) return rc;
+  LAB_HIP(c, launch_pointwise(PW_ADD, HV(0, hbpp), HV(0, hbpp), HV(0, hbpp + 1), 1, L, tabs, s, np, js, js, js));
+  if ((rc = from_hat_jobs(hbpp, 1, JP(&Job::cbpp), false))) return rc;
+
+  // ================= step 7 (:301-314): phi_i = alpha phi^(F)_i + beta phi''_i  (layout [n][r] like phi')
+  LAB_HIP(c, launch_poly_by_vec(HV(0, hphif), HV(0, hab), HV(0, hphi), nr, L, tabs, s, np, js));
+  LAB_HIP(c, launch_poly_by_vec(HV(0, hbphi), HV(0, hab + 1), HV(0, hphipp), nr, L, tabs, s, np, js));
+  LAB_HIP(c, launch_pointwise(PW_ADD, HV(0, hphif), HV(0, hphif), HV(0, hbphi), nr, L, tabs, s, np, js, js, js));
+  if (!c->direct) {  // canonicalise before the next product (see header comment)
+    if ((rc = from_hat_jobs(hphif, nr, JP(&Job::cphif), false))) return rc;
+    if ((rc = to_hat_jobs(JP(&Job::cphif), hphif, nr, false))) return rc;
+  }
+
+  // ================= step 8 (:320-358): H = 2^-1 (Phi^T S + S^T Phi)
+  if ((rc = gram_jobs(hX, hphif, hS))) return rc;
+  if ((rc = from_hat_jobs(hX, rr, JP(&Job::cX), false))) return rc;
+  LAB_HIP(c, launch_symmetrize_half_jobs(JP(&Job::cH), JP(&Job::cX), r, q, inv2_mod(q), np, s));
+  // digits of the upper triangle of H for step 9
+  LAB_HIP(c, launch_gather_upper_jobs(JP(&Job::cHup), JP(&Job::cH), r, np, s));
+  LAB_HIP(c, launch_decompose_jobs(JP(&Job::cHdec), JP(&Job::cHup), pairs, q, (uint64_t)in->b1, t1, 1, np, s));
+  if ((rc = to_hat_jobs(JP(&Job::cHdec), hHdec, pairs * t1, true))) return rc;
 
   // ================= step 9 (:364-378): u_2 = sum_{i<=j,k} h_ij^(k) D_ijk ; D streamed once per group
   if ((rc = for_groups([&](size_t j0, int g) {
         return axpy_commit_batched_any(c, g, HD(j0, hu2), perd * D, HD(j0, hHdec), perd * D, in->Dm, in->d_off, pairs * t1, k2,
                                        HD(j0, hpartd), perd * D);
       }))) return rc;
+  if ((rc = from_hat_jobs(hu2, k2, JP(&Job::cu2), true))) return rc;
 
-  // ================= per proof: u_2 out, step 10 (:380-399): z = sum_i c_i s_i
-  for (size_t j = 0; j < np; j++) {
-    Job& J = jobs[j];
-    if ((rc = from_hat(c, HD(j, hu2), k2, dense_tmp, J.cu2, bdig))) return rc;
-    LAB_HIP(c, launch_matvec_partial(HV(j, hz), HV(j, hS), HV(j, hc), 1, n, r, L, tabs, s));
-    if ((rc = from_hat(c, HV(j, hz), n, dense_tmp, J.cz))) return rc;
-  }
+  // ================= step 10 (:380-399): z = sum_i c_i s_i
+  LAB_HIP(c, launch_matvec_partial(HV(0, hz), HV(0, hS), HV(0, hc), 1, n, r, L, tabs, s, np, js));
+  if ((rc = from_hat_jobs(hz, n, JP(&Job::cz), false))) return rc;
 
   // ================= copy-out and the two verifier callbacks that can reject
   std::vector<int64_t> hproj(np * 256);
