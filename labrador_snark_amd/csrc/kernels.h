@@ -122,6 +122,7 @@ struct Gemm8Args {
   size_t v8_job_stride;
   unsigned planes, rt_count, kt_count, rgroups /* row groups per slot */, njobs, rows, ns, ns_valid;
   uint32_t p;
+  const LimbTable* tab;     // this limb's table (device): Montgomery constants for the recombination
 };
 hipError_t launch_gemm_i8(const Gemm8Args& a, size_t nt, hipStream_t s);
 // out[i*r + k] = sum_x P[x*r+i] * S[x*r+k]

@@ -61,6 +61,7 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
     g.planes = (unsigned)pl; g.rt_count = (unsigned)m->rt_count; g.kt_count = (unsigned)m->kt_count;
     g.rgroups = (unsigned)((m->rt_count + 4 / pl - 1) / (4 / pl)); g.njobs = (unsigned)njobs; g.rows = (unsigned)m->rows;
     g.ns = (unsigned)ns; g.ns_valid = (unsigned)ns_valid; g.p = primes[l];
+    g.tab = (m->basis ? c->dg_tabs : c->d_tabs) + l;
     const bool prof = c->prof_on && pl == 4 && njobs == 1 && v_k_stride == (size_t)D;
     if (prof && c->prof_used == c->prof_events.size()) {
       hipEvent_t a, b;
@@ -88,7 +89,7 @@ extern "C" int lab_mat8_pack(lab_ctx* c, const lab_vec* M, size_t m_off, size_t 
   int rc;
   if (nmat == 0 || rows == 0 || cols == 0) return fail(c, LAB_ERR_ARG, "lab_mat8_pack: empty dimension");
   if ((rc = check_range(c, M, m_off, nmat * rows * cols, "lab_mat8_pack(M)"))) return rc;
-  if (nmat * cols >= (1u << 17)) return fail(c, LAB_ERR_RANGE, "lab_mat8_pack: %zu products per sum exceed the int32 exactness bound 131071 of the int8 formulation", nmat * cols);
+  if (nmat * cols >= (1u << 17) - 1) return fail(c, LAB_ERR_RANGE, "lab_mat8_pack: %zu products per sum exceed the int32 exactness bound 131070 of the int8 formulation", nmat * cols);
   const uint64_t limit = M->basis ? c->dg_terms : c->max_len;
   if (nmat * cols > limit) return fail(c, LAB_ERR_RANGE, "lab_mat8_pack: reduction length %zu exceeds the exactness bound %llu of this basis", nmat * cols, (unsigned long long)limit);
   LAB_HIP(c, hipSetDevice(c->device));

@@ -230,16 +230,26 @@ k_gemm_i8(const Gemm8Args a) {
 #pragma unroll
     for (int g = 0; g < 16; g++) dl[((w * NT + n) * 16 + g) * 64 + lane] = acc[n][g];
   __syncthreads();
-  // c_t = sum_{i+i'=t} D_i[row][(i',s)] (|c_t| < 2^33), then Horner in 256 with a division-free reduction per step
+  // out = sum_{i,i'} 256^(i+i') D_i[row][(i',s)] mod p.  For the 30-bit limb primes everything stays in 32-bit
+  // conditional subtractions and one Montgomery reduction: |D| <= K * 2^14 < 2^31 - 766 (K < 2^17 - 1 is enforced at pack
+  // time), so D + 2p lies in (0, 4p) and fits 32 bits; c_t = sum over i+i'=t of at most 4 canonical residues < 4p.
+  // A small prime (the 2-plane limb of the digit basis) takes a division-free double-reciprocal path.
   const uint32_t p = a.p;
-  const double inv_p = 1.0 / (double)p;
-  auto modp = [&](int64_t v) -> int64_t {        // |v| < 2^40: floor(v / p) from one double multiply is off by at most 1
-    const int64_t q = (int64_t)__builtin_floor((double)v * inv_p);
-    int64_t r = v - q * (int64_t)p;
-    r += r < 0 ? (int64_t)p : 0;
-    r -= r >= (int64_t)p ? (int64_t)p : 0;
-    return r;
-  };
+  const LimbTable* tab = a.tab;
+  const uint32_t p2 = tab->p2, pinv = tab->pinv, r2 = tab->r2;
+  const bool big = p > (1u << 29);
+  uint32_t pw[7];
+  {  // 256^e mod p by repeated doubling (8 doublings per step): no division, any p
+    uint32_t v = 1 % p;
+    pw[0] = v;
+#pragma unroll
+    for (int e = 1; e < 7; e++) {
+#pragma unroll
+      for (int d = 0; d < 8; d++) { v <<= 1; v -= v >= p ? p : 0; }
+      pw[e] = v;
+    }
+  }
+  const double inv_p = tab->inv_p;
   const unsigned ns = a.ns;
   uint32_t* out = a.out + (size_t)job * a.out_job_stride;
   for (unsigned o = t; o < tiles_per_block * 32 * ns; o += 256) {
@@ -247,20 +257,47 @@ k_gemm_i8(const Gemm8Args a) {
     const unsigned grow = (rg * tiles_per_block + tl) * 32 + row;
     if (s >= a.ns_valid || grow >= a.rows) continue;
     const unsigned g = (row & 3) | ((row >> 3) << 2), lh = ((row >> 2) & 1) * 32;
-    int64_t ct[7] = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t res;
+    if (big) {
+      uint32_t ct[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (unsigned pi = 0; pi < 4; pi++)
+      for (unsigned pi = 0; pi < 4; pi++)
 #pragma unroll
-      for (unsigned pv = 0; pv < 4; pv++) {
-        if (pi < planes && pv < planes) {
-          const unsigned n = pv * ns + s;
-          ct[pi + pv] += dl[(((tl * planes + pi) * NT + n / 32) * 16 + g) * 64 + lh + (n % 32)];
+        for (unsigned pv = 0; pv < 4; pv++) {
+          if (pi < planes && pv < planes) {
+            const unsigned n = pv * ns + s;
+            const int32_t d = dl[(((tl * planes + pi) * NT + n / 32) * 16 + g) * 64 + lh + (n % 32)];
+            ct[pi + pv] += csub(csub((uint32_t)d + p2, p2), p);      // canonical residue; at most 4 per c_t: < 4p < 2^32
+          }
         }
-      }
-    int64_t r = 0;
+      uint64_t acc = 0;
 #pragma unroll
-    for (int e = 6; e >= 0; e--) r = modp(r * 256 + modp(ct[e]));
-    out[(size_t)s * a.out_set_stride + (size_t)grow * D + j] = (uint32_t)r;
+      for (int e = 0; e < 7; e++) acc += (uint64_t)csub(csub(ct[e], p2), p) * pw[e];   // 7 products < 2^60
+      res = mont_mul(redc64(acc_fold(acc, p, p2), p, pinv), r2, p, pinv);
+    } else {
+      auto modp = [&](int64_t v) -> int64_t {      // |v| < 2^40: floor(v / p) from one double multiply is off by at most 1
+        const int64_t qq = (int64_t)__builtin_floor((double)v * inv_p);
+        int64_t r = v - qq * (int64_t)p;
+        r += r < 0 ? (int64_t)p : 0;
+        r -= r >= (int64_t)p ? (int64_t)p : 0;
+        return r;
+      };
+      int64_t ct[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (unsigned pi = 0; pi < 4; pi++)
+#pragma unroll
+        for (unsigned pv = 0; pv < 4; pv++) {
+          if (pi < planes && pv < planes) {
+            const unsigned n = pv * ns + s;
+            ct[pi + pv] += dl[(((tl * planes + pi) * NT + n / 32) * 16 + g) * 64 + lh + (n % 32)];
+          }
+        }
+      int64_t r = 0;
+#pragma unroll
+      for (int e = 6; e >= 0; e--) r = modp(r * 256 + modp(ct[e]));
+      res = (uint32_t)r;
+    }
+    out[(size_t)s * a.out_set_stride + (size_t)grow * D + j] = res;
   }
 }
 
