@@ -81,7 +81,7 @@ def challenge_poly(rng, q):
     return np.where((vals > 0) & (signs == 1), q - vals, vals).astype(np.uint64)
 
 
-def make_inputs(k, q, seed):
+def make_inputs(k, q, seed, dev=None):
     """Seeded synthetic witness / state / challenge tape (same recipe as tests/cases.py, without the oracle):
     witness coefficients uniform in [0, beta/sqrt(n r d)] so the norm bound of generate_witness holds
     (src/proofgen.rs:460-518), phi and a uniform (src/structs.rs:289-314), Pi in {-1,0,1} with weights
@@ -95,7 +95,16 @@ def make_inputs(k, q, seed):
     for i in range(r):
         for j in range(i):
             a[i, j] = a[j, i]
-    Pi = rng.choice(np.array([-1, 0, 1], dtype=np.int8), size=(r, 256, n * D), p=[0.25, 0.5, 0.25]).astype(np.int8)
+    if dev is not None:
+        # the 512 MiB projection tape is drawn on the device (numpy needs seconds per proof for it): two fair bits
+        # per entry, {00 -> -1, 01/10 -> 0, 11 -> 1}
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        bits = torch.randint(0, 4, (r, 256, n * D), dtype=torch.int8, device=dev, generator=g)
+        Pi = (bits == 3).to(torch.int8) - (bits == 0).to(torch.int8)
+        del bits
+    else:
+        Pi = rng.choice(np.array([-1, 0, 1], dtype=np.int8), size=(r, 256, n * D), p=[0.25, 0.5, 0.25]).astype(np.int8)
     tape = dict(Pi=Pi, psi=int(rng.integers(0, q)), omega=rng.integers(0, q, size=256, dtype=np.uint64),
                 alpha=rng.integers(0, q, size=D, dtype=np.uint64), beta=rng.integers(0, q, size=D, dtype=np.uint64),
                 c=np.stack([challenge_poly(rng, q) for _ in range(r)]))
@@ -159,7 +168,7 @@ def main():
     nbatch = max(1, args.batch)
     dSs, sts, dtapes = [], [], []
     for j in range(nbatch):
-        S, phi, a, tape = make_inputs(k, q, seed=50 + rank * nbatch + j)
+        S, phi, a, tape = make_inputs(k, q, seed=50 + rank * nbatch + j, dev=dev)
         # b' = const term of b = sum a_ij<s_i,s_j> + sum <phi_i,s_i> (src/structs.rs:320-341, 373): computed on the
         # GPU with the product's own kernels (the oracle is not on the product path)
         hS, hphi, ha = ctx.vec_from(S), ctx.vec_from(phi), ctx.vec_from(a)
@@ -172,7 +181,8 @@ def main():
             v.close()
         dSs.append(dev64(S))
         sts.append(lab.State(dev64(phi), dev64(a), b_prime))
-        dtapes.append(dict(Pi=torch.from_numpy(tape["Pi"]).to(dev), psi=tape["psi"], omega=dev64(tape["omega"]),
+        dtapes.append(dict(Pi=tape["Pi"] if torch.is_tensor(tape["Pi"]) else torch.from_numpy(tape["Pi"]).to(dev),
+                           psi=tape["psi"], omega=dev64(tape["omega"]),
                            alpha=dev64(tape["alpha"]), beta=dev64(tape["beta"]), c=dev64(tape["c"])))
     # B, C, D are only ever multiplied by decomposition digits: keep them in the digit basis (u16 small limb)
     crs = lab.ResidentCRS(ctx, k, compact=not args.no_compact_crs).fill_synthetic(1000 + 10 * rank)

@@ -147,6 +147,8 @@ hipError_t launch_gather_upper(uint64_t* out, const uint64_t* in, size_t r, hipS
 hipError_t launch_decompose_jobs(const JobPtrs& out, const JobPtrs& in, size_t count, uint64_t q, uint64_t base, int exp,
                                  size_t group, size_t njobs, hipStream_t s);
 hipError_t launch_gather_upper_jobs(const JobPtrs& out, const JobPtrs& in, size_t r, size_t njobs, hipStream_t s);
+hipError_t launch_gather_jobs(uint64_t* dst, const JobPtrs& src, size_t words, size_t njobs, hipStream_t s);
+hipError_t launch_scatter_jobs(const JobPtrs& dst, const uint64_t* src, size_t words, size_t njobs, hipStream_t s);
 hipError_t launch_lift_i64_jobs(const JobPtrs& out, const JobPtrs& in, size_t n, uint64_t q, size_t njobs, hipStream_t s);
 hipError_t launch_coef_elementwise_jobs(const JobPtrs& out, const JobPtrs& a, const JobPtrs& b, size_t count, uint64_t q,
                                         const JobU64& s1, int mode, size_t njobs, hipStream_t s);

@@ -213,6 +213,26 @@ __global__ void k_lift_i64(const JobPtrs outp, const JobPtrs inp, unsigned n, ui
   out[i] = v < 0 ? (m == 0 ? 0 : q - m) : m;
 }
 
+// dst[job*words + i] = src[job][i] / the reverse: small per-job arrays to and from one contiguous staging buffer
+__global__ void k_gather_jobs(uint64_t* __restrict__ dst, const JobPtrs srcp, unsigned words) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < words) dst[(size_t)blockIdx.y * words + i] = static_cast<const uint64_t*>(srcp.p[blockIdx.y])[i];
+}
+__global__ void k_scatter_jobs(const JobPtrs dstp, const uint64_t* __restrict__ src, unsigned words) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < words && dstp.p[blockIdx.y]) static_cast<uint64_t*>(dstp.p[blockIdx.y])[i] = src[(size_t)blockIdx.y * words + i];
+}
+hipError_t launch_gather_jobs(uint64_t* dst, const JobPtrs& src, size_t words, size_t njobs, hipStream_t s) {
+  if (words == 0 || njobs == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_gather_jobs, dim3((unsigned)((words + 255) / 256), (unsigned)njobs), dim3(256), 0, s, dst, src, (unsigned)words);
+  return hipGetLastError();
+}
+hipError_t launch_scatter_jobs(const JobPtrs& dst, const uint64_t* src, size_t words, size_t njobs, hipStream_t s) {
+  if (words == 0 || njobs == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_scatter_jobs, dim3((unsigned)((words + 255) / 256), (unsigned)njobs), dim3(256), 0, s, dst, src, (unsigned)words);
+  return hipGetLastError();
+}
+
 hipError_t launch_lift_i64_jobs(const JobPtrs& out, const JobPtrs& in, size_t n, uint64_t q, size_t njobs, hipStream_t s) {
   if (n == 0 || njobs == 0) return hipSuccess;
   hipLaunchKernelGGL(k_lift_i64, dim3((unsigned)((n + 255) / 256), (unsigned)njobs), dim3(256), 0, s, out, in, (unsigned)n, q);

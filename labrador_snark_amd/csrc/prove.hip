@@ -188,7 +188,9 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   // results the caller wants in device memory are produced in place (no staging copy)
   auto OUT = [&](uint64_t* user, size_t elems) { return (user && is_device_pointer(user)) ? user : CO(elems); };
   std::vector<Job> jobs(np);
-  int64_t* proj_all = cv.take<int64_t>(np * 256);   // contiguous: one memset for the batch
+  // [np][256] integer projections | [np][256] omega | [np][64] b'': contiguous, so the host-side checks need ONE copy
+  uint64_t* host_stage = cv.take<uint64_t>(np * (256 + 256 + D));
+  int64_t* proj_all = reinterpret_cast<int64_t*>(host_stage);
   Staging st(c, &cv);  // inputs only (no pending outputs are registered on it)
   for (size_t j = 0; j < np; j++) {
     Job& J = jobs[j];
@@ -197,9 +199,9 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     J.cT = OUT(o->t_i_all, rk); J.cTdec = CO(rk * t1); J.cG = OUT(o->g_mat, rr); J.cGup = CO(pairs); J.cGdec = CO(pairs * t2);
     J.cW = CO(nr); J.cphipp = CO(nr); J.capp = CO(rr); J.cphif = CO(nr); J.cX = CO(rr); J.cH = OUT(o->h_mat, rr);
     J.cHup = CO(pairs); J.cHdec = CO(pairs * t1); J.cu1 = OUT(o->u_1, k1); J.cu2 = OUT(o->u_2, k2); J.cz = OUT(o->z, n);
-    J.cbpp = CO(1); J.cab = CO(2);
+    J.cbpp = OUT(o->b_prime_prime, 1); J.cab = CO(2);
     J.dproj_int = proj_all + j * 256;
-    J.dproj = cv.take<uint64_t>(256);
+    J.dproj = OUT(o->projection, 4);
     if ((rc = st.in(x->S, nr * D, &J.dS))) return rc;
     if ((rc = st.in(x->phi, nr * D, &J.dphi))) return rc;
     if ((rc = st.in(x->a, rr * D, &J.da))) return rc;
@@ -389,22 +391,37 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if ((rc = from_hat_jobs(hz, n, JP(&Job::cz), false))) return rc;
 
   // ================= copy-out and the two verifier callbacks that can reject
-  std::vector<int64_t> hproj(np * 256);
-  std::vector<uint64_t> hbpp0(np), homega(np * 256);
+  std::vector<uint64_t> hst(np * (256 + 256 + D));
+  const int64_t* hproj = reinterpret_cast<const int64_t*>(hst.data());
+  const uint64_t* homega = hst.data() + np * 256;
+  const uint64_t* hbpp_st = hst.data() + np * 512;
+  LAB_HIP(c, launch_gather_jobs(host_stage + np * 256, JP(&Job::domega), 256, np, s));
+  LAB_HIP(c, launch_gather_jobs(host_stage + np * 512, JP(&Job::cbpp), D, np, s));
+  {  // integer projections to device-resident caller buffers (host ones are filled from the staged copy below)
+    JobPtrs pi;
+    bool any = false;
+    for (size_t j = 0; j < np; j++) {
+      void* u = outs[j]->projection_int;
+      pi.p[j] = (u && is_device_pointer(u)) ? u : nullptr;
+      any = any || pi.p[j];
+    }
+    if (any) LAB_HIP(c, launch_scatter_jobs(pi, host_stage, 256, np, s));
+  }
   for (size_t j = 0; j < np; j++) {
     Job& J = jobs[j];
     lab_transcript* o = outs[j];
     struct { uint64_t* dst; const uint64_t* src; size_t words; } cp[] = {
         {o->u_1, J.cu1, k1 * D}, {o->projection, J.dproj, 256}, {o->b_prime_prime, J.cbpp, D}, {o->u_2, J.cu2, k2 * D},
         {o->z, J.cz, n * D}, {o->t_i_all, J.cT, rk * D}, {o->g_mat, J.cG, rr * D}, {o->h_mat, J.cH, rr * D}};
-    for (auto& e : cp)
+    for (auto& e : cp)   // results produced in place (device-resident caller buffers) need no copy
       if (e.dst && e.dst != e.src) LAB_HIP(c, hipMemcpyAsync(e.dst, e.src, e.words * 8, hipMemcpyDefault, s));
-    if (o->projection_int) LAB_HIP(c, hipMemcpyAsync(o->projection_int, J.dproj_int, 256 * 8, hipMemcpyDefault, s));
-    LAB_HIP(c, hipMemcpyAsync(&hproj[j * 256], J.dproj_int, 256 * 8, hipMemcpyDeviceToHost, s));
-    LAB_HIP(c, hipMemcpyAsync(&hbpp0[j], J.cbpp, 8, hipMemcpyDeviceToHost, s));
-    LAB_HIP(c, hipMemcpyAsync(&homega[j * 256], J.domega, 256 * 8, hipMemcpyDeviceToHost, s));
   }
+  LAB_HIP(c, hipMemcpyAsync(hst.data(), host_stage, hst.size() * 8, hipMemcpyDeviceToHost, s));
   LAB_HIP(c, hipStreamSynchronize(s));
+  for (size_t j = 0; j < np; j++) {
+    void* u = outs[j]->projection_int;
+    if (u && !is_device_pointer(u)) memcpy(u, hproj + j * 256, 256 * 8);
+  }
 
   int first_fail = LAB_OK;
   for (size_t j = 0; j < np; j++) {
@@ -426,9 +443,9 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
         chk = (chk + (u128)(homega[j * 256 + m] % q) * (u128)pm) % q;
       }
       chk = (chk + (u128)(x->psi % q) * (u128)(x->b_prime % q)) % q;
-      if ((uint64_t)chk != hbpp0[j])
+      if ((uint64_t)chk != hbpp_st[j * D])
         stj = fail(c, LAB_ERR_BPP_CHECK, "verify_b_prime_prime check failed: b_prime_prime_k constant coefficient is: %llu, and check_val is: %llu",
-                   (unsigned long long)hbpp0[j], (unsigned long long)(uint64_t)chk);
+                   (unsigned long long)hbpp_st[j * D], (unsigned long long)(uint64_t)chk);
     }
     if (status) status[j] = stj;
     if (stj != LAB_OK && first_fail == LAB_OK) first_fail = stj;
