@@ -121,9 +121,13 @@ struct Gemm8Args {
   const int8_t* V8;          // + job*v8_job_stride (bytes)
   size_t v8_job_stride;
   unsigned planes, rt_count, kt_count, rgroups /* row groups per slot */, njobs, rows, ns, ns_valid;
+  unsigned tile_r, tile_j;   // block-order super-tile (set by launch_gemm_i8)
   uint32_t p;
   const LimbTable* tab;     // this limb's table (device): Montgomery constants for the recombination
+  uint32_t* stage;          // non-null: results go to stage[job][slot][row][set] (full-line stores), see k_slot_transpose
 };
+hipError_t launch_slot_transpose(uint32_t* out_plane, size_t out_set_stride, size_t out_job_stride, const uint32_t* stage,
+                                 size_t rows, size_t rows_pad, size_t ns, size_t ns_valid, size_t njobs, hipStream_t s);
 hipError_t launch_gemm_i8(const Gemm8Args& a, size_t nt, hipStream_t s);
 // out[i*r + k] = sum_x P[x*r+i] * S[x*r+k]
 hipError_t launch_gram(HatView out, ConstHatView P, ConstHatView S, size_t n, size_t r, int nlimbs,

@@ -36,7 +36,11 @@ static size_t v8_job_bytes(const lab_mat8* m, int ns) {
   return Carver::padded(v8);
 }
 
-size_t mfma_scratch_bytes(const lab_mat8* m, int ns, size_t njobs) { return v8_job_bytes(m, ns) * njobs; }
+// B-operand tiles of every job, plus (several jobs: many blocks) the slot-major staging array of the results
+static size_t stage_bytes(const lab_mat8* m, int ns, size_t njobs) {
+  return njobs > 1 ? Carver::padded(njobs * (size_t)D * m->rt_count * 32 * ns * 4) : 0;
+}
+size_t mfma_scratch_bytes(const lab_mat8* m, int ns, size_t njobs) { return v8_job_bytes(m, ns) * njobs + stage_bytes(m, ns, njobs); }
 
 // For every job b < njobs: out_s[rho] (s < ns_valid; hat elements at out.base + b*out_job_stride + s*out_set_stride)
 //   = sum_k M[rho][k] V_s[k],  V_s[k] at V.base + b*v_job_stride + s*v_set_stride + k*v_k_stride
@@ -50,6 +54,7 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
   const size_t ktotal = m->nmat * m->cols;
   int8_t* v8 = static_cast<int8_t*>(scratch);
   const size_t v8_stride = v8_job_bytes(m, ns);
+  uint32_t* stage = njobs > 1 ? reinterpret_cast<uint32_t*>(v8 + v8_stride * njobs) : nullptr;
   for (int l = 0; l < m->nlimbs; l++) {
     const int pl = m->planes[l];
     const size_t nt = nt_for(ns, pl);
@@ -62,6 +67,7 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
     g.rgroups = (unsigned)((m->rt_count + 4 / pl - 1) / (4 / pl)); g.njobs = (unsigned)njobs; g.rows = (unsigned)m->rows;
     g.ns = (unsigned)ns; g.ns_valid = (unsigned)ns_valid; g.p = primes[l];
     g.tab = (m->basis ? c->dg_tabs : c->d_tabs) + l;
+    g.stage = stage;
     const bool prof = c->prof_on && pl == 4 && njobs == 1 && v_k_stride == (size_t)D;
     if (prof && c->prof_used == c->prof_events.size()) {
       hipEvent_t a, b;
@@ -78,6 +84,9 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
       c->prof_bytes += (double)D * pl * m->rt_count * m->kt_count * 1024 + (double)D * m->kt_count * nt * 1024 +
                        (double)ns_valid * m->rows * D * 4;
     }
+    if (stage)
+      LAB_HIP(c, launch_slot_transpose(g.out, out_set_stride, out_job_stride, stage, m->rows, m->rt_count * 32, ns, ns_valid, njobs,
+                                       c->stream));
   }
   return LAB_OK;
 }

@@ -297,8 +297,38 @@ k_gemm_i8(const Gemm8Args a) {
       for (int e = 6; e >= 0; e--) r = modp(r * 256 + modp(ct[e]));
       res = (uint32_t)r;
     }
-    out[(size_t)s * a.out_set_stride + (size_t)grow * D + j] = res;
+    // A result word belongs to a 256-byte ring element whose other 63 slots come from 63 other blocks.  With few blocks
+    // (the outer commitment) the scattered 4-byte stores are harmless; with many (the Ajtai product of a batch: 6.7e7
+    // stores per launch) every one of them makes L2 fetch a line to merge into, so results go to a slot-major
+    // staging array with full-line stores and k_slot_transpose moves them into place.
+    if (a.stage) a.stage[(((size_t)job * D + j) * (rt_count * 32) + grow) * ns + s] = res;
+    else out[(size_t)s * a.out_set_stride + (size_t)grow * D + j] = res;
   }
+}
+
+// stage[job][j][row][s] -> out[job*out_job_stride + s*out_set_stride + row*64 + j]; block = (row, job)
+__global__ void __launch_bounds__(256)
+k_slot_transpose(uint32_t* __restrict__ out, size_t out_set_stride, size_t out_job_stride, const uint32_t* __restrict__ stage,
+                 unsigned rows_pad, unsigned ns, unsigned ns_valid) {
+  __shared__ uint32_t tile[D][33];
+  const unsigned row = blockIdx.x, job = blockIdx.y;
+  for (unsigned e = threadIdx.x; e < D * ns; e += 256) {
+    const unsigned j = e / ns, s = e % ns;
+    tile[j][s] = stage[(((size_t)job * D + j) * rows_pad + row) * ns + s];
+  }
+  __syncthreads();
+  for (unsigned e = threadIdx.x; e < D * ns_valid; e += 256) {
+    const unsigned s = e / D, j = e % D;
+    out[(size_t)job * out_job_stride + (size_t)s * out_set_stride + (size_t)row * D + j] = tile[j][s];
+  }
+}
+
+hipError_t launch_slot_transpose(uint32_t* out_plane, size_t out_set_stride, size_t out_job_stride, const uint32_t* stage,
+                                 size_t rows, size_t rows_pad, size_t ns, size_t ns_valid, size_t njobs, hipStream_t s) {
+  if (rows == 0 || njobs == 0 || ns > 32) return ns > 32 ? hipErrorInvalidValue : hipSuccess;
+  hipLaunchKernelGGL(k_slot_transpose, dim3((unsigned)rows, (unsigned)njobs), dim3(256), 0, s, out_plane, out_set_stride,
+                     out_job_stride, stage, (unsigned)rows_pad, (unsigned)ns, (unsigned)ns_valid);
+  return hipGetLastError();
 }
 
 hipError_t launch_gemm_i8(const Gemm8Args& a, size_t nt, hipStream_t s) {
