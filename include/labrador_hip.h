@@ -198,7 +198,7 @@ int lab_gram(lab_ctx *ctx, lab_vec *out, size_t out_off, const lab_vec *P, size_
  * For 8 or more proofs per batch lab_matvec_sum_batched is bound by the 64-bit multiply-add issue rate, not by HBM.
  * lab_mat8_pack re-stores the matrices M (as for lab_matvec_sum: nmat matrices of rows x cols elements, plain or
  * compact, either basis) once as signed base-256 digit planes in MFMA operand-tile order (same bytes per residue);
- * lab_matvec_sum_mfma then computes, for ns in {8,16,32} vector sets V_s (set s at v_off + s*nmat*cols),
+ * lab_matvec_sum_mfma then computes, for ns in {8,16,32,64} vector sets V_s (set s at v_off + s*nmat*cols),
  *   out[out_off + s*rows + rho] = sum_{m,c} M[m][rho][c] * V_s[m*cols + c]
  * as exact int8 GEMMs (v_mfma_i32_32x32x32_i8, int32 accumulation: nmat*cols must stay below 2^17) followed by a
  * recombination mod each limb prime.  Bit-identical to lab_matvec_sum. */
@@ -273,7 +273,7 @@ typedef struct {
   const uint64_t *beta;    /* [64]  fetch_beta             (src/verification.rs:449-456) */
   const uint64_t *c;       /* [r][64] fetch_challenge      (src/verification.rs:460-489) */
   const struct lab_mat8 *B8; /* optional: the B matrices packed for the matrix cores (lab_mat8_pack(B, b_off, r*t1, kappa1,
-                              * kappa)); when set, step 3 of lab_prove_core[_batch] runs as int8 GEMMs over up to 32 proofs
+                              * kappa)); when set, step 3 of lab_prove_core[_batch] runs as int8 GEMMs over up to 64 proofs
                               * per pass and B itself may be NULL (lab_verify_core still needs B) */
   const struct lab_mat8 *A8; /* optional: lab_mat8_pack(A, a_off, 1, kappa, n): step 1 (t_i = A s_i) as int8 GEMMs */
 } lab_prove_input;

@@ -27,7 +27,7 @@ int mfma_planes(uint32_t p) {   // digits d_i in [-128,127] (the last one unrest
 // column tiles for ns sets whose residues need `planes_v` digit planes
 static size_t nt_for(int ns, int planes_v) {
   const size_t nt = ((size_t)ns * planes_v + 31) / 32;
-  return nt == 3 ? 4 : nt;                                  // the GEMM is instantiated for 1, 2, 4 column tiles
+  return nt == 3 ? 4 : (nt > 4 ? 8 : nt);                   // the GEMM is instantiated for 1, 2, 4, 8 column tiles
 }
 
 static size_t v8_job_bytes(const lab_mat8* m, int ns) {
@@ -79,7 +79,7 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
     LAB_HIP(c, launch_gemm_i8(g, nt, c->stream));
     if (prof) {
       LAB_HIP(c, hipEventRecord(c->prof_events[c->prof_used++].second, c->stream));
-      c->prof_kernel = nt == 4 ? "k_gemm_i8<4>" : nt == 2 ? "k_gemm_i8<2>" : "k_gemm_i8<1>";
+      c->prof_kernel = nt == 8 ? "k_gemm_i8<8>" : nt == 4 ? "k_gemm_i8<4>" : nt == 2 ? "k_gemm_i8<2>" : "k_gemm_i8<1>";
       // the matrix digit planes once, the B-operand tiles once per 32-row block (from L2), the residues out
       c->prof_bytes += (double)D * pl * m->rt_count * m->kt_count * 1024 + (double)D * m->kt_count * nt * 1024 +
                        (double)ns_valid * m->rows * D * 4;
@@ -156,7 +156,7 @@ int mat8_basis(const lab_mat8* m) { return m->basis; }
 
 extern "C" int lab_matvec_sum_mfma(lab_ctx* c, lab_vec* out, size_t out_off, const lab_mat8* m, const lab_vec* V, size_t v_off, int ns) {
   if (!c || !m) return LAB_ERR_ARG;
-  if (ns != 8 && ns != 16 && ns != 32) return fail(c, LAB_ERR_ARG, "lab_matvec_sum_mfma: ns must be 8, 16 or 32");
+  if (ns != 8 && ns != 16 && ns != 32 && ns != 64) return fail(c, LAB_ERR_ARG, "lab_matvec_sum_mfma: ns must be 8, 16, 32 or 64");
   int rc;
   if ((rc = check_range(c, out, out_off, (size_t)ns * m->rows, "lab_matvec_sum_mfma(out)"))) return rc;
   if ((rc = check_range(c, V, v_off, (size_t)ns * m->nmat * m->cols, "lab_matvec_sum_mfma(V)"))) return rc;

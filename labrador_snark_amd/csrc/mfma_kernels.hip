@@ -155,9 +155,11 @@ template <int NT>
 __global__ void __launch_bounds__(256)
 k_gemm_i8(const Gemm8Args a) {
   // B staging during the K loop (2 x KS*NT KiB), the four waves' int32 tiles afterwards (4 x NT*4 KiB)
-  __shared__ u32x4_t lds[4 * NT * 16 * 64 / 4];
-  static_assert(2 * G8_KS * NT * 64 <= 4 * NT * 16 * 64 / 4, "the B stage fits the recombination buffer");
+  constexpr int RN = NT > 4 ? 4 : NT;              // column tiles recombined per pass (NT = 8: two passes of 4)
+  constexpr int LQ = 2 * G8_KS * NT * 64 > 4 * RN * 16 * 64 / 4 ? 2 * G8_KS * NT * 64 : 4 * RN * 16 * 64 / 4;
+  __shared__ u32x4_t lds[LQ];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;   // LDS byte address
   const unsigned planes = a.planes, rt_count = a.rt_count, kt_count = a.kt_count;
   const unsigned x = blockIdx.x & 7, seq = blockIdx.x >> 3;
   const unsigned per_j = a.rgroups * a.njobs;
@@ -199,15 +201,28 @@ k_gemm_i8(const Gemm8Args a) {
     const int buf = st & 1;
     if (st + 1 < nstages) loadB(st + 1);           // issued before the A loads: waiting for it leaves those in flight
     if (st + 2 < nstages) loadA(st + 2, nxt);
+    // B fragments are read from LDS PF multiplies ahead of their use (a 32x32x32 MFMA issues in 32 cycles, an LDS
+    // read takes ~100): fragment i of the stage is tile (k-step i / NT, column tile i % NT).  The reads are inline
+    // asm with counted waits: left to the scheduler they are sunk next to their use and every other MFMA waits
+    // a full LDS latency.
+    constexpr int NM = G8_KS * NT, PF = 4;
+    const uint32_t fbase = lds_base + (uint32_t)buf * (BQ * 16) + lane * 16;
+    u32x4_t fr[PF];
 #pragma unroll
-    for (int s = 0; s < G8_KS; s++) {
-      const i32x4_t af = {(int)cur[s].x, (int)cur[s].y, (int)cur[s].z, (int)cur[s].w};
+    for (int i = 0; i < PF; i++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[i]) : "v"(fbase), "n"(i * 1024));
 #pragma unroll
-      for (int n = 0; n < NT; n++) {
-        const u32x4_t bq = lds[buf * BQ + (s * NT + n) * 64 + lane];
-        const i32x4_t bf = {(int)bq.x, (int)bq.y, (int)bq.z, (int)bq.w};
-        acc[n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[n], 0, 0, 0);
-      }
+    for (int i = 0; i < NM; i++) {
+      const int ks = i / NT, n = i % NT;
+      const i32x4_t af = {(int)cur[ks].x, (int)cur[ks].y, (int)cur[ks].z, (int)cur[ks].w};
+      // fragment i has landed once at most the reads issued after it are outstanding
+      if (NM - 1 - i >= PF - 1) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fr[i % PF]) : "n"(PF - 1));
+      else if (NM - 1 - i == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fr[i % PF]));
+      else if (NM - 1 - i == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fr[i % PF]));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[i % PF]));
+      const u32x4_t bq = fr[i % PF];
+      const i32x4_t bf = {(int)bq.x, (int)bq.y, (int)bq.z, (int)bq.w};
+      acc[n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[n], 0, 0, 0);
+      if (i + PF < NM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[i % PF]) : "v"(fbase), "n"((i + PF) * 1024));
     }
     if (st + 1 < nstages) parkB(buf ^ 1);
     __syncthreads();
@@ -222,13 +237,22 @@ k_gemm_i8(const Gemm8Args a) {
     step(st + 1, a1, a0);
     step(st + 2, a2, a1);
   }
-  // ---- recombination.  Wave w parks tile n, register g, lane l at dl[((w*NT + n)*16 + g)*64 + l]; element (row, col)
-  // of a 32x32 tile sits in register g = (row & 3) | ((row >> 3) << 2) of lane ((row >> 2) & 1) * 32 + col.
+  // ---- recombination.  Wave w parks column tile n (compact index nc), register g, lane l at
+  // dl[((w*RN + nc)*16 + g)*64 + l]; element (row, col) of a 32x32 tile sits in register
+  // g = (row & 3) | ((row >> 3) << 2) of lane ((row >> 2) & 1) * 32 + col.  With 8 column tiles (64 sets x 4 planes:
+  // column n = i'*64 + s lies in tile 2i' + s/32) the sets are recombined in two passes of 32, each parking the four
+  // tiles of its half.
   int32_t* dl = reinterpret_cast<int32_t*>(lds);
+  constexpr int HALVES = NT / RN;
+#pragma unroll
+  for (int half = 0; half < HALVES; half++) {
+  if (half) __syncthreads();                      // everybody finished reading the first half
 #pragma unroll
   for (int n = 0; n < NT; n++)
+    if (n % HALVES == half) {
 #pragma unroll
-    for (int g = 0; g < 16; g++) dl[((w * NT + n) * 16 + g) * 64 + lane] = acc[n][g];
+      for (int g = 0; g < 16; g++) dl[((w * RN + n / HALVES) * 16 + g) * 64 + lane] = acc[n][g];
+    }
   __syncthreads();
   // out = sum_{i,i'} 256^(i+i') D_i[row][(i',s)] mod p.  For the 30-bit limb primes everything stays in 32-bit
   // conditional subtractions and one Montgomery reduction: |D| <= K * 2^14 < 2^31 - 766 (K < 2^17 - 1 is enforced at pack
@@ -250,10 +274,10 @@ k_gemm_i8(const Gemm8Args a) {
     }
   }
   const double inv_p = tab->inv_p;
-  const unsigned ns = a.ns;
+  const unsigned ns = a.ns, nsh = ns / HALVES;     // sets per pass
   uint32_t* out = a.out + (size_t)job * a.out_job_stride;
-  for (unsigned o = t; o < tiles_per_block * 32 * ns; o += 256) {
-    const unsigned s = o % ns, row = (o / ns) % 32, tl = o / (ns * 32);
+  for (unsigned o = t; o < tiles_per_block * 32 * nsh; o += 256) {
+    const unsigned s = half * nsh + o % nsh, row = (o / nsh) % 32, tl = o / (nsh * 32);
     const unsigned grow = (rg * tiles_per_block + tl) * 32 + row;
     if (s >= a.ns_valid || grow >= a.rows) continue;
     const unsigned g = (row & 3) | ((row >> 3) << 2), lh = ((row >> 2) & 1) * 32;
@@ -266,7 +290,7 @@ k_gemm_i8(const Gemm8Args a) {
         for (unsigned pv = 0; pv < 4; pv++) {
           if (pi < planes && pv < planes) {
             const unsigned n = pv * ns + s;
-            const int32_t d = dl[(((tl * planes + pi) * NT + n / 32) * 16 + g) * 64 + lh + (n % 32)];
+            const int32_t d = dl[(((tl * planes + pi) * RN + (n / 32) / HALVES) * 16 + g) * 64 + lh + (n % 32)];
             ct[pi + pv] += csub(csub((uint32_t)d + p2, p2), p);      // canonical residue; at most 4 per c_t: < 4p < 2^32
           }
         }
@@ -289,7 +313,7 @@ k_gemm_i8(const Gemm8Args a) {
         for (unsigned pv = 0; pv < 4; pv++) {
           if (pi < planes && pv < planes) {
             const unsigned n = pv * ns + s;
-            ct[pi + pv] += dl[(((tl * planes + pi) * NT + n / 32) * 16 + g) * 64 + lh + (n % 32)];
+            ct[pi + pv] += dl[(((tl * planes + pi) * RN + (n / 32) / HALVES) * 16 + g) * 64 + lh + (n % 32)];
           }
         }
       int64_t r = 0;
@@ -304,6 +328,7 @@ k_gemm_i8(const Gemm8Args a) {
     if (a.stage) a.stage[(((size_t)job * D + j) * (rt_count * 32) + grow) * ns + s] = res;
     else out[(size_t)s * a.out_set_stride + (size_t)grow * D + j] = res;
   }
+  }  // half
 }
 
 // stage[job][j][row][s] -> out[job*out_job_stride + s*out_set_stride + row*64 + j]; block = (row, job)
@@ -337,6 +362,7 @@ hipError_t launch_gemm_i8(const Gemm8Args& a, size_t nt, hipStream_t s) {
     case 1: hipLaunchKernelGGL((k_gemm_i8<1>), g, dim3(256), 0, s, a); break;
     case 2: hipLaunchKernelGGL((k_gemm_i8<2>), g, dim3(256), 0, s, a); break;
     case 4: hipLaunchKernelGGL((k_gemm_i8<4>), g, dim3(256), 0, s, a); break;
+    case 8: hipLaunchKernelGGL((k_gemm_i8<8>), g, dim3(256), 0, s, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

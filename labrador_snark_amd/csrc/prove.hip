@@ -170,7 +170,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
              Staging::need(x->beta, D * 8) + Staging::need(x->c, r * D * 8);
   }
   // int8-MFMA step 3: padded set count of the largest group and its scratch (B-operand tiles + int32 results)
-  const int mf_ns = np > 16 ? 32 : np > 8 ? 16 : 8;
+  const int mf_ns = np > 32 ? 64 : np > 16 ? 32 : np > 8 ? 16 : 8;
   size_t mf_bytes = b8 ? mfma_scratch_bytes(b8, mf_ns, 1) + 4096 : 0;
   const int a8_ns = r <= 8 ? 8 : r <= 16 ? 16 : 32;       // witness columns per Ajtai GEMM pass
   if (a8 && mfma_scratch_bytes(a8, a8_ns, np) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(a8, a8_ns, np) + 4096;
@@ -296,9 +296,9 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if ((rc = to_hat_jobs(JP(&Job::cTdec), hTdec, rk * t1, true))) return rc;
 
   // ================= step 3 (:101-132) for the whole batch: lhs_j = sum_{i,k} B_ik t_{j,i}^(k); B streamed once per group
-  for (size_t j0 = 0; b8 && j0 < np;) {   // matrix cores: up to 32 proofs per pass over B, result written in place
+  for (size_t j0 = 0; b8 && j0 < np;) {   // matrix cores: up to 64 proofs per pass over B, result written in place
     const size_t left = np - j0;
-    const int ns = left > 16 ? 32 : left > 8 ? 16 : 8, valid = (int)(left < (size_t)ns ? left : (size_t)ns);
+    const int ns = left > 32 ? 64 : left > 16 ? 32 : left > 8 ? 16 : 8, valid = (int)(left < (size_t)ns ? left : (size_t)ns);
     if ((rc = matvec_mfma_impl(c, HD(j0, hlhs), perd * D, b8, HD(j0, hTdec), perd * D, ns, valid, mf_scratch, D, 1, 0, 0))) return rc;
     j0 += valid;
   }

@@ -326,7 +326,7 @@ def test_axpy_commit_batched_all_kernels(nb, nterms, length, compact):
     ctx.close()
 
 
-@pytest.mark.parametrize("ns", [8, 16, 32])
+@pytest.mark.parametrize("ns", [8, 16, 32, 64])
 @pytest.mark.parametrize("nmat,rows,cols", [(3, 40, 37), (2, 64, 64), (1, 100, 200), (5, 31, 7)])
 @pytest.mark.parametrize("compact", [False, True])
 def test_matvec_sum_mfma_digit_basis(ns, nmat, rows, cols, compact):

@@ -210,7 +210,7 @@ def test_prove_core_batch_equals_separate_proofs(nb, kappa1, compact):
     ctx.close()
 
 
-@pytest.mark.parametrize("nb,kappa1", [(1, 20), (5, 20), (9, 64), (20, 40), (33, 20)])
+@pytest.mark.parametrize("nb,kappa1", [(1, 20), (5, 20), (9, 64), (20, 40), (33, 20), (64, 20), (66, 20)])
 @pytest.mark.parametrize("compact", [False, True])
 def test_prove_core_batch_on_matrix_cores(nb, kappa1, compact):
     # step 3 as exact int8 GEMMs (B packed with lab_mat8_pack, up to 32 proofs per pass, groups padded to 8/16/32
