@@ -38,8 +38,9 @@ def biggest(kind, name):
 fs, ws = biggest("fetch", "FETCH_SIZE"), biggest("write", "WRITE_SIZE")
 alg = bench["roofline"]["algorithmic_bytes_per_launch"]
 fetch_bytes, write_bytes = fs[0] * 1024 * 2, ws[0] * 1024
-out = {"kernel": "lab::" + DOM + " (step-3 launch of bench.py: nmat=96, rows=1024, cols=1024, the u32 limbs, all proofs of the step)",
+out = {"kernel": "lab::" + DOM + " (step-3 launch of bench.py: nmat=96, rows=1024, cols=1024, all proofs of the step; one 30-bit limb per launch on the matrix-core path, both u32 limbs on the multiply-add path)",
        "workload_key": [cfg["q"], cfg["n"], cfg["r"], cfg["kappa"], cfg["nlimbs"], cfg["crs_basis"] != "main basis", cfg["proofs_per_step_per_gpu"]],
+       "step3": "mfma" if cfg.get("step3", "").startswith("int8") else "valu",
        "FETCH_SIZE_KB_raw": fs[0], "WRITE_SIZE_KB_raw": ws[0],
        "correction": "FETCH_SIZE x2 on gfx950 for 16-B/lane coalesced streaming loads (MI355X_MICROARCH.md 'HBM'); "
                      "WRITE_SIZE exact; FETCH and WRITE collected in separate --pmc passes",
@@ -47,7 +48,7 @@ out = {"kernel": "lab::" + DOM + " (step-3 launch of bench.py: nmat=96, rows=102
        "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (fetch_bytes + write_bytes) / alg,
        "kernel_ns_under_pmc": fs[1],
        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --no-cpu-baseline "
-                  "--no-extras --steps 2 --warmup 1"}
+                  "--no-extras --steps 2 --warmup 1  (tools/run_profiles.sh)"}
 json.dump(out, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
 
 tr = list(csv.DictReader(open(newest(P + "trace/*/*_kernel_trace.csv"))))
@@ -60,7 +61,8 @@ lines = ["# rocprofv3 --kernel-trace --stats --output-format csv -- python3 benc
          "# workload: " + tb["config"]["workload"] + " | CRS: " + tb["config"]["crs_basis"],
          "# bench line under the profiler: " + json.dumps({k: tb[k] for k in ("value", "ms_per_step", "roofline")}),
          "# kernels of ONE timed step (between two consecutive step-3 mat-vec launches), from the kernel trace:"]
-seg = tr[big[-2]:big[-1]]
+per_step = max(1, len(big) // (tb["steps"] + tb["warmup"]))   # step-3 launches per bench step (one per limb and pass over B)
+seg = tr[big[-2 * per_step]:big[-per_step]]
 agg = collections.OrderedDict()
 for r in seg:
     k = r["Kernel_Name"].split("(")[0]
