@@ -181,26 +181,37 @@ k_gemm_i8(const Gemm8Args a) {
     for (int g = 0; g < 16; g++) acc[n][g] = 0;
 
   const unsigned nstages = kt_count / G8_KS;       // kt_count is padded to a multiple of 3 * G8_KS
+  const bool reuse_a = a.njobs > 1;
   u32x4_t a0[G8_KS], a1[G8_KS], a2[G8_KS];
-  u32x4_t bNxt[BPT];
+  // B operands on their way to LDS: up to 4 column tiles a ring of 3 stages like A (two stages in flight: sums as
+  // short as K = 1024 are 8 stages, there is no steady state to hide a one-stage prefetch behind); with 8 column
+  // tiles (long sums only) one stage, for the registers
+  constexpr bool BRING = NT <= 4;
+  u32x4_t b0[BPT], b1[BRING ? BPT : 1], b2[BRING ? BPT : 1];
   auto loadA = [&](unsigned st, u32x4_t (&dst)[G8_KS]) {
 #pragma unroll
-    for (int s = 0; s < G8_KS; s++) dst[s] = __builtin_nontemporal_load(A + ((size_t)st * G8_KS + s) * 64);
+    for (int s = 0; s < G8_KS; s++)   // read once (outer commitment): non-temporal; shared by many jobs (Ajtai): keep it in L2
+      dst[s] = reuse_a ? A[((size_t)st * G8_KS + s) * 64] : __builtin_nontemporal_load(A + ((size_t)st * G8_KS + s) * 64);
   };
-  auto loadB = [&](unsigned st) {
+  auto loadB = [&](unsigned st, u32x4_t (&dst)[BPT]) {
 #pragma unroll
-    for (int q = 0; q < BPT; q++) bNxt[q] = B[(size_t)st * BQ + t + q * 256];
+    for (int q = 0; q < BPT; q++) dst[q] = B[(size_t)st * BQ + t + q * 256];
   };
-  auto parkB = [&](int buf) {
+  auto parkB = [&](int buf, const u32x4_t (&src)[BPT]) {
 #pragma unroll
-    for (int q = 0; q < BPT; q++) lds[buf * BQ + t + q * 256] = bNxt[q];
+    for (int q = 0; q < BPT; q++) lds[buf * BQ + t + q * 256] = src[q];
   };
-  // one stage: multiply stage st (A operands in `cur`, B operands in LDS buffer st & 1) while stage st+1's B operands
-  // and stage st+2's A operands (into `nxt`, the ring slot stage st-1 used) are fetched
-  auto step = [&](unsigned st, u32x4_t (&cur)[G8_KS], u32x4_t (&nxt)[G8_KS]) {
+  // one stage: multiply stage st (A operands in `cur`, B operands in LDS buffer st & 1) while later stages' operands
+  // are fetched: A of stage st+2 into `nxt` (the ring slot stage st-1 used); B of stage st+2 into `bld` with the ring
+  // (st+1 without), and at the end of the stage the B operands of stage st+1 (`bpk`) are parked in the other LDS buffer
+  auto step = [&](unsigned st, u32x4_t (&cur)[G8_KS], u32x4_t (&nxt)[G8_KS], auto& bld, auto& bpk) {
     const int buf = st & 1;
-    if (st + 1 < nstages) loadB(st + 1);           // issued before the A loads: waiting for it leaves those in flight
-    if (st + 2 < nstages) loadA(st + 2, nxt);
+    if constexpr (BRING) {
+      if (st + 2 < nstages) { loadB(st + 2, bld); loadA(st + 2, nxt); }
+    } else {
+      if (st + 1 < nstages) loadB(st + 1, bld);    // issued before the A loads: waiting for it leaves those in flight
+      if (st + 2 < nstages) loadA(st + 2, nxt);
+    }
     // B fragments are read from LDS PF multiplies ahead of their use (a 32x32x32 MFMA issues in 32 cycles, an LDS
     // read takes ~100): fragment i of the stage is tile (k-step i / NT, column tile i % NT).  The reads are inline
     // asm with counted waits: left to the scheduler they are sunk next to their use and every other MFMA waits
@@ -224,18 +235,29 @@ k_gemm_i8(const Gemm8Args a) {
       acc[n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[n], 0, 0, 0);
       if (i + PF < NM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[i % PF]) : "v"(fbase), "n"((i + PF) * 1024));
     }
-    if (st + 1 < nstages) parkB(buf ^ 1);
+    if (st + 1 < nstages) parkB(buf ^ 1, bpk);
     __syncthreads();
   };
-  loadB(0);
+  loadB(0, b0);
   loadA(0, a0);
-  if (nstages > 1) loadA(1, a1);
-  parkB(0);
-  __syncthreads();
-  for (unsigned st = 0; st < nstages; st += 3) {   // nstages is a multiple of 3 (kt_count is padded to 12 k-tiles)
-    step(st, a0, a2);
-    step(st + 1, a1, a0);
-    step(st + 2, a2, a1);
+  if constexpr (BRING) {
+    if (nstages > 1) { loadB(1, b1); loadA(1, a1); }
+    parkB(0, b0);
+    __syncthreads();
+    for (unsigned st = 0; st < nstages; st += 3) {   // nstages is a multiple of 3 (kt_count is padded to 12 k-tiles)
+      step(st, a0, a2, b2, b1);       // fetch B(st+2) -> b2, park B(st+1) = b1
+      step(st + 1, a1, a0, b0, b2);
+      step(st + 2, a2, a1, b1, b0);
+    }
+  } else {
+    if (nstages > 1) loadA(1, a1);
+    parkB(0, b0);
+    __syncthreads();
+    for (unsigned st = 0; st < nstages; st += 3) {
+      step(st, a0, a2, b0, b0);       // fetch B(st+1) -> b0, park it at the end of the same stage
+      step(st + 1, a1, a0, b0, b0);
+      step(st + 2, a2, a1, b0, b0);
+    }
   }
   // ---- recombination.  Wave w parks column tile n (compact index nc), register g, lane l at
   // dl[((w*RN + nc)*16 + g)*64 + l]; element (row, col) of a 32x32 tile sits in register
