@@ -490,8 +490,9 @@ int lab::from_hat(lab_ctx* c, ConstHatView src, size_t count, uint32_t* tmp, uin
 }
 
 int lab::to_hat(lab_ctx* c, const uint64_t* dcoeffs, HatView dst, size_t count, int basis) {
-  LAB_HIP(c, launch_reduce_u64(dcoeffs, dst, count, basis_nlimbs(c, basis), basis_tabs(c, basis), c->stream));
-  LAB_HIP(c, launch_ntt(true, dst, dst, count, basis_nlimbs(c, basis), basis_tabs(c, basis), 0, c->stream));
+  JobPtrs src;
+  src.p[0] = const_cast<uint64_t*>(dcoeffs);
+  LAB_HIP(c, launch_to_hat_fused(src, dst, 0, count, basis_nlimbs(c, basis), basis_tabs(c, basis), 1, c->stream));   // reduce + NTT
   return LAB_OK;
 }
 

@@ -73,6 +73,85 @@ k_reduce_u64(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, size_
   }
 }
 
+// v < 2^40 mod a prime p < 2^16 (the small limb of the digit basis): Barrett with m ~ 2^32 / p, all in 32 bits.
+// umulhi(x, m) underestimates floor(x / p) by at most 2, so the remainder is below 3p < 2^18.
+__device__ __forceinline__ uint32_t reduce_small16(uint32_t hi8, uint32_t lo, uint32_t p, uint32_t m, uint32_t r1) {
+  uint32_t b = lo - __umulhi(lo, m) * p;          // lo mod p, in [0, 3p)
+  uint32_t s = hi8 * r1 + b;                       // hi * (2^32 mod p) + ...: < 2^8 * 2^16 + 2^18
+  s -= __umulhi(s, m) * p;
+  return csub(csub(s, 2 * p), p);
+}
+
+// ---- to_hat in one pass: coefficients (u64 mod q) -> residues -> forward NTT, for every limb, without the
+// intermediate residue planes (k_reduce_u64 + k_ntt64 move 44 bytes per coefficient, this kernel 8 + 4 per limb).
+// One wave per block, one polynomial per thread: the wave's 64 polynomials (32 KiB of u64) come in two halves of 32
+// coefficients through the LDS tile (lane l, iteration i fetches the 16-byte piece i*64 + l of the half: polynomial
+// (i*64 + l) / 16, piece % 16 — 256 B contiguous per polynomial), are read back transposed (row pitch 68 words:
+// conflict-free) and stay in registers while each limb is reduced, transformed and stored.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_to_hat_fused(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, size_t dst_js, size_t count, int nlimbs,
+               const LimbTable* __restrict__ tabs) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[TILE_WORDS];
+  const uint64_t* __restrict__ coeffs = static_cast<const uint64_t*>(src.p[blockIdx.y]);
+  dst += (size_t)blockIdx.y * dst_js;
+  const size_t base = (size_t)blockIdx.x * 64;
+  const int lane = threadIdx.x;
+  // q < 2^40: a coefficient is a 32-bit low word and an 8-bit high part (packed four to a register)
+  uint32_t clo[D], chi[D / 4];
+#pragma unroll
+  for (int k = 0; k < D / 4; k++) chi[k] = 0;
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    u32x4_t v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int idx = i * 64 + lane, poly = idx >> 4, piece = idx & 15;
+      const u32x4_t z = {0, 0, 0, 0};
+      v[i] = base + poly < count
+                 ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(coeffs + (base + poly) * D + half * 32) + piece)
+                 : z;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int idx = i * 64 + lane, poly = idx >> 4, piece = idx & 15;
+      *reinterpret_cast<u32x4_t*>(lds + poly * TILE_PITCH + piece * 4) = v[i];
+    }
+    __syncthreads();   // block == one wave
+#pragma unroll
+    for (int piece = 0; piece < 16; piece++) {
+      const u32x4_t t = *reinterpret_cast<const u32x4_t*>(lds + lane * TILE_PITCH + piece * 4);
+      const int k = half * 32 + piece * 2;
+      clo[k] = t.x; clo[k + 1] = t.z;
+      chi[k / 4] |= ((t.y & 0xFFu) << (8 * (k & 3))) | ((t.w & 0xFFu) << (8 * ((k + 1) & 3)));
+    }
+    __syncthreads();
+  }
+#pragma unroll 1
+  for (int l = 0; l < nlimbs; l++) {
+    const LimbTable* tab = tabs + l;
+    uint32_t x[D];
+    if (tab->p > (1u << 29)) {
+#pragma unroll
+      for (int k = 0; k < D; k++) x[k] = reduce_u40(((uint64_t)((chi[k / 4] >> (8 * (k & 3))) & 0xFFu) << 32) | clo[k], *tab);
+    } else {   // the small limb of the digit basis (p < 2^16)
+      const uint32_t p = tab->p, m = (uint32_t)(4294967296.0 * tab->inv_p) - 1, r1 = tab->r1;
+#pragma unroll
+      for (int k = 0; k < D; k++) x[k] = reduce_small16((chi[k / 4] >> (8 * (k & 3))) & 0xFFu, clo[k], p, m, r1);
+    }
+    ntt64_forward(x, tab);
+    tile_store_u32(x, dst + (size_t)l * dst_ps, base, count, lds, lane);
+  }
+}
+
+hipError_t launch_to_hat_fused(const JobPtrs& coeffs, HatView dst, size_t dst_js, size_t count, int nlimbs, const LimbTable* tabs,
+                               size_t njobs, hipStream_t s) {
+  if (count == 0 || njobs == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_to_hat_fused, dim3((unsigned)((count + 63) / 64), (unsigned)njobs), dim3(64), 0, s, coeffs, dst.base,
+                     dst.plane_stride, dst_js, count, nlimbs, tabs);
+  return hipGetLastError();
+}
+
 hipError_t launch_reduce_u64_jobs(const JobPtrs& coeffs, HatView dst, size_t dst_js, size_t count, int nlimbs,
                                   const LimbTable* tabs, size_t njobs, hipStream_t s) {
   if (count == 0 || njobs == 0) return hipSuccess;

@@ -229,8 +229,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     const int basis = darena ? bdig : 0;
     HatView dst = darena ? HD(0, off) : HV(0, off);
     const size_t st = darena ? jsd : js;
-    LAB_HIP(c, launch_reduce_u64_jobs(src, dst, st, count, basis_nlimbs(c, basis), basis_tabs(c, basis), np, s));
-    LAB_HIP(c, launch_ntt(true, dst, dst, count, basis_nlimbs(c, basis), basis_tabs(c, basis), 0, s, np, st, st));
+    LAB_HIP(c, launch_to_hat_fused(src, dst, st, count, basis_nlimbs(c, basis), basis_tabs(c, basis), np, s));   // reduce + NTT
     return LAB_OK;
   };
   auto from_hat_jobs = [&](size_t off, size_t count, const JobPtrs& dst, bool darena) -> int {
