@@ -64,7 +64,8 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
     g.out = out.base + (size_t)l * out.plane_stride; g.out_set_stride = out_set_stride; g.out_job_stride = out_job_stride;
     g.M8 = m->d[l]; g.V8 = v8; g.v8_job_stride = v8_stride;
     g.planes = (unsigned)pl; g.rt_count = (unsigned)m->rt_count; g.kt_count = (unsigned)m->kt_count;
-    g.rgroups = (unsigned)((m->rt_count + 4 / pl - 1) / (4 / pl)); g.njobs = (unsigned)njobs; g.rows = (unsigned)m->rows;
+    const int waves = gemm_i8_waves(pl, m->rt_count, nt);
+    g.rgroups = (unsigned)((m->rt_count + waves / pl - 1) / (waves / pl)); g.njobs = (unsigned)njobs; g.rows = (unsigned)m->rows;
     g.ns = (unsigned)ns; g.ns_valid = (unsigned)ns_valid; g.p = primes[l];
     g.tab = (m->basis ? c->dg_tabs : c->d_tabs) + l;
     g.stage = stage;
@@ -76,7 +77,7 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
       c->prof_events.emplace_back(a, b);
     }
     if (prof) LAB_HIP(c, hipEventRecord(c->prof_events[c->prof_used].first, c->stream));
-    LAB_HIP(c, launch_gemm_i8(g, nt, c->stream));
+    LAB_HIP(c, launch_gemm_i8(g, nt, waves, c->stream));
     if (prof) {
       LAB_HIP(c, hipEventRecord(c->prof_events[c->prof_used++].second, c->stream));
       c->prof_kernel = nt == 8 ? "k_gemm_i8<8>" : nt == 4 ? "k_gemm_i8<4>" : nt == 2 ? "k_gemm_i8<2>" : "k_gemm_i8<1>";

@@ -14,6 +14,7 @@
 // A operand, 1 KiB contiguous), 4 bytes per residue as before.  The vectors are re-packed per batch into B-operand
 // tiles V8[limb][slot j][k tile][col tile][lane][16 B], column n = i' * NS + s.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace lab {
 
@@ -151,10 +152,13 @@ hipError_t launch_pack_vectors_i8(int ns, int ns_valid, int8_t* dst, const uint3
 constexpr int G8_KS = 4;
 
 
-template <int NT>
-__global__ void __launch_bounds__(256)
+// WAVES = 4 or 8 waves per block: with 8 the block owns two 32-row tiles (of a 4-plane limb) that share every B stage,
+// which halves the L2 -> LDS operand traffic per multiply and the B staging registers per thread.
+template <int NT, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
 k_gemm_i8(const Gemm8Args a) {
-  // B staging during the K loop (2 x KS*NT KiB), the four waves' int32 tiles afterwards (4 x NT*4 KiB)
+  // B staging during the K loop (2 x KS*NT KiB), afterwards the int32 tiles of four waves at a time (4 x RN*4 KiB)
+  constexpr int NTHR = 64 * WAVES;
   constexpr int RN = NT > 4 ? 4 : NT;              // column tiles recombined per pass (NT = 8: two passes of 4)
   constexpr int LQ = 2 * G8_KS * NT * 64 > 4 * RN * 16 * 64 / 4 ? 2 * G8_KS * NT * 64 : 4 * RN * 16 * 64 / 4;
   __shared__ u32x4_t lds[LQ];
@@ -165,14 +169,14 @@ k_gemm_i8(const Gemm8Args a) {
   const unsigned per_j = a.rgroups * a.njobs;
   const unsigned j = x + 8 * (seq / per_j), sub = seq % per_j;
   const unsigned job = sub % a.njobs, rg = sub / a.njobs;
-  const unsigned tiles_per_block = 4 / planes;     // row tiles per block
+  const unsigned tiles_per_block = WAVES / planes; // row tiles per block
   const unsigned i = w % planes, rtl = w / planes, rt = rg * tiles_per_block + rtl;
   const unsigned ji = j * planes + i;
   const u32x4_t* A = reinterpret_cast<const u32x4_t*>(a.M8) + ((size_t)ji * rt_count + min(rt, rt_count - 1)) * kt_count * 64 + lane;
   const u32x4_t* B = reinterpret_cast<const u32x4_t*>(a.V8 + (size_t)job * a.v8_job_stride) + (size_t)j * kt_count * NT * 64;
   constexpr int BQ = G8_KS * NT * 64;              // B quads per stage
-  constexpr int BPT = BQ / 256;                    // per thread (= NT)
-  static_assert(BQ % 256 == 0, "a stage's B operands are a whole number of quads per thread");
+  constexpr int BPT = BQ / NTHR;                   // per thread
+  static_assert(BQ % NTHR == 0, "a stage's B operands are a whole number of quads per thread");
 
   i32x16_t acc[NT];
 #pragma unroll
@@ -186,7 +190,7 @@ k_gemm_i8(const Gemm8Args a) {
   // B operands on their way to LDS: up to 4 column tiles a ring of 3 stages like A (two stages in flight: sums as
   // short as K = 1024 are 8 stages, there is no steady state to hide a one-stage prefetch behind); with 8 column
   // tiles (long sums only) one stage, for the registers
-  constexpr bool BRING = NT <= 4;
+  constexpr bool BRING = NT * 4 / WAVES <= 4;      // i.e. BPT <= 4
   u32x4_t b0[BPT], b1[BRING ? BPT : 1], b2[BRING ? BPT : 1];
   auto loadA = [&](unsigned st, u32x4_t (&dst)[G8_KS]) {
 #pragma unroll
@@ -195,11 +199,11 @@ k_gemm_i8(const Gemm8Args a) {
   };
   auto loadB = [&](unsigned st, u32x4_t (&dst)[BPT]) {
 #pragma unroll
-    for (int q = 0; q < BPT; q++) dst[q] = B[(size_t)st * BQ + t + q * 256];
+    for (int q = 0; q < BPT; q++) dst[q] = B[(size_t)st * BQ + t + q * NTHR];
   };
   auto parkB = [&](int buf, const u32x4_t (&src)[BPT]) {
 #pragma unroll
-    for (int q = 0; q < BPT; q++) lds[buf * BQ + t + q * 256] = src[q];
+    for (int q = 0; q < BPT; q++) lds[buf * BQ + t + q * NTHR] = src[q];
   };
   // one stage: multiply stage st (A operands in `cur`, B operands in LDS buffer st & 1) while later stages' operands
   // are fetched: A of stage st+2 into `nxt` (the ring slot stage st-1 used); B of stage st+2 into `bld` with the ring
@@ -266,15 +270,23 @@ k_gemm_i8(const Gemm8Args a) {
   // tiles of its half.
   int32_t* dl = reinterpret_cast<int32_t*>(lds);
   constexpr int HALVES = NT / RN;
+  constexpr int WG = WAVES / 4;                     // groups of four waves take turns in the buffer
+  const unsigned tiles_per_pass = 4 / planes;       // row tiles whose planes sit in one group of four waves
+  bool first_pass = true;
+#pragma unroll
+  for (int wg = 0; wg < WG; wg++)
 #pragma unroll
   for (int half = 0; half < HALVES; half++) {
-  if (half) __syncthreads();                      // everybody finished reading the first half
+  if (!first_pass) __syncthreads();               // everybody finished reading the previous pass
+  first_pass = false;
+  if (w / 4 == wg) {
 #pragma unroll
-  for (int n = 0; n < NT; n++)
-    if (n % HALVES == half) {
+    for (int n = 0; n < NT; n++)
+      if (n % HALVES == half) {
 #pragma unroll
-      for (int g = 0; g < 16; g++) dl[((w * RN + n / HALVES) * 16 + g) * 64 + lane] = acc[n][g];
-    }
+        for (int g = 0; g < 16; g++) dl[(((w % 4) * RN + n / HALVES) * 16 + g) * 64 + lane] = acc[n][g];
+      }
+  }
   __syncthreads();
   // out = sum_{i,i'} 256^(i+i') D_i[row][(i',s)] mod p.  For the 30-bit limb primes everything stays in 32-bit
   // conditional subtractions and one Montgomery reduction: |D| <= K * 2^14 < 2^31 - 766 (K < 2^17 - 1 is enforced at pack
@@ -298,9 +310,9 @@ k_gemm_i8(const Gemm8Args a) {
   const double inv_p = tab->inv_p;
   const unsigned ns = a.ns, nsh = ns / HALVES;     // sets per pass
   uint32_t* out = a.out + (size_t)job * a.out_job_stride;
-  for (unsigned o = t; o < tiles_per_block * 32 * nsh; o += 256) {
-    const unsigned s = half * nsh + o % nsh, row = (o / nsh) % 32, tl = o / (nsh * 32);
-    const unsigned grow = (rg * tiles_per_block + tl) * 32 + row;
+  for (unsigned o = t; o < tiles_per_pass * 32 * nsh; o += NTHR) {
+    const unsigned s = half * nsh + o % nsh, row = (o / nsh) % 32, tl = o / (nsh * 32);   // tl: row tile inside this pass
+    const unsigned grow = (rg * tiles_per_block + wg * tiles_per_pass + tl) * 32 + row;
     if (s >= a.ns_valid || grow >= a.rows) continue;
     const unsigned g = (row & 3) | ((row >> 3) << 2), lh = ((row >> 2) & 1) * 32;
     uint32_t res;
@@ -350,7 +362,7 @@ k_gemm_i8(const Gemm8Args a) {
     if (a.stage) a.stage[(((size_t)job * D + j) * (rt_count * 32) + grow) * ns + s] = res;
     else out[(size_t)s * a.out_set_stride + (size_t)grow * D + j] = res;
   }
-  }  // half
+  }  // (wave group, half)
 }
 
 // stage[job][j][row][s] -> out[job*out_job_stride + s*out_set_stride + row*64 + j]; block = (row, job)
@@ -378,15 +390,30 @@ hipError_t launch_slot_transpose(uint32_t* out_plane, size_t out_set_stride, siz
   return hipGetLastError();
 }
 
-hipError_t launch_gemm_i8(const Gemm8Args& a, size_t nt, hipStream_t s) {
+// Blocks of 8 waves (two row tiles per B stage) when the limb has 4 planes, at least 2 row tiles and at least 2 column
+// tiles; the caller derives rgroups from gemm_i8_waves().  LAB_GEMM_WAVES=4 in the environment keeps 4-wave blocks.
+int gemm_i8_waves(int planes, size_t rt_count, size_t nt) {
+  static const int env = getenv("LAB_GEMM_WAVES") ? atoi(getenv("LAB_GEMM_WAVES")) : 0;
+  if (env == 4) return 4;
+  return planes == 4 && rt_count >= 2 && nt >= 2 ? 8 : 4;
+}
+
+hipError_t launch_gemm_i8(const Gemm8Args& a, size_t nt, int waves, hipStream_t s) {
   dim3 g((unsigned)(D * a.rgroups * a.njobs));     // D = 64 slots = 8 per XCD
+#define LAB_G8(NTV)                                                                                   \
+  if (waves == 8) hipLaunchKernelGGL((k_gemm_i8<NTV, 8>), g, dim3(512), 0, s, a);                     \
+  else hipLaunchKernelGGL((k_gemm_i8<NTV, 4>), g, dim3(256), 0, s, a)
   switch (nt) {
-    case 1: hipLaunchKernelGGL((k_gemm_i8<1>), g, dim3(256), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((k_gemm_i8<2>), g, dim3(256), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((k_gemm_i8<4>), g, dim3(256), 0, s, a); break;
-    case 8: hipLaunchKernelGGL((k_gemm_i8<8>), g, dim3(256), 0, s, a); break;
+    case 1:
+      if (waves != 4) return hipErrorInvalidValue;
+      hipLaunchKernelGGL((k_gemm_i8<1, 4>), g, dim3(256), 0, s, a);
+      break;
+    case 2: LAB_G8(2); break;
+    case 4: LAB_G8(4); break;
+    case 8: LAB_G8(8); break;
     default: return hipErrorInvalidValue;
   }
+#undef LAB_G8
   return hipGetLastError();
 }
 
