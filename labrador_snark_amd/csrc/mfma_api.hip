@@ -1,5 +1,7 @@
 // mfma_api.hip — host side of the int8-MFMA outer commitment (mfma_kernels.hip): the packed-matrix handle
 // (lab_mat8), the stand-alone batched op lab_matvec_sum_mfma and the helper prove.hip calls.
+#include <cstdio>
+
 #include "context.h"
 
 using namespace lab;
@@ -80,7 +82,9 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
     LAB_HIP(c, launch_gemm_i8(g, nt, waves, c->stream));
     if (prof) {
       LAB_HIP(c, hipEventRecord(c->prof_events[c->prof_used++].second, c->stream));
-      c->prof_kernel = nt == 8 ? "k_gemm_i8<8>" : nt == 4 ? "k_gemm_i8<4>" : nt == 2 ? "k_gemm_i8<2>" : "k_gemm_i8<1>";
+      static char kname[48];
+      snprintf(kname, sizeof kname, "k_gemm_i8<%d, %d>", (int)nt, waves);
+      c->prof_kernel = kname;
       // the matrix digit planes once, the B-operand tiles once per 32-row block (from L2), the residues out
       c->prof_bytes += (double)D * pl * m->rt_count * m->kt_count * 1024 + (double)D * m->kt_count * nt * 1024 +
                        (double)ns_valid * m->rows * D * 4;
