@@ -70,6 +70,8 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
     g.rgroups = (unsigned)((m->rt_count + waves / pl - 1) / (waves / pl)); g.njobs = (unsigned)njobs; g.rows = (unsigned)m->rows;
     g.ns = (unsigned)ns; g.ns_valid = (unsigned)ns_valid; g.p = primes[l];
     g.tab = (m->basis ? c->dg_tabs : c->d_tabs) + l;
+    g.pw[0] = 1 % primes[l];
+    for (int e = 1; e < 7; e++) g.pw[e] = (uint32_t)(((uint64_t)g.pw[e - 1] * 256) % primes[l]);
     g.stage = stage;
     const bool prof = c->prof_on && pl == 4 && njobs == 1 && v_k_stride == (size_t)D;
     if (prof && c->prof_used == c->prof_events.size()) {

@@ -264,7 +264,7 @@ k_gemm_i8(const Gemm8Args a) {
     }
   }
   // ---- recombination.  Wave w parks column tile n (compact index nc), register g, lane l at
-  // dl[((w*RN + nc)*16 + g)*64 + l]; element (row, col) of a 32x32 tile sits in register
+  // dl[((w*RN + nc)*16 + g)*64 + l] (register-major: the readers' 32 consecutive columns hit 32 different banks); element (row, col) of a 32x32 tile sits in register
   // g = (row & 3) | ((row >> 3) << 2) of lane ((row >> 2) & 1) * 32 + col.  With 8 column tiles (64 sets x 4 planes:
   // column n = i'*64 + s lies in tile 2i' + s/32) the sets are recombined in two passes of 32, each parking the four
   // tiles of its half.
@@ -296,17 +296,9 @@ k_gemm_i8(const Gemm8Args a) {
   const LimbTable* tab = a.tab;
   const uint32_t p2 = tab->p2, pinv = tab->pinv, r2 = tab->r2;
   const bool big = p > (1u << 29);
-  uint32_t pw[7];
-  {  // 256^e mod p by repeated doubling (8 doublings per step): no division, any p
-    uint32_t v = 1 % p;
-    pw[0] = v;
+  uint32_t pw[7];                                 // 256^e mod p, from the host
 #pragma unroll
-    for (int e = 1; e < 7; e++) {
-#pragma unroll
-      for (int d = 0; d < 8; d++) { v <<= 1; v -= v >= p ? p : 0; }
-      pw[e] = v;
-    }
-  }
+  for (int e = 0; e < 7; e++) pw[e] = a.pw[e];
   const double inv_p = tab->inv_p;
   const unsigned ns = a.ns, nsh = ns / HALVES;     // sets per pass
   uint32_t* out = a.out + (size_t)job * a.out_job_stride;
