@@ -276,6 +276,8 @@ typedef struct {
                               * kappa)); when set, step 3 of lab_prove_core[_batch] runs as int8 GEMMs over up to 64 proofs
                               * per pass and B itself may be NULL (lab_verify_core still needs B) */
   const struct lab_mat8 *A8; /* optional: lab_mat8_pack(A, a_off, 1, kappa, n): step 1 (t_i = A s_i) as int8 GEMMs */
+  const struct lab_mat8 *C8; /* optional: lab_mat8_pack(C, c_off, pairs*t2, kappa2, 1): step 4 (sum g^(k) C) as int8 GEMMs */
+  const struct lab_mat8 *D8; /* optional: lab_mat8_pack(Dm, d_off, pairs*t1, kappa2, 1): step 9 (sum h^(k) D) likewise */
 } lab_prove_input;
 
 /* The computed fields of `Transcript` (src/structs.rs:192-209); pi_i_all, psi, omega, alpha, beta, c are the tape.

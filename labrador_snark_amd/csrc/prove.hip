@@ -91,7 +91,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     if (!x->S || !x->phi || !x->a || !x->Pi || !x->omega || !x->alpha || !x->beta || !x->c)
       return fail(c, LAB_ERR_ARG, "lab_prove_core: null input array");
     if (x->n != n || x->r != r || x->kappa != kappa || x->kappa1 != k1 || x->kappa2 != k2 || x->t1 != t1 || x->t2 != t2 ||
-        x->b1 != in->b1 || x->b2 != in->b2 || x->beta_bound != in->beta_bound || x->A != in->A || x->B != in->B || x->B8 != in->B8 || x->A8 != in->A8 ||
+        x->b1 != in->b1 || x->b2 != in->b2 || x->beta_bound != in->beta_bound || x->A != in->A || x->B != in->B || x->B8 != in->B8 || x->A8 != in->A8 || x->C8 != in->C8 || x->D8 != in->D8 ||
         x->C != in->C || x->Dm != in->Dm || x->a_off != in->a_off || x->b_off != in->b_off || x->c_off != in->c_off ||
         x->d_off != in->d_off)
       return fail(c, LAB_ERR_ARG, "lab_prove_core_batch: all proofs of a batch must share dimensions, constants and the CRS");
@@ -112,6 +112,10 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   const lab_mat8* a8 = in->A8;
   if (a8 && !mat8_matches(a8, 0, 1, kappa, n))
     return fail(c, LAB_ERR_ARG, "lab_prove_core: A8 was not packed from the kappa x n matrix A in the main basis");
+  // C and D packed the same way: element (rho, m) of the "matrix" is C[m][rho], i.e. pairs*t matrices of kappa2 x 1
+  const lab_mat8 *c8 = in->C8, *d8 = in->D8;
+  if ((c8 && !mat8_matches(c8, bdig, pairs * (size_t)t2, k2, 1)) || (d8 && !mat8_matches(d8, bdig, pairs * (size_t)t1, k2, 1)))
+    return fail(c, LAB_ERR_ARG, "lab_prove_core: C8 / D8 were not packed as lab_mat8_pack(C, c_off, pairs*t2, kappa2, 1) / (D, d_off, pairs*t1, kappa2, 1)");
   if (b8 && !mat8_matches(b8, bdig, r * (size_t)t1, k1, kappa))
     return fail(c, LAB_ERR_ARG, "lab_prove_core: B8 was not packed from r*t1 matrices of kappa1 x kappa elements in the basis of C, D");
   if (in->A->basis != 0 || in->A->compact) return fail(c, LAB_ERR_ARG, "lab_prove_core: A must be a main-basis vector");
@@ -174,6 +178,8 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   size_t mf_bytes = b8 ? mfma_scratch_bytes(b8, mf_ns, 1) + 4096 : 0;
   const int a8_ns = r <= 8 ? 8 : r <= 16 ? 16 : 32;       // witness columns per Ajtai GEMM pass
   if (a8 && mfma_scratch_bytes(a8, a8_ns, np) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(a8, a8_ns, np) + 4096;
+  if (c8 && mfma_scratch_bytes(c8, mf_ns, 1) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(c8, mf_ns, 1) + 4096;
+  if (d8 && mfma_scratch_bytes(d8, mf_ns, 1) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(d8, mf_ns, 1) + 4096;
   bytes += mf_bytes;
   if ((rc = ensure_scratch(c, bytes + (1 << 16)))) return rc;
   Carver cv(c->scratch);
@@ -331,10 +337,25 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   LAB_HIP(c, launch_gather_upper_jobs(JP(&Job::cGup), JP(&Job::cG), r, np, s));
   LAB_HIP(c, launch_decompose_jobs(JP(&Job::cGdec), JP(&Job::cGup), pairs, q, (uint64_t)in->b2, t2, 1, np, s));  // [pair][k]
   if ((rc = to_hat_jobs(JP(&Job::cGdec), hGdec, pairs * t2, true))) return rc;
-  if ((rc = for_groups([&](size_t j0, int g) {   // C streamed once per group
-        return axpy_commit_batched_any(c, g, HD(j0, hrhs), perd * D, HD(j0, hGdec), perd * D, in->C, in->c_off, pairs * t2, k2,
-                                       HD(j0, hpartd), perd * D);
-      }))) return rc;
+  // sum_m digits[m] * Cm[m][rho] for every proof: on the matrix cores when Cm was packed for them (up to 64 proofs per
+  // pass), else with the multiply-add kernels in groups of 8
+  auto commit_digits = [&](const lab_mat8* m8, const lab_vec* Cm, size_t cm_off, size_t out_off, size_t dig_off, size_t nterms) -> int {
+    if (m8) {
+      for (size_t j0 = 0; j0 < np;) {
+        const size_t left = np - j0;
+        const int ns = left > 32 ? 64 : left > 16 ? 32 : left > 8 ? 16 : 8, valid = (int)(left < (size_t)ns ? left : (size_t)ns);
+        int e = matvec_mfma_impl(c, HD(j0, out_off), perd * D, m8, HD(j0, dig_off), perd * D, ns, valid, mf_scratch, D, 1, 0, 0);
+        if (e) return e;
+        j0 += valid;
+      }
+      return LAB_OK;
+    }
+    return for_groups([&](size_t j0, int g) {   // Cm streamed once per group
+      return axpy_commit_batched_any(c, g, HD(j0, out_off), perd * D, HD(j0, dig_off), perd * D, Cm, cm_off, nterms, k2,
+                                     HD(j0, hpartd), perd * D);
+    });
+  };
+  if ((rc = commit_digits(c8, in->C, in->c_off, hrhs, hGdec, pairs * t2))) return rc;
   LAB_HIP(c, launch_pointwise(PW_ADD, HD(0, hlhs), HD(0, hlhs), HD(0, hrhs), k1, Ld, tabsd, s, np, jsd, jsd, jsd));
   if ((rc = from_hat_jobs(hlhs, k1, JP(&Job::cu1), true))) return rc;
 
@@ -379,10 +400,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if ((rc = to_hat_jobs(JP(&Job::cHdec), hHdec, pairs * t1, true))) return rc;
 
   // ================= step 9 (:364-378): u_2 = sum_{i<=j,k} h_ij^(k) D_ijk ; D streamed once per group
-  if ((rc = for_groups([&](size_t j0, int g) {
-        return axpy_commit_batched_any(c, g, HD(j0, hu2), perd * D, HD(j0, hHdec), perd * D, in->Dm, in->d_off, pairs * t1, k2,
-                                       HD(j0, hpartd), perd * D);
-      }))) return rc;
+  if ((rc = commit_digits(d8, in->Dm, in->d_off, hu2, hHdec, pairs * t1))) return rc;
   if ((rc = from_hat_jobs(hu2, k2, JP(&Job::cu2), true))) return rc;
 
   // ================= step 10 (:380-399): z = sum_i c_i s_i

@@ -90,6 +90,9 @@ class ResidentCRS:
         k = self.constants
         self.B8 = Mat8(self.ctx, self.B, k.R * k.T_1, k.KAPPA_1, k.KAPPA)
         self.A8 = Mat8(self.ctx, self.A, 1, k.KAPPA, k.N)
+        pairs = k.R * (k.R + 1) // 2
+        self.C8 = Mat8(self.ctx, self.C, pairs * k.T_2, k.KAPPA_2, 1)      # element (rho, m) = C[m][rho]
+        self.D8 = Mat8(self.ctx, self.Dm, pairs * k.T_1, k.KAPPA_2, 1)
         if drop_B:
             self.ctx.synchronize()
             self.B.close()
@@ -97,7 +100,8 @@ class ResidentCRS:
         return self
 
     def close(self):
-        for v in (self.A, self.B, self.C, self.Dm, getattr(self, "B8", None), getattr(self, "A8", None)):
+        for v in (self.A, self.B, self.C, self.Dm, getattr(self, "B8", None), getattr(self, "A8", None),
+                  getattr(self, "C8", None), getattr(self, "D8", None)):
             if v is not None:
                 v.close()
 
@@ -228,6 +232,8 @@ def _prove_io(ctx, k, witness, st, crs, tape, device_outputs):
     pin.A, pin.B, pin.C, pin.Dm = crs.A._h, (crs.B._h if crs.B is not None else None), crs.C._h, crs.Dm._h
     pin.B8 = crs.B8._h if getattr(crs, "B8", None) is not None else None
     pin.A8 = crs.A8._h if getattr(crs, "A8", None) is not None else None
+    pin.C8 = crs.C8._h if getattr(crs, "C8", None) is not None else None
+    pin.D8 = crs.D8._h if getattr(crs, "D8", None) is not None else None
     pin.a_off = pin.b_off = pin.c_off = pin.d_off = 0
     Pi = tape["Pi"]
     if isinstance(Pi, np.ndarray):
@@ -303,6 +309,8 @@ def verify_core(ctx, k, st, b_poly, crs, T, tape=None):
     pin.A, pin.B, pin.C, pin.Dm = crs.A._h, (crs.B._h if crs.B is not None else None), crs.C._h, crs.Dm._h
     pin.B8 = crs.B8._h if getattr(crs, "B8", None) is not None else None
     pin.A8 = crs.A8._h if getattr(crs, "A8", None) is not None else None
+    pin.C8 = crs.C8._h if getattr(crs, "C8", None) is not None else None
+    pin.D8 = crs.D8._h if getattr(crs, "D8", None) is not None else None
     pin.a_off = pin.b_off = pin.c_off = pin.d_off = 0
     Pi = tape["Pi"]
     if isinstance(Pi, np.ndarray):
