@@ -134,7 +134,8 @@ int check_range(lab_ctx* c, const lab_vec* v, size_t off, size_t n, const char* 
 // int8-MFMA outer commitment (mfma_api.hip)
 size_t mfma_scratch_bytes(const lab_mat8* m, int ns, size_t njobs);
 int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_mat8* m, ConstHatView V, size_t v_set_stride, int ns,
-                     int ns_valid, void* scratch, size_t v_k_stride, size_t njobs, size_t out_job_stride, size_t v_job_stride);
+                     int ns_valid, void* scratch, size_t v_k_stride, size_t njobs, size_t out_job_stride, size_t v_job_stride,
+                     bool timed = false);
 bool mat8_matches(const lab_mat8* m, int basis, size_t nmat, size_t rows, size_t cols);
 int mat8_basis(const lab_mat8* m);
 // launch_matvec_partial wrapped in the profiling events when the hook is active

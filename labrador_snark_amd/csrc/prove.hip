@@ -304,7 +304,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   for (size_t j0 = 0; b8 && j0 < np;) {   // matrix cores: up to 64 proofs per pass over B, result written in place
     const size_t left = np - j0;
     const int ns = left > 32 ? 64 : left > 16 ? 32 : left > 8 ? 16 : 8, valid = (int)(left < (size_t)ns ? left : (size_t)ns);
-    if ((rc = matvec_mfma_impl(c, HD(j0, hlhs), perd * D, b8, HD(j0, hTdec), perd * D, ns, valid, mf_scratch, D, 1, 0, 0))) return rc;
+    if ((rc = matvec_mfma_impl(c, HD(j0, hlhs), perd * D, b8, HD(j0, hTdec), perd * D, ns, valid, mf_scratch, D, 1, 0, 0, true))) return rc;
     j0 += valid;
   }
   for (size_t j0 = 0; !b8 && j0 < np;) {
