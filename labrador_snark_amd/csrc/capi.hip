@@ -9,6 +9,8 @@
 
 #include <vector>
 
+#include <unordered_map>
+
 #include "context.h"
 
 using namespace lab;
@@ -39,14 +41,29 @@ int ensure_scratch(lab_ctx* ctx, size_t bytes) {
   return LAB_OK;
 }
 
+// hipPointerGetAttributes costs about a microsecond; a batch of 64 proofs asks about ~1700 pointers (every input and
+// output, several times), which was 2 ms of GPU idle time per call.  Inside a PtrCacheScope (one API call: nothing is
+// allocated or freed by the caller meanwhile) answers are remembered per address.
+static thread_local std::unordered_map<const void*, bool>* g_ptr_cache = nullptr;
+PtrCacheScope::PtrCacheScope() : owner(g_ptr_cache == nullptr) {
+  if (owner) g_ptr_cache = new std::unordered_map<const void*, bool>();
+}
+PtrCacheScope::~PtrCacheScope() {
+  if (owner) { delete g_ptr_cache; g_ptr_cache = nullptr; }
+}
+
 bool is_device_pointer(const void* p) {
+  if (g_ptr_cache) {
+    auto it = g_ptr_cache->find(p);
+    if (it != g_ptr_cache->end()) return it->second;
+  }
   hipPointerAttribute_t attr;
   hipError_t e = hipPointerGetAttributes(&attr, p);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();  // plain malloc memory: clear the sticky error
-    return false;
-  }
-  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+  bool dev = false;
+  if (e != hipSuccess) (void)hipGetLastError();  // plain malloc memory: clear the sticky error
+  else dev = attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+  if (g_ptr_cache) (*g_ptr_cache)[p] = dev;
+  return dev;
 }
 
 }  // namespace lab

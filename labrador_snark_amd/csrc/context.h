@@ -68,6 +68,12 @@ int fail(const lab_ctx* ctx, int code, const char* fmt, ...);
 // ensures ctx->scratch holds at least `bytes`; contents are not preserved
 int ensure_scratch(lab_ctx* ctx, size_t bytes);
 bool is_device_pointer(const void* p);
+// remembers is_device_pointer() answers for the lifetime of the outermost scope object on this thread
+struct PtrCacheScope {
+  bool owner;
+  PtrCacheScope();
+  ~PtrCacheScope();
+};
 
 #define LAB_HIP(ctx, expr)                                                                         \
   do {                                                                                             \

@@ -65,6 +65,7 @@ struct Job {  // device pointers of one proof of the batch
 static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const* ins, lab_transcript* const* outs, int* status) {
   if (!c) return LAB_ERR_ARG;
   if (np == 0) return LAB_OK;
+  PtrCacheScope ptr_cache;   // every boundary pointer is classified host/device once per call
   if (!ins || !outs) return fail(c, LAB_ERR_ARG, "lab_prove_core: null argument");
   for (size_t j = 0; j < np; j++)
     if (!ins[j] || !outs[j]) return fail(c, LAB_ERR_ARG, "lab_prove_core: null argument");

@@ -214,8 +214,18 @@ class Prover:
                     raise RuntimeError("failed JL...")
 
 
-def _prove_io(ctx, k, witness, st, crs, tape, device_outputs):
-    """ctypes input/output structs for one proof; returns (lab_prove_input, lab_transcript, Transcript, keep-alive list)."""
+_OUT_FIELDS = ("u_1", "projection_int", "projection", "b_prime_prime", "u_2", "z", "t_i_all", "g_mat", "h_mat")
+
+
+def _out_shapes(k):
+    return {"u_1": (k.KAPPA_1, D), "projection_int": (256,), "projection": (256,), "b_prime_prime": (D,),
+            "u_2": (k.KAPPA_2, D), "z": (k.N, D), "t_i_all": (k.R, k.KAPPA, D), "g_mat": (k.R, k.R, D), "h_mat": (k.R, k.R, D)}
+
+
+def _prove_io(ctx, k, witness, st, crs, tape, device_outputs, out_views=None):
+    """ctypes input/output structs for one proof; returns (lab_prove_input, lab_transcript, Transcript, keep-alive list).
+    out_views: preallocated device tensors for the nine outputs (prove_core_batch slices them out of one allocation
+    per field instead of nine allocations per proof)."""
     n, r = k.N, k.R
     pin = _lib.lab_prove_input()
     pin.n, pin.r, pin.kappa, pin.kappa1, pin.kappa2 = n, r, k.KAPPA, k.KAPPA_1, k.KAPPA_2
@@ -252,11 +262,15 @@ def _prove_io(ctx, k, witness, st, crs, tape, device_outputs):
         def mk(shape, dt=None):
             return np.empty(shape, dtype=np.int64 if dt == "i64" else np.uint64)
     T = Transcript()
-    T.u_1 = mk((k.KAPPA_1, D)); T.projection_int = mk((256,), None if device_outputs else "i64")
-    T.projection = mk((256,)); T.b_prime_prime = mk((D,)); T.u_2 = mk((k.KAPPA_2, D)); T.z = mk((n, D))
-    T.t_i_all = mk((r, k.KAPPA, D)); T.g_mat = mk((r, r, D)); T.h_mat = mk((r, r, D))
+    if out_views is not None:
+        for name in _OUT_FIELDS:
+            setattr(T, name, out_views[name])
+    else:
+        T.u_1 = mk((k.KAPPA_1, D)); T.projection_int = mk((256,), None if device_outputs else "i64")
+        T.projection = mk((256,)); T.b_prime_prime = mk((D,)); T.u_2 = mk((k.KAPPA_2, D)); T.z = mk((n, D))
+        T.t_i_all = mk((r, k.KAPPA, D)); T.g_mat = mk((r, r, D)); T.h_mat = mk((r, r, D))
     tr = _lib.lab_transcript()
-    for name in ("u_1", "projection_int", "projection", "b_prime_prime", "u_2", "z", "t_i_all", "g_mat", "h_mat"):
+    for name in _OUT_FIELDS:
         setattr(tr, name, _ptr(getattr(T, name)))
     T.tape = tape
     return pin, tr, T, keep
@@ -271,10 +285,15 @@ def prove_core(ctx, k, witness, st, crs, tape, device_outputs=False):
 
 def prove_core_batch(ctx, k, witnesses, states, crs, tapes, device_outputs=False, raise_on_reject=True):
     """lab_prove_core_batch: independent proofs (own witness, state, tape) under ONE common reference string; the
-    outer-commitment matrices are streamed from HBM once per group of up to 8 proofs.  Returns the list of
+    CRS matrices are streamed from HBM once per group of proofs (up to 64 on the matrix-core path).  Returns the list of
     Transcripts (bit-identical to separate prove_core calls); with raise_on_reject=False also the status codes."""
     nb = len(witnesses)
-    ios = [_prove_io(ctx, k, witnesses[j], states[j], crs, tapes[j], device_outputs) for j in range(nb)]
+    views = [None] * nb
+    if device_outputs:      # one device allocation per output field for the whole batch
+        import torch
+        big = {name: torch.empty((nb,) + shape, dtype=torch.int64, device="cuda") for name, shape in _out_shapes(k).items()}
+        views = [{name: big[name][j] for name in _OUT_FIELDS} for j in range(nb)]
+    ios = [_prove_io(ctx, k, witnesses[j], states[j], crs, tapes[j], device_outputs, views[j]) for j in range(nb)]
     pins = (C.POINTER(_lib.lab_prove_input) * nb)(*[C.pointer(io[0]) for io in ios])
     trs = (C.POINTER(_lib.lab_transcript) * nb)(*[C.pointer(io[1]) for io in ios])
     status = (C.c_int * nb)()
