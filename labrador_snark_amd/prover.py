@@ -194,6 +194,23 @@ class Transcript:
     pass
 
 
+class BatchTranscript(Transcript):
+    """Transcript j of a batch whose outputs live in one device tensor per field ([nb, ...]): the per-proof views are
+    made on first access (building 9 views for each of 64 proofs per call costs more than launching the kernels)."""
+
+    def __init__(self, big, j, tape):
+        self.__dict__["_big"], self.__dict__["_j"] = big, j
+        self.tape = tape
+
+    def __getattr__(self, name):
+        big = self.__dict__["_big"]
+        if name in big:
+            v = big[name][self.__dict__["_j"]]
+            self.__dict__[name] = v
+            return v
+        raise AttributeError(name)
+
+
 class Prover:
     def __init__(self, witness, verifier, constants, ctx):
         self.witness, self.verifier, self.constants, self.ctx = witness, verifier, constants, ctx
@@ -222,29 +239,37 @@ def _out_shapes(k):
             "u_2": (k.KAPPA_2, D), "z": (k.N, D), "t_i_all": (k.R, k.KAPPA, D), "g_mat": (k.R, k.R, D), "h_mat": (k.R, k.R, D)}
 
 
-def _prove_io(ctx, k, witness, st, crs, tape, device_outputs, out_views=None):
+def _io_template(k, crs):
+    """The fields of lab_prove_input that are the same for every proof under one CRS."""
+    pin = _lib.lab_prove_input()
+    pin.n, pin.r, pin.kappa, pin.kappa1, pin.kappa2 = k.N, k.R, k.KAPPA, k.KAPPA_1, k.KAPPA_2
+    pin.b1, pin.b2, pin.t1, pin.t2, pin.beta_bound = k.B_1, k.B_2, k.T_1, k.T_2, k.BETA_BOUND
+    pin.A, pin.B, pin.C, pin.Dm = crs.A._h, (crs.B._h if crs.B is not None else None), crs.C._h, crs.Dm._h
+    for name in ("B8", "A8", "C8", "D8"):
+        m = getattr(crs, name, None)
+        setattr(pin, name, m._h if m is not None else None)
+    pin.a_off = pin.b_off = pin.c_off = pin.d_off = 0
+    return pin
+
+
+def _prove_io(ctx, k, witness, st, crs, tape, device_outputs, out_views=None, template=None):
     """ctypes input/output structs for one proof; returns (lab_prove_input, lab_transcript, Transcript, keep-alive list).
     out_views: preallocated device tensors for the nine outputs (prove_core_batch slices them out of one allocation
-    per field instead of nine allocations per proof)."""
+    per field instead of nine allocations per proof); template: _io_template(k, crs), copied instead of refilled."""
     n, r = k.N, k.R
-    pin = _lib.lab_prove_input()
-    pin.n, pin.r, pin.kappa, pin.kappa1, pin.kappa2 = n, r, k.KAPPA, k.KAPPA_1, k.KAPPA_2
-    pin.b1, pin.b2, pin.t1, pin.t2, pin.beta_bound = k.B_1, k.B_2, k.T_1, k.T_2, k.BETA_BOUND
+    pin = _lib.lab_prove_input.from_buffer_copy(template) if template is not None else _io_template(k, crs)
     keep = []
 
     def p64(a):
+        if hasattr(a, "data_ptr") and a.is_contiguous() and a.element_size() == 8:   # device/host tensor: no conversion
+            keep.append(a)
+            return a.data_ptr()
         a = _as_u64(a)
         keep.append(a)
         return _ptr(a)
 
     pin.S, pin.phi, pin.a = p64(witness), p64(st.phi), p64(st.a)
     pin.b_prime = st.b_prime
-    pin.A, pin.B, pin.C, pin.Dm = crs.A._h, (crs.B._h if crs.B is not None else None), crs.C._h, crs.Dm._h
-    pin.B8 = crs.B8._h if getattr(crs, "B8", None) is not None else None
-    pin.A8 = crs.A8._h if getattr(crs, "A8", None) is not None else None
-    pin.C8 = crs.C8._h if getattr(crs, "C8", None) is not None else None
-    pin.D8 = crs.D8._h if getattr(crs, "D8", None) is not None else None
-    pin.a_off = pin.b_off = pin.c_off = pin.d_off = 0
     Pi = tape["Pi"]
     if isinstance(Pi, np.ndarray):
         Pi = np.ascontiguousarray(Pi, dtype=np.int8)
@@ -261,14 +286,16 @@ def _prove_io(ctx, k, witness, st, crs, tape, device_outputs, out_views=None):
     else:
         def mk(shape, dt=None):
             return np.empty(shape, dtype=np.int64 if dt == "i64" else np.uint64)
+    if out_views is not None:      # (big tensors, proof index, byte addresses of this proof's slices)
+        big, j, addrs = out_views
+        tr = _lib.lab_transcript()
+        for name, addr in zip(_OUT_FIELDS, addrs):
+            setattr(tr, name, addr)
+        return pin, tr, BatchTranscript(big, j, tape), keep
     T = Transcript()
-    if out_views is not None:
-        for name in _OUT_FIELDS:
-            setattr(T, name, out_views[name])
-    else:
-        T.u_1 = mk((k.KAPPA_1, D)); T.projection_int = mk((256,), None if device_outputs else "i64")
-        T.projection = mk((256,)); T.b_prime_prime = mk((D,)); T.u_2 = mk((k.KAPPA_2, D)); T.z = mk((n, D))
-        T.t_i_all = mk((r, k.KAPPA, D)); T.g_mat = mk((r, r, D)); T.h_mat = mk((r, r, D))
+    T.u_1 = mk((k.KAPPA_1, D)); T.projection_int = mk((256,), None if device_outputs else "i64")
+    T.projection = mk((256,)); T.b_prime_prime = mk((D,)); T.u_2 = mk((k.KAPPA_2, D)); T.z = mk((n, D))
+    T.t_i_all = mk((r, k.KAPPA, D)); T.g_mat = mk((r, r, D)); T.h_mat = mk((r, r, D))
     tr = _lib.lab_transcript()
     for name in _OUT_FIELDS:
         setattr(tr, name, _ptr(getattr(T, name)))
@@ -292,8 +319,10 @@ def prove_core_batch(ctx, k, witnesses, states, crs, tapes, device_outputs=False
     if device_outputs:      # one device allocation per output field for the whole batch
         import torch
         big = {name: torch.empty((nb,) + shape, dtype=torch.int64, device="cuda") for name, shape in _out_shapes(k).items()}
-        views = [{name: big[name][j] for name in _OUT_FIELDS} for j in range(nb)]
-    ios = [_prove_io(ctx, k, witnesses[j], states[j], crs, tapes[j], device_outputs, views[j]) for j in range(nb)]
+        base = [(big[name].data_ptr(), big[name][0].numel() * 8) for name in _OUT_FIELDS]
+        views = [(big, j, [p + j * step for p, step in base]) for j in range(nb)]
+    template = _io_template(k, crs)
+    ios = [_prove_io(ctx, k, witnesses[j], states[j], crs, tapes[j], device_outputs, views[j], template) for j in range(nb)]
     pins = (C.POINTER(_lib.lab_prove_input) * nb)(*[C.pointer(io[0]) for io in ios])
     trs = (C.POINTER(_lib.lab_transcript) * nb)(*[C.pointer(io[1]) for io in ios])
     status = (C.c_int * nb)()
