@@ -134,9 +134,6 @@ hipError_t launch_slot_transpose(uint32_t* out_plane, size_t out_set_stride, siz
                                  size_t rows, size_t rows_pad, size_t ns, size_t ns_valid, size_t njobs, hipStream_t s);
 int gemm_i8_waves(int planes, size_t rt_count, size_t nt);   // waves per block (4 or 8) the launcher will use
 hipError_t launch_gemm_i8(const Gemm8Args& a, size_t nt, int waves, hipStream_t s);
-// out[i*r + k] = sum_x P[x*r+i] * S[x*r+k]
-hipError_t launch_gram(HatView out, ConstHatView P, ConstHatView S, size_t n, size_t r, int nlimbs,
-                       const LimbTable* tabs, hipStream_t s);
 // tiled Gram: partial[chunk][i][k], gram_num_chunks(n) chunks, to be summed with launch_sum_terms(rows = r*r)
 size_t gram_num_chunks(size_t n);
 hipError_t launch_gram_tiled(HatView partial, ConstHatView P, ConstHatView S, size_t n, size_t r, int nlimbs,

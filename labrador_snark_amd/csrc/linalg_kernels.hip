@@ -255,112 +255,6 @@ k_matvec_partial(uint32_t* __restrict__ partial, size_t partial_ps, size_t parti
   }
 }
 
-// Row-split variant for tall matrices and several vector sets: wave w of the block owns rows row0+2w, row0+2w+1
-// and walks ALL chunks of them, so the 8 waves of a block read the same vector chunks (served by L1 after the
-// first wave) and a vector byte fetched from L2 feeds 16 rows x NB sets.  No cross-wave reduction is needed.
-constexpr int RS_ROWS_W = 2;  // rows per wave
-
-template <typename MT, int NB>
-__global__ void __launch_bounds__(64 * MV_WAVES)
-k_matvec_rowsplit(uint32_t* __restrict__ partial, size_t partial_ps, size_t partial_bs, const MT* __restrict__ M, size_t m_ps,
-                  const uint32_t* __restrict__ V, size_t v_ps, size_t v_bs, unsigned rows, unsigned cols,
-                  const LimbTable* __restrict__ tabs) {
-  typedef typename Quad<MT>::raw mraw;
-  constexpr int GROUP = NB >= 4 ? 2 : 4;
-  const int limb = blockIdx.z;
-  const unsigned mat = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned row0 = (blockIdx.x * MV_WAVES + wave) * RS_ROWS_W;
-  if (row0 >= rows) return;  // whole wave idle (no barriers in this kernel)
-  const uint32_t p = tabs[limb].p, p2 = tabs[limb].p2, pinv = tabs[limb].pinv, r2 = tabs[limb].r2;
-  const int sub = lane >> 4, jq = lane & 15;
-  const uint4* Vp = reinterpret_cast<const uint4*>(V + (size_t)limb * v_ps + (size_t)mat * cols * D);
-  const size_t vb4 = v_bs / 4;
-  const mraw* Mp[RS_ROWS_W];
-#pragma unroll
-  for (int r = 0; r < RS_ROWS_W; r++) {
-    unsigned row = min(row0 + r, rows - 1);
-    Mp[r] = reinterpret_cast<const mraw*>(M + (size_t)limb * m_ps + ((size_t)mat * rows + row) * cols * D);
-  }
-  uint64_t acc[RS_ROWS_W][NB][4];
-#pragma unroll
-  for (int r = 0; r < RS_ROWS_W; r++)
-#pragma unroll
-    for (int b = 0; b < NB; b++)
-#pragma unroll
-      for (int k = 0; k < 4; k++) acc[r][b][k] = 0;
-  const unsigned full_chunks = cols / 4, nchunks = (cols + 3) / 4;
-  unsigned ch = 0;
-  while (ch + 8 <= full_chunks) {
-#pragma unroll
-    for (int part = 0; part < 8 / GROUP; part++) {
-      uint4 v[GROUP][NB], m[GROUP][RS_ROWS_W];
-#pragma unroll
-      for (int u = 0; u < GROUP; u++) {
-        const size_t off = (size_t)((ch + u) * 4 + sub) * 16 + jq;
-#pragma unroll
-        for (int b = 0; b < NB; b++) v[u][b] = Vp[off + b * vb4];
-#pragma unroll
-        for (int r = 0; r < RS_ROWS_W; r++) m[u][r] = Quad<MT>::load(Mp[r] + off);
-      }
-#pragma unroll
-      for (int u = 0; u < GROUP; u++)
-#pragma unroll
-        for (int r = 0; r < RS_ROWS_W; r++)
-#pragma unroll
-          for (int b = 0; b < NB; b++) {
-            acc[r][b][0] += (uint64_t)m[u][r].x * v[u][b].x;
-            acc[r][b][1] += (uint64_t)m[u][r].y * v[u][b].y;
-            acc[r][b][2] += (uint64_t)m[u][r].z * v[u][b].z;
-            acc[r][b][3] += (uint64_t)m[u][r].w * v[u][b].w;
-          }
-      ch += GROUP;
-    }
-#pragma unroll
-    for (int r = 0; r < RS_ROWS_W; r++)
-#pragma unroll
-      for (int b = 0; b < NB; b++)
-#pragma unroll
-        for (int k = 0; k < 4; k++) acc[r][b][k] = acc_fold(acc[r][b][k], p, p2);
-  }
-  for (; ch < nchunks; ch++) {  // fewer than 8 chunks left
-    const unsigned c = ch * 4 + sub;
-    if (c < cols) {
-      const size_t off = (size_t)c * 16 + jq;
-      uint4 v[NB];
-#pragma unroll
-      for (int b = 0; b < NB; b++) v[b] = Vp[off + b * vb4];
-#pragma unroll
-      for (int r = 0; r < RS_ROWS_W; r++) {
-        const uint4 m = Quad<MT>::load(Mp[r] + off);
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-          acc[r][b][0] += (uint64_t)m.x * v[b].x;
-          acc[r][b][1] += (uint64_t)m.y * v[b].y;
-          acc[r][b][2] += (uint64_t)m.z * v[b].z;
-          acc[r][b][3] += (uint64_t)m.w * v[b].w;
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < RS_ROWS_W; r++)
-#pragma unroll
-    for (int b = 0; b < NB; b++) {
-      uint32_t o[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        uint32_t x = redc64(acc_fold(acc[r][b][k], p, p2), p, pinv);
-        x += __shfl_xor(x, 16);
-        x += __shfl_xor(x, 32);             // < 4p < 2^32
-        o[k] = mont_mul(csub(csub(x, p2), p), r2, p, pinv);
-      }
-      if (sub == 0 && row0 + r < rows)
-        *reinterpret_cast<uint4*>(partial + (size_t)limb * partial_ps + (size_t)b * partial_bs +
-                                  ((size_t)mat * rows + row0 + r) * D + jq * 4) = make_uint4(o[0], o[1], o[2], o[3]);
-    }
-}
-
 // ---- batched mat-vec with the matrix tile staged through LDS ("sets" kernel)
 // For NB >= 2 vector sets the register file cannot hold NB x rows accumulators AND enough matrix loads in flight to
 // cover HBM latency.  Here a 512-thread block owns ST_ROWS = 16 matrix rows and walks the columns in tiles of
@@ -1195,47 +1089,6 @@ hipError_t launch_matmul_t(HatView out, ConstHatView A, ConstHatView S, size_t r
   return hipGetLastError();
 }
 
-// ------------------------------------------------ Gram-type products
-// out[i][k][j] = sum_x P[x][i][j] * S[x][k][j]   for i,k < r   (P, S: [n][r][64])
-// G = S^T S (src/proofgen.rs:59-70) and the two inner products of every h_ij
-// (src/proofgen.rs:334-335).  One block per (i,k); 4 waves split x; lanes are slots.
-__global__ void __launch_bounds__(256)
-k_gram(uint32_t* __restrict__ out, size_t out_ps, const uint32_t* __restrict__ P, size_t p_ps,
-       const uint32_t* __restrict__ S, size_t s_ps, unsigned n, unsigned r, const LimbTable* __restrict__ tabs) {
-  __shared__ uint32_t red[4][D];
-  const int limb = blockIdx.z;
-  const uint32_t p = tabs[limb].p, p2 = tabs[limb].p2, pinv = tabs[limb].pinv, r2 = tabs[limb].r2;
-  const unsigned i = blockIdx.y, k = blockIdx.x;
-  const int j = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t* Pp = P + (size_t)limb * p_ps + (size_t)i * D + j;
-  const uint32_t* Sp = S + (size_t)limb * s_ps + (size_t)k * D + j;
-  const size_t xstride = (size_t)r * D;
-  uint64_t acc = 0;
-  unsigned x = wave;
-  while (x < n) {
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      if (x < n) acc += (uint64_t)Pp[x * xstride] * Sp[x * xstride];
-      x += 4;
-    }
-    acc = acc_fold(acc, p, p2);
-  }
-  red[wave][j] = redc64(acc, p, pinv);
-  __syncthreads();
-  if (wave == 0) {
-    uint32_t v = red[0][j] + red[1][j] + red[2][j] + red[3][j];
-    v = csub(csub(v, p2), p);
-    out[(size_t)limb * out_ps + ((size_t)i * r + k) * D + j] = mont_mul(v, r2, p, pinv);
-  }
-}
-
-hipError_t launch_gram(HatView out, ConstHatView P, ConstHatView S, size_t n, size_t r, int nlimbs,
-                       const LimbTable* tabs, hipStream_t s) {
-  if (r == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_gram, dim3((unsigned)r, (unsigned)r, (unsigned)nlimbs), dim3(256), 0, s, out.base,
-                     out.plane_stride, P.base, P.plane_stride, S.base, S.plane_stride, (unsigned)n, (unsigned)r, tabs);
-  return hipGetLastError();
-}
 
 // ------------------------------------------------ sum of polynomial-times-vector terms
 // partial[chunk][rho][j] = sum_{m in chunk} G[m][j] * C[m][rho][j]
