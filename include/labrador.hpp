@@ -186,11 +186,42 @@ struct ChallengeTape {
   std::vector<Rq> c;  // [r]
 };
 
+// matrices re-stored for the matrix cores (lab_mat8_pack): signed base-256 digit planes in MFMA operand-tile order
+class PackedMatrix {
+ public:
+  PackedMatrix() = default;
+  PackedMatrix(const Context& c, const HatVec& M, size_t nmat, size_t rows, size_t cols) {
+    c.check(lab_mat8_pack(c.handle(), M.handle(), 0, nmat, rows, cols, &m_));
+  }
+  PackedMatrix(PackedMatrix&& o) noexcept : m_(o.m_) { o.m_ = nullptr; }
+  PackedMatrix& operator=(PackedMatrix&& o) noexcept {
+    if (this != &o) { reset(); m_ = o.m_; o.m_ = nullptr; }
+    return *this;
+  }
+  PackedMatrix(const PackedMatrix&) = delete;
+  PackedMatrix& operator=(const PackedMatrix&) = delete;
+  ~PackedMatrix() { reset(); }
+  const lab_mat8* handle() const { return m_; }
+  size_t bytes() const { return lab_mat8_bytes(m_); }
+
+ private:
+  void reset() { if (m_) lab_mat8_destroy(m_); m_ = nullptr; }
+  lab_mat8* m_ = nullptr;
+};
+
 struct ResidentCRS {  // A, B_ik, C_ijk, D_ijk in the transform domain (stand-in for CRS::fetch_*, src/structs.rs:55-144)
   HatVec A, B, C, Dm;
+  PackedMatrix A8, B8, C8, D8;   // optional (pack_mfma): the CRS-streaming steps of a batch then run on the matrix cores
   ResidentCRS(const Context& c, const RuntimeConstants& k)
       : A(c, k.KAPPA * k.N), B(c, k.R * (size_t)k.T_1 * k.KAPPA_1 * k.KAPPA), C(c, k.R * (k.R + 1) / 2 * (size_t)k.T_2 * k.KAPPA_2),
         Dm(c, k.R * (k.R + 1) / 2 * (size_t)k.T_1 * k.KAPPA_2) {}
+  void pack_mfma(const Context& c, const RuntimeConstants& k) {
+    const size_t pairs = k.R * (k.R + 1) / 2;
+    B8 = PackedMatrix(c, B, k.R * (size_t)k.T_1, k.KAPPA_1, k.KAPPA);
+    A8 = PackedMatrix(c, A, 1, k.KAPPA, k.N);
+    C8 = PackedMatrix(c, C, pairs * (size_t)k.T_2, k.KAPPA_2, 1);   // element (rho, m) = C[m][rho]
+    D8 = PackedMatrix(c, Dm, pairs * (size_t)k.T_1, k.KAPPA_2, 1);
+  }
 };
 
 struct State {  // the parts of src/structs.rs:269-286 the prover reads
@@ -206,21 +237,35 @@ class Prover {  // src/proofgen.rs:14-28
 
   // One attempt with a given tape.  Throws Error(LAB_ERR_JL_REJECTED) / Error(LAB_ERR_BPP_CHECK) like lab_prove_core.
   Transcript prove_with_tape(const State& st, const ResidentCRS& crs, const ChallengeTape& tape) const {
-    lab_prove_input in{};
-    in.n = k_.N; in.r = k_.R; in.kappa = k_.KAPPA; in.kappa1 = k_.KAPPA_1; in.kappa2 = k_.KAPPA_2;
-    in.b1 = k_.B_1; in.b2 = k_.B_2; in.t1 = (int)k_.T_1; in.t2 = (int)k_.T_2; in.beta_bound = k_.BETA_BOUND;
-    in.S = witness_[0].data(); in.phi = st.phi[0].data(); in.a = st.a[0].data(); in.b_prime = st.b_prime;
-    in.A = crs.A.handle(); in.B = crs.B.handle(); in.C = crs.C.handle(); in.Dm = crs.Dm.handle();
-    in.Pi = tape.Pi.data(); in.psi = tape.psi; in.omega = tape.omega.data();
-    in.alpha = tape.alpha.data(); in.beta = tape.beta.data(); in.c = tape.c[0].data();
+    lab_prove_input in = input(k_, witness_, st, crs, tape);
     Transcript T;
-    T.u_1.resize(k_.KAPPA_1); T.u_2.resize(k_.KAPPA_2); T.z.resize(k_.N); T.t_i_all.resize(k_.R * k_.KAPPA);
-    T.g_mat.resize(k_.R * k_.R); T.h_mat.resize(k_.R * k_.R); T.projection_int.resize(256); T.projection.resize(256);
-    lab_transcript out{};
-    out.u_1 = T.u_1[0].data(); out.projection_int = T.projection_int.data(); out.projection = T.projection.data();
-    out.b_prime_prime = T.b_prime_prime.data(); out.u_2 = T.u_2[0].data(); out.z = T.z[0].data();
-    out.t_i_all = T.t_i_all[0].data(); out.g_mat = T.g_mat[0].data(); out.h_mat = T.h_mat[0].data();
+    lab_transcript out = output(k_, T);
     c_.check(lab_prove_core(c_.handle(), &in, &out));
+    return T;
+  }
+
+  // Many independent proofs (own witness, state, tape) under ONE common reference string: lab_prove_core_batch.  The
+  // CRS-streaming steps run once per group of proofs (up to 64 per pass over B after crs.pack_mfma()).  status[j] is
+  // LAB_OK / LAB_ERR_JL_REJECTED / LAB_ERR_BPP_CHECK for proof j; transcripts are bit-identical to prove_with_tape.
+  static std::vector<Transcript> prove_batch(const Context& c, const RuntimeConstants& k,
+                                             const std::vector<const std::vector<Rq>*>& witnesses,
+                                             const std::vector<const State*>& states, const ResidentCRS& crs,
+                                             const std::vector<const ChallengeTape*>& tapes, std::vector<int>& status) {
+    const size_t np = witnesses.size();
+    if (states.size() != np || tapes.size() != np) throw LengthMismatch(LAB_ERR_LEN_MISMATCH, "prove_batch: one witness, state and tape per proof");
+    std::vector<lab_prove_input> ins(np);
+    std::vector<lab_transcript> outs(np);
+    std::vector<Transcript> T(np);
+    std::vector<const lab_prove_input*> pin(np);
+    std::vector<lab_transcript*> pout(np);
+    for (size_t j = 0; j < np; j++) {
+      ins[j] = input(k, *witnesses[j], *states[j], crs, *tapes[j]);
+      outs[j] = output(k, T[j]);
+      pin[j] = &ins[j];
+      pout[j] = &outs[j];
+    }
+    status.assign(np, LAB_OK);
+    c.check(lab_prove_core_batch(c.handle(), np, pin.data(), pout.data(), status.data()));
     return T;
   }
 
@@ -239,6 +284,27 @@ class Prover {  // src/proofgen.rs:14-28
   }
 
  private:
+  static lab_prove_input input(const RuntimeConstants& k, const std::vector<Rq>& witness, const State& st, const ResidentCRS& crs,
+                               const ChallengeTape& tape) {
+    lab_prove_input in{};
+    in.n = k.N; in.r = k.R; in.kappa = k.KAPPA; in.kappa1 = k.KAPPA_1; in.kappa2 = k.KAPPA_2;
+    in.b1 = k.B_1; in.b2 = k.B_2; in.t1 = (int)k.T_1; in.t2 = (int)k.T_2; in.beta_bound = k.BETA_BOUND;
+    in.S = witness[0].data(); in.phi = st.phi[0].data(); in.a = st.a[0].data(); in.b_prime = st.b_prime;
+    in.A = crs.A.handle(); in.B = crs.B.handle(); in.C = crs.C.handle(); in.Dm = crs.Dm.handle();
+    in.A8 = crs.A8.handle(); in.B8 = crs.B8.handle(); in.C8 = crs.C8.handle(); in.D8 = crs.D8.handle();
+    in.Pi = tape.Pi.data(); in.psi = tape.psi; in.omega = tape.omega.data();
+    in.alpha = tape.alpha.data(); in.beta = tape.beta.data(); in.c = tape.c[0].data();
+    return in;
+  }
+  static lab_transcript output(const RuntimeConstants& k, Transcript& T) {
+    T.u_1.resize(k.KAPPA_1); T.u_2.resize(k.KAPPA_2); T.z.resize(k.N); T.t_i_all.resize(k.R * k.KAPPA);
+    T.g_mat.resize(k.R * k.R); T.h_mat.resize(k.R * k.R); T.projection_int.resize(256); T.projection.resize(256);
+    lab_transcript out{};
+    out.u_1 = T.u_1[0].data(); out.projection_int = T.projection_int.data(); out.projection = T.projection.data();
+    out.b_prime_prime = T.b_prime_prime.data(); out.u_2 = T.u_2[0].data(); out.z = T.z[0].data();
+    out.t_i_all = T.t_i_all[0].data(); out.g_mat = T.g_mat[0].data(); out.h_mat = T.h_mat[0].data();
+    return out;
+  }
   const std::vector<Rq>& witness_;
   const RuntimeConstants& k_;
   const Context& c_;

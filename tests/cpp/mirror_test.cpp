@@ -159,6 +159,31 @@ static void prover_test(uint64_t q) {
   CHECK(memcmp(T.z[0].data(), oz.data(), oz.size() * 8) == 0);
   CHECK(memcmp(T.b_prime_prime.data(), obpp.data(), D * 8) == 0);
   CHECK(memcmp(T.projection_int.data(), oproj_int.data(), 256 * 8) == 0);
+  // the batched call, first on the multiply-add kernels, then with the CRS packed for the matrix cores: the same
+  // three proofs (one of them with a wrong b') give the same transcripts and per-proof status codes
+  {
+    State wrong = st;
+    wrong.b_prime = (st.b_prime + 1) % q;
+    std::vector<const std::vector<Rq>*> ws = {&S, &S, &S};
+    std::vector<const State*> sts = {&st, &wrong, &st};
+    std::vector<const ChallengeTape*> tps = {&tape, &tape, &tape};
+    for (int pass = 0; pass < 2; pass++) {
+      if (pass == 1) {
+        crs.pack_mfma(ctx, k);
+        CHECK(crs.B8.bytes() > 0 && crs.A8.bytes() > 0);
+      }
+      std::vector<int> status;
+      std::vector<Transcript> Tb = Prover::prove_batch(ctx, k, ws, sts, crs, tps, status);
+      CHECK(status.size() == 3 && status[0] == LAB_OK && status[1] == LAB_ERR_BPP_CHECK && status[2] == LAB_OK);
+      for (int j : {0, 2}) {
+        CHECK(memcmp(Tb[j].u_1[0].data(), ou1.data(), ou1.size() * 8) == 0);
+        CHECK(memcmp(Tb[j].u_2[0].data(), ou2.data(), ou2.size() * 8) == 0);
+        CHECK(memcmp(Tb[j].t_i_all[0].data(), ot.data(), ot.size() * 8) == 0);
+        CHECK(memcmp(Tb[j].z[0].data(), oz.data(), oz.size() * 8) == 0);
+        CHECK(memcmp(Tb[j].h_mat[0].data(), oH.data(), oH.size() * 8) == 0);
+      }
+    }
+  }
   // a wrong b' trips verify_b_prime_prime (src/verification.rs:550)
   State bad = st;
   bad.b_prime = (st.b_prime + 1) % q;
