@@ -377,3 +377,22 @@ def test_matvec_sum_mfma_main_basis_full_residues(contexts, q):
     for b in range(ns):
         assert np.array_equal(got[b], lab.matvec_sum(ctx, hM, hV, nmat, rows, cols, v_off=b * nmat * cols).store())
     M8.close()
+
+
+def test_mat8_misuse_is_refused(contexts):
+    # exactness bound of the int8 formulation (int32 accumulators: fewer than 2^17 - 1 products per sum), set counts
+    # the GEMM is instantiated for, basis mismatches
+    import labrador_snark_amd as lab
+    ctx = contexts(Q_REF33)
+    big = ctx.vec(131072)
+    with pytest.raises(lab.LabradorError):
+        lab.Mat8(ctx, big, 1, 1, 131072)
+    M = ctx.vec(2 * 3 * 5).fill_synthetic(1)
+    M8 = lab.Mat8(ctx, M, 2, 3, 5)
+    V = ctx.vec(16 * 2 * 5).fill_synthetic(2)
+    with pytest.raises(lab.LabradorError):
+        lab.matvec_sum_mfma(ctx, M8, V, 12)
+    with pytest.raises(lab.LabradorError):
+        lab.matvec_sum_mfma(ctx, M8, ctx.vec(8), 8)          # V too short for 8 sets
+    M8.close()
+    big.close()

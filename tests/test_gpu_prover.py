@@ -238,3 +238,23 @@ def test_prove_core_batch_on_matrix_cores(nb, kappa1, compact):
     assert np.array_equal(got[0].u_1, want0["u1"]) and np.array_equal(got[0].u_2, want0["u2"])
     crs.close()
     ctx.close()
+
+
+def test_verifier_needs_the_unpacked_B():
+    # a prover-only process may drop B after packing it for the matrix cores; lab_verify_core then refuses cleanly
+    import labrador_snark_amd as lab
+    q, n, r, kappa, kappa1 = Q_REF33, 4, 8, 64, 20
+    ctx = lab.Context(q, 0)
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
+    crs = lab.ResidentCRS(ctx, k, compact=True).fill_synthetic(1000)
+    case, (S, phi, a, tape) = cases.oracle_case(p, seed=7)
+    st = lab.State(phi, a, case.b_prime)
+    crs.pack_mfma(drop_B=True)
+    T = lab.prove_core(ctx, k, S, st, crs, tape)                     # single proof on the matrix-core path
+    want = case.prove()
+    assert np.array_equal(T.u_1, want["u1"]) and np.array_equal(T.u_2, want["u2"])
+    with pytest.raises(lab.LabradorError):
+        lab.verify_core(ctx, k, st, case.b_poly, crs, T)
+    crs.close()
+    ctx.close()
