@@ -117,6 +117,11 @@ extern "C" int lab_mat8_pack(lab_ctx* c, const lab_vec* M, size_t m_off, size_t 
   m->kt_count = ((nmat * cols + 31) / 32 + 11) / 12 * 12;   // the GEMM walks K in stages of 4 k-tiles, 3 stages per loop trip
   const uint32_t* primes = M->basis ? c->dg_primes : c->primes;
   const int nfull = M->planes32();
+  for (int l = 0; l < m->nlimbs; l++)   // the 32-bit recombination adds 2p to an int32 sum of K byte products: K * 2^14 < 2p
+    if (primes[l] > (1u << 29) && (uint64_t)nmat * cols * 16384 >= 2ull * primes[l]) {
+      delete m;
+      return fail(c, LAB_ERR_RANGE, "lab_mat8_pack: %zu products per sum are too many for limb prime %u", nmat * cols, primes[l]);
+    }
   for (int l = 0; l < m->nlimbs; l++) {
     m->planes[l] = mfma_planes(primes[l]);
     const size_t bytes = (size_t)D * m->planes[l] * m->rt_count * m->kt_count * 1024;
