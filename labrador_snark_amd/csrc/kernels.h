@@ -116,7 +116,7 @@ hipError_t launch_pack_matrix_i8(int8_t* dst, const void* src, bool src_u16, siz
                                  size_t rt_count, size_t kt_count, int planes, hipStream_t s);
 hipError_t launch_pack_vectors_i8(int ns, int ns_valid, int8_t* dst, const uint32_t* src, size_t set_stride, size_t k_stride,
                                   size_t ktotal, size_t kt_count, size_t nt_count, int planes, size_t njobs, size_t src_job_stride,
-                                  size_t dst_job_stride, hipStream_t s);
+                                  size_t dst_job_stride, size_t nsub, size_t src_sub_stride, hipStream_t s);
 struct Gemm8Args {
   uint32_t* out;             // this limb's plane: out + job*out_job_stride + s*out_set_stride + row*64 + j
   size_t out_set_stride, out_job_stride;
@@ -124,6 +124,7 @@ struct Gemm8Args {
   const int8_t* V8;          // + job*v8_job_stride (bytes)
   size_t v8_job_stride;
   unsigned planes, rt_count, kt_count, rgroups /* row groups per slot */, njobs, rows, ns, ns_valid;
+  unsigned nsub;            // sets per source job (= ns unless several source jobs are multiplied as one job); ns_valid counts within it
   unsigned tile_r, tile_j;   // block-order super-tile (set by launch_gemm_i8)
   uint32_t p;
   const LimbTable* tab;     // this limb's table (device): Montgomery constants for the recombination
@@ -131,7 +132,7 @@ struct Gemm8Args {
   uint32_t* stage;          // non-null: results go to stage[job][slot][row][set] (full-line stores), see k_slot_transpose
 };
 hipError_t launch_slot_transpose(uint32_t* out_plane, size_t out_set_stride, size_t out_job_stride, const uint32_t* stage,
-                                 size_t rows, size_t rows_pad, size_t ns, size_t ns_valid, size_t njobs, hipStream_t s);
+                                 size_t rows, size_t rows_pad, size_t ns, size_t ns_valid, size_t njobs, size_t nsub, hipStream_t s);
 int gemm_i8_waves(int planes, size_t rt_count, size_t nt);   // waves per block (4 or 8) the launcher will use
 hipError_t launch_gemm_i8(const Gemm8Args& a, size_t nt, int waves, hipStream_t s);
 // tiled Gram: partial[chunk][i][k], gram_num_chunks(n) chunks, to be summed with launch_sum_terms(rows = r*r)

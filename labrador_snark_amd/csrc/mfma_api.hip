@@ -1,6 +1,7 @@
 // mfma_api.hip — host side of the int8-MFMA outer commitment (mfma_kernels.hip): the packed-matrix handle
 // (lab_mat8), the stand-alone batched op lab_matvec_sum_mfma and the helper prove.hip calls.
 #include <cstdio>
+#include <cstdlib>
 
 #include "context.h"
 
@@ -55,21 +56,36 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
                      bool timed) {
   const uint32_t* primes = m->basis ? c->dg_primes : c->primes;
   const size_t ktotal = m->nmat * m->cols;
+  // Many 32-set jobs sharing the matrix (the Ajtai product of a batch): two source jobs are multiplied as ONE 64-set job,
+  // so every matrix tile fetched from L2 feeds 8 column tiles instead of 4 (the launch is bound by that operand traffic).
+  const size_t nsub = ns;                                    // sets per source job
+  size_t sub_stride_v = 0;
+  static const bool no_pair = getenv("LAB_GEMM_NO_PAIR") != nullptr;
+  bool paired = false;
+  if (!no_pair && njobs >= 2 && njobs % 2 == 0 && ns == 32) {
+    bool all4 = true;
+    for (int l = 0; l < m->nlimbs; l++) all4 = all4 && m->planes[l] == 4;
+    if (all4) {
+      paired = true;
+      sub_stride_v = v_job_stride;
+      njobs /= 2; ns = 64; v_job_stride *= 2;
+    }
+  }
   int8_t* v8 = static_cast<int8_t*>(scratch);
   const size_t v8_stride = v8_job_bytes(m, ns);
-  uint32_t* stage = njobs > 1 ? reinterpret_cast<uint32_t*>(v8 + v8_stride * njobs) : nullptr;
+  uint32_t* stage = (njobs > 1 || paired) ? reinterpret_cast<uint32_t*>(v8 + v8_stride * njobs) : nullptr;
   for (int l = 0; l < m->nlimbs; l++) {
     const int pl = m->planes[l];
     const size_t nt = nt_for(ns, pl);
     LAB_HIP(c, launch_pack_vectors_i8(ns, ns_valid, v8, V.base + (size_t)l * V.plane_stride, v_set_stride, v_k_stride, ktotal,
-                                      m->kt_count, nt, pl, njobs, v_job_stride, v8_stride, c->stream));
+                                      m->kt_count, nt, pl, njobs, v_job_stride, v8_stride, nsub, sub_stride_v, c->stream));
     Gemm8Args g;
     g.out = out.base + (size_t)l * out.plane_stride; g.out_set_stride = out_set_stride; g.out_job_stride = out_job_stride;
     g.M8 = m->d[l]; g.V8 = v8; g.v8_job_stride = v8_stride;
     g.planes = (unsigned)pl; g.rt_count = (unsigned)m->rt_count; g.kt_count = (unsigned)m->kt_count;
     const int waves = gemm_i8_waves(pl, m->rt_count, nt);
     g.rgroups = (unsigned)((m->rt_count + waves / pl - 1) / (waves / pl)); g.njobs = (unsigned)njobs; g.rows = (unsigned)m->rows;
-    g.ns = (unsigned)ns; g.ns_valid = (unsigned)ns_valid; g.p = primes[l];
+    g.ns = (unsigned)ns; g.ns_valid = (unsigned)ns_valid; g.nsub = (unsigned)nsub; g.p = primes[l];
     g.tab = (m->basis ? c->dg_tabs : c->d_tabs) + l;
     g.pw[0] = 1 % primes[l];
     for (int e = 1; e < 7; e++) g.pw[e] = (uint32_t)(((uint64_t)g.pw[e - 1] * 256) % primes[l]);
@@ -94,7 +110,7 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
     }
     if (stage)
       LAB_HIP(c, launch_slot_transpose(g.out, out_set_stride, out_job_stride, stage, m->rows, m->rt_count * 32, ns, ns_valid, njobs,
-                                       c->stream));
+                                       nsub, c->stream));
   }
   return LAB_OK;
 }

@@ -92,7 +92,7 @@ constexpr int PV_PITCH = 16 * D + 4;     // words per set in LDS (16-byte aligne
 __global__ void __launch_bounds__(256)
 k_pack_vectors_i8(int8_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t set_stride, size_t k_stride, unsigned ktotal,
                   unsigned kt_count, unsigned nt_count, int planes, unsigned ns, unsigned ns_valid, size_t src_job_stride,
-                  size_t dst_job_stride) {
+                  size_t dst_job_stride, unsigned nsub, size_t src_sub_stride) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[PV_SETS * PV_PITCH];
   const unsigned groups = ns / PV_SETS, job = blockIdx.z / groups;
   const unsigned kt = blockIdx.x, h = blockIdx.y, s0 = (blockIdx.z % groups) * PV_SETS;
@@ -102,8 +102,12 @@ k_pack_vectors_i8(int8_t* __restrict__ dst, const uint32_t* __restrict__ src, si
   for (unsigned e = threadIdx.x; e < PV_SETS * 16 * D / 4; e += 256) {       // quads
     const unsigned sset = e / (16 * D / 4), wq = e % (16 * D / 4), k = k0 + wq / (D / 4);
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (k < ktotal && s0 + sset < ns_valid)   // sets past ns_valid are padding: zero columns, never read
-      v = *reinterpret_cast<const uint4*>(src + (size_t)(s0 + sset) * set_stride + (size_t)k * k_stride + (wq % (D / 4)) * 4);
+    // a job's ns sets may come from ns / nsub source jobs of nsub sets each (two 32-column proofs as one 64-set job);
+    // sets past ns_valid (per source job) are padding: zero columns, never read
+    const unsigned sg = s0 + sset;
+    if (k < ktotal && sg % nsub < ns_valid)
+      v = *reinterpret_cast<const uint4*>(src + (size_t)(sg / nsub) * src_sub_stride + (size_t)(sg % nsub) * set_stride +
+                                          (size_t)k * k_stride + (wq % (D / 4)) * 4);
     *reinterpret_cast<uint4*>(&lds[sset * PV_PITCH + wq * 4]) = v;
   }
   __syncthreads();
@@ -129,11 +133,12 @@ k_pack_vectors_i8(int8_t* __restrict__ dst, const uint32_t* __restrict__ src, si
 // an [n][r] witness matrix
 hipError_t launch_pack_vectors_i8(int ns, int ns_valid, int8_t* dst, const uint32_t* src, size_t set_stride, size_t k_stride,
                                   size_t ktotal, size_t kt_count, size_t nt_count, int planes, size_t njobs, size_t src_job_stride,
-                                  size_t dst_job_stride, hipStream_t s) {
+                                  size_t dst_job_stride, size_t nsub, size_t src_sub_stride, hipStream_t s) {
   if (ns % PV_SETS || (set_stride % 4) || (k_stride % 4) || (src_job_stride % 4) || njobs * (ns / PV_SETS) > 65535) return hipErrorInvalidValue;
   dim3 g((unsigned)kt_count, 2, (unsigned)(njobs * (ns / PV_SETS)));
   hipLaunchKernelGGL(k_pack_vectors_i8, g, dim3(256), 0, s, dst, src, set_stride, k_stride, (unsigned)ktotal, (unsigned)kt_count,
-                     (unsigned)nt_count, planes, (unsigned)ns, (unsigned)ns_valid, src_job_stride, dst_job_stride);
+                     (unsigned)nt_count, planes, (unsigned)ns, (unsigned)ns_valid, src_job_stride, dst_job_stride, (unsigned)nsub,
+                     src_sub_stride);
   return hipGetLastError();
 }
 
@@ -305,7 +310,7 @@ k_gemm_i8(const Gemm8Args a) {
   for (unsigned o = t; o < tiles_per_pass * 32 * nsh; o += NTHR) {
     const unsigned s = half * nsh + o % nsh, row = (o / nsh) % 32, tl = o / (nsh * 32);   // tl: row tile inside this pass
     const unsigned grow = (rg * tiles_per_block + wg * tiles_per_pass + tl) * 32 + row;
-    if (s >= a.ns_valid || grow >= a.rows) continue;
+    if (s % a.nsub >= a.ns_valid || grow >= a.rows) continue;
     const unsigned g = (row & 3) | ((row >> 3) << 2), lh = ((row >> 2) & 1) * 32;
     uint32_t res;
     if (big) {
@@ -360,25 +365,27 @@ k_gemm_i8(const Gemm8Args a) {
 // stage[job][j][row][s] -> out[job*out_job_stride + s*out_set_stride + row*64 + j]; block = (row, job)
 __global__ void __launch_bounds__(256)
 k_slot_transpose(uint32_t* __restrict__ out, size_t out_set_stride, size_t out_job_stride, const uint32_t* __restrict__ stage,
-                 unsigned rows_pad, unsigned ns, unsigned ns_valid) {
-  __shared__ uint32_t tile[D][33];
+                 unsigned rows_pad, unsigned ns, unsigned ns_valid, unsigned nsub) {
+  __shared__ uint32_t tile[D][65];
   const unsigned row = blockIdx.x, job = blockIdx.y;
   for (unsigned e = threadIdx.x; e < D * ns; e += 256) {
     const unsigned j = e / ns, s = e % ns;
     tile[j][s] = stage[(((size_t)job * D + j) * rows_pad + row) * ns + s];
   }
   __syncthreads();
-  for (unsigned e = threadIdx.x; e < D * ns_valid; e += 256) {
+  const unsigned sub = ns / nsub;                 // source jobs per GEMM job: their outputs are out_job_stride apart
+  for (unsigned e = threadIdx.x; e < D * ns; e += 256) {
     const unsigned s = e / D, j = e % D;
-    out[(size_t)job * out_job_stride + (size_t)s * out_set_stride + (size_t)row * D + j] = tile[j][s];
+    if (s % nsub < ns_valid)
+      out[((size_t)job * sub + s / nsub) * out_job_stride + (size_t)(s % nsub) * out_set_stride + (size_t)row * D + j] = tile[j][s];
   }
 }
 
 hipError_t launch_slot_transpose(uint32_t* out_plane, size_t out_set_stride, size_t out_job_stride, const uint32_t* stage,
-                                 size_t rows, size_t rows_pad, size_t ns, size_t ns_valid, size_t njobs, hipStream_t s) {
-  if (rows == 0 || njobs == 0 || ns > 32) return ns > 32 ? hipErrorInvalidValue : hipSuccess;
+                                 size_t rows, size_t rows_pad, size_t ns, size_t ns_valid, size_t njobs, size_t nsub, hipStream_t s) {
+  if (rows == 0 || njobs == 0 || ns > 64) return ns > 64 ? hipErrorInvalidValue : hipSuccess;
   hipLaunchKernelGGL(k_slot_transpose, dim3((unsigned)rows, (unsigned)njobs), dim3(256), 0, s, out_plane, out_set_stride,
-                     out_job_stride, stage, (unsigned)rows_pad, (unsigned)ns, (unsigned)ns_valid);
+                     out_job_stride, stage, (unsigned)rows_pad, (unsigned)ns, (unsigned)ns_valid, (unsigned)nsub);
   return hipGetLastError();
 }
 

@@ -258,3 +258,31 @@ def test_verifier_needs_the_unpacked_B():
         lab.verify_core(ctx, k, st, case.b_poly, crs, T)
     crs.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("nb", [2, 4, 5])
+def test_prove_core_batch_matrix_cores_r32(nb):
+    # r = 32 witness columns: the Ajtai product of an even number of proofs multiplies two proofs as one 64-set job
+    # (paired jobs), an odd number keeps one 32-set job per proof; both equal the multiply-add path and the oracle
+    import labrador_snark_amd as lab
+    q, n, r, kappa, kappa1 = Q_REF33, 6, 32, 40, 36
+    ctx = lab.Context(q, 0)
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
+    crs = lab.ResidentCRS(ctx, k, compact=True).fill_synthetic(1000)
+    ws, sts, tapes = [], [], []
+    want_last = None
+    for j in range(nb):
+        case, (S, phi, a, tape) = cases.oracle_case(p, seed=500 + j)
+        ws.append(S); sts.append(lab.State(phi, a, case.b_prime)); tapes.append(tape)
+        if j == nb - 1:
+            want_last = case.prove()
+    ref = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes)
+    crs.pack_mfma()
+    got = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes)
+    for j in range(nb):
+        for f in ("t_i_all", "g_mat", "h_mat", "u_1", "u_2", "z", "b_prime_prime", "projection_int"):
+            assert np.array_equal(getattr(got[j], f), getattr(ref[j], f)), (j, f)
+    assert np.array_equal(got[-1].t_i_all, want_last["t"]) and np.array_equal(got[-1].u_1, want_last["u1"])
+    crs.close()
+    ctx.close()
