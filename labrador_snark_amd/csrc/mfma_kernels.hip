@@ -89,6 +89,11 @@ hipError_t launch_pack_matrix_i8(int8_t* dst, const void* src, bool src_u16, siz
 constexpr int PV_SETS = 8;
 constexpr int PV_PITCH = 16 * D + 4;     // words per set in LDS (16-byte aligned rows, 2-way bank conflicts at most)
 
+// all four signed digits of x at once: adding 128 at every digit position below the top one and flipping those bits
+// back gives byte i = digit i (x = y - sum 128*256^i, y = x + offs, so digit i = byte_i(y) - 128 = byte_i(y) ^ 0x80)
+__device__ __forceinline__ uint32_t signed_digit_word(uint32_t x, uint32_t offs) { return (x + offs) ^ offs; }
+__device__ __forceinline__ uint32_t digit_offsets(int planes) { return planes >= 4 ? 0x00808080u : planes == 3 ? 0x8080u : planes == 2 ? 0x80u : 0u; }
+
 __global__ void __launch_bounds__(256)
 k_pack_vectors_i8(int8_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t set_stride, size_t k_stride, unsigned ktotal,
                   unsigned kt_count, unsigned nt_count, int planes, unsigned ns, unsigned ns_valid, size_t src_job_stride,
@@ -99,32 +104,46 @@ k_pack_vectors_i8(int8_t* __restrict__ dst, const uint32_t* __restrict__ src, si
   src += (size_t)job * src_job_stride;
   dst += (size_t)job * dst_job_stride;
   const unsigned k0 = kt * 32 + 16 * h;
-  for (unsigned e = threadIdx.x; e < PV_SETS * 16 * D / 4; e += 256) {       // quads
-    const unsigned sset = e / (16 * D / 4), wq = e % (16 * D / 4), k = k0 + wq / (D / 4);
-    uint4 v = make_uint4(0, 0, 0, 0);
+  // thread t fetches quad t of every set's 16 x 64-word slab (polynomial k0 + t/16, words 4*(t%16)..): all 8 loads are
+  // issued before the first LDS write
+  const unsigned wq = threadIdx.x, k = k0 + wq / (D / 4);
+  u32x4_t v[PV_SETS];
+#pragma unroll
+  for (int sset = 0; sset < PV_SETS; sset++) {
     // a job's ns sets may come from ns / nsub source jobs of nsub sets each (two 32-column proofs as one 64-set job);
     // sets past ns_valid (per source job) are padding: zero columns, never read
-    const unsigned sg = s0 + sset;
-    if (k < ktotal && sg % nsub < ns_valid)
-      v = *reinterpret_cast<const uint4*>(src + (size_t)(sg / nsub) * src_sub_stride + (size_t)(sg % nsub) * set_stride +
-                                          (size_t)k * k_stride + (wq % (D / 4)) * 4);
-    *reinterpret_cast<uint4*>(&lds[sset * PV_PITCH + wq * 4]) = v;
+    const unsigned sg = s0 + sset, sub = sg / nsub, sl = sg - sub * nsub;
+    const u32x4_t z = {0, 0, 0, 0};
+    v[sset] = (k < ktotal && sl < ns_valid)
+                  ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(src + (size_t)sub * src_sub_stride + (size_t)sl * set_stride +
+                                                                                (size_t)k * k_stride) + (wq % (D / 4)))
+                  : z;
   }
+#pragma unroll
+  for (int sset = 0; sset < PV_SETS; sset++) *reinterpret_cast<u32x4_t*>(&lds[sset * PV_PITCH + wq * 4]) = v[sset];
   __syncthreads();
-  for (unsigned e = threadIdx.x; e < PV_SETS * D; e += 256) {
-    const unsigned sset = e % PV_SETS, j = e / PV_SETS;
-    union { int8_t b[16]; uint4 v; } outp[4];
+  const uint32_t offs = digit_offsets(planes);
 #pragma unroll
-    for (int b = 0; b < 16; b++) {
-      int8_t d[4];
-      signed_digits(lds[sset * PV_PITCH + b * D + j], planes, d);
+  for (int it = 0; it < PV_SETS * D / 256; it++) {
+    const unsigned e = threadIdx.x + 256 * it, sset = e % PV_SETS, j = e / PV_SETS;
+    uint32_t w[16];
 #pragma unroll
-      for (int i = 0; i < 4; i++) outp[i].b[b] = d[i];
-    }
-    for (int i = 0; i < planes; i++) {
+    for (int b = 0; b < 16; b++) w[b] = signed_digit_word(lds[sset * PV_PITCH + b * D + j], offs);
+    // byte i of w[4q .. 4q+3] -> dword q of plane i
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (i >= planes) break;
+      u32x4_t o;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t sel = 0x04000400u + 0x01010101u * i;   // perm selectors: bytes (i of src1, i of src0) twice
+        const uint32_t lo = __builtin_amdgcn_perm(w[4 * q + 1], w[4 * q], sel);        // [.., .., b_i(w1), b_i(w0)] in the low half
+        const uint32_t hi = __builtin_amdgcn_perm(w[4 * q + 3], w[4 * q + 2], sel);
+        o[q] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+      }
       const unsigned n = i * ns + s0 + sset, nt = n / 32, lane = (h << 5) | (n % 32);
       const size_t t = ((size_t)j * kt_count + kt) * nt_count + nt;
-      *reinterpret_cast<uint4*>(dst + t * 1024 + lane * 16) = outp[i].v;
+      *reinterpret_cast<u32x4_t*>(dst + t * 1024 + lane * 16) = o;
     }
   }
 }
