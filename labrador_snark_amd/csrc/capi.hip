@@ -420,7 +420,7 @@ extern "C" int lab_negacyclic_polymul_u64(lab_ctx* c, uint64_t* prod, const uint
   LAB_HIP(c, launch_ntt(false, va, va, batch, c->nlimbs, c->d_tabs, 1, c->stream));  // scale n^-1 * 2^32 undoes the REDC factor
   const bool out_dev = is_device_pointer(prod);
   uint64_t* dout = out_dev ? prod : so;
-  LAB_HIP(c, launch_crt_to_u64(va, dout, batch, c->d_crt, c->stream));
+  LAB_HIP(c, launch_crt_to_u64(va, dout, batch, c->d_crt, c->nlimbs, c->stream));
   if (!out_dev) {
     LAB_HIP(c, hipMemcpyAsync(prod, so, words * 8, hipMemcpyDeviceToHost, c->stream));
     LAB_HIP(c, hipStreamSynchronize(c->stream));
@@ -502,7 +502,7 @@ int lab::check_range(lab_ctx* c, const lab_vec* v, size_t off, size_t n, const c
 int lab::from_hat(lab_ctx* c, ConstHatView src, size_t count, uint32_t* tmp, uint64_t* dcoeffs, int basis) {
   HatView t{tmp, count * D};
   LAB_HIP(c, launch_ntt(false, src, t, count, basis_nlimbs(c, basis), basis_tabs(c, basis), 0, c->stream));
-  LAB_HIP(c, launch_crt_to_u64(t, dcoeffs, count, basis_crt(c, basis), c->stream));
+  LAB_HIP(c, launch_crt_to_u64(t, dcoeffs, count, basis_crt(c, basis), basis_nlimbs(c, basis), c->stream));
   return LAB_OK;
 }
 
@@ -588,7 +588,7 @@ extern "C" int lab_vec_store_u64(lab_ctx* c, const lab_vec* src, size_t src_off,
     sv = ConstHatView(unp, words);
   }
   LAB_HIP(c, launch_ntt(false, sv, t, count, (int)L, src->tabs(), 0, c->stream));
-  LAB_HIP(c, launch_crt_to_u64(t, out_dev ? coeffs : so, count, src->crt(), c->stream));
+  LAB_HIP(c, launch_crt_to_u64(t, out_dev ? coeffs : so, count, src->crt(), (int)L, c->stream));
   if (!out_dev) {
     LAB_HIP(c, hipMemcpyAsync(coeffs, so, words * 8, hipMemcpyDeviceToHost, c->stream));
     LAB_HIP(c, hipStreamSynchronize(c->stream));

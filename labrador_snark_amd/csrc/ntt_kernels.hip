@@ -55,7 +55,7 @@ __device__ __forceinline__ uint32_t reduce_u40(uint64_t v, const LimbTable& tb) 
     const uint32_t a = mul_shoup_lazy(hi, tb.q_hi_mul, tb.q_hi_mul_sh, p);   // [0, 2p)
     return csub(csub(a + b, 2 * p), p);                                      // a + b < 3p < 2^32
   }
-  return (uint32_t)mod_u64(v, p, tb.inv_p);
+  return (uint32_t)mod_u64_near(v, p, tb.inv_p);
 }
 
 __global__ void __launch_bounds__(256)
@@ -171,74 +171,103 @@ hipError_t launch_reduce_u64(const uint64_t* coeffs, HatView dst, size_t count, 
 }
 
 __device__ __forceinline__ uint64_t mulmod_q(uint32_t d, uint64_t c, uint64_t q, double inv_q) {
-  // d < 2^30, c < q < 2^40: the product fits 64 bits when q < 2^34, else c is split at bit 20
-  if (q < (1ull << 34)) return mod_u64((uint64_t)d * c, q, inv_q);
+  // d < 2^30, c < q < 2^40: the product fits 64 bits when q < 2^34, else c is split at bit 20 (quotients < 2^50)
+  if (q < (1ull << 34)) return mod_u64_near((uint64_t)d * c, q, inv_q);
   const uint64_t chi = c >> 20, clo = c & 0xFFFFF;
-  uint64_t t = mod_u64((uint64_t)d * chi, q, inv_q);
-  t = mod_u64(t << 20, q, inv_q);
-  return mod_u64(t + (uint64_t)d * clo, q, inv_q);
+  uint64_t t = mod_u64_near((uint64_t)d * chi, q, inv_q);
+  t = mod_u64_near(t << 20, q, inv_q);
+  return mod_u64_near(t + (uint64_t)d * clo, q, inv_q);
 }
 
 // hat residues (already inverse-transformed, canonical) -> signed CRT -> mod q.
 // The integer being reconstructed is the exact negacyclic result; it lies in
 // (-M/2, M/2), which lab_ctx guarantees through max_len.  No integer divisions: see mod_u64.
+// L (limbs) is a template parameter so that the Garner recurrence is straight-line code with the table in scalar
+// registers; a thread converts two neighbouring coefficients (8-byte loads per limb, one 16-byte store).
+template <int L>
+__device__ __forceinline__ uint64_t crt_one(const uint32_t (&r)[L], const CrtTable* __restrict__ crt, uint64_t q, double inv_q) {
+  if (L == 1 && (uint64_t)crt->p[0] == q) return r[0];
+  uint32_t d[L];
+  // Garner mixed-radix digits
+  d[0] = r[0];
+#pragma unroll
+  for (int a = 1; a < L; a++) {
+    const uint32_t p = crt->p[a];
+    uint32_t t = r[a];
+#pragma unroll
+    for (int b = 0; b < a; b++) {
+      // digits of the other limbs are < 2^30: below 2p for the 30-bit primes, anything for a small last prime
+      const uint32_t db = p > (1u << 29) ? csub(d[b], p) : (uint32_t)mod_u64_near(d[b], p, crt->inv_p[a]);
+      const uint32_t diff = t >= db ? t - db : t + p - db;
+      t = csub(mul_shoup_lazy(diff, crt->ginv[a][b][0], crt->ginv[a][b][1], p), p);
+    }
+    d[a] = t;
+  }
+  // sign: value > (M-1)/2 ?  (lexicographic comparison of the digits, most significant first)
+  bool neg = false, decided = false;
+#pragma unroll
+  for (int a = L - 1; a >= 0; a--) {
+    const uint32_t hd = crt->half_digits[a];
+    if (!decided && d[a] != hd) { neg = d[a] > hd; decided = true; }
+  }
+  uint64_t acc = d[0] < q ? d[0] : mod_u64_near(d[0], q, inv_q);
+#pragma unroll
+  for (int a = 1; a < L; a++) {
+    acc += mulmod_q(d[a], crt->prefix_mod_q[a], q, inv_q);
+    acc -= acc >= q ? q : 0;
+  }
+  const uint64_t mm = crt->m_mod_q;
+  if (neg) acc = acc >= mm ? acc - mm : acc + q - mm;
+  return acc;
+}
+
+template <int L>
 __global__ void __launch_bounds__(256)
 k_crt_to_u64(const uint32_t* __restrict__ src, size_t src_ps, const JobPtrs dstp, size_t nwords,
              const CrtTable* __restrict__ crt, size_t src_js) {
   uint64_t* __restrict__ coeffs = static_cast<uint64_t*>(dstp.p[blockIdx.y]);
   src += (size_t)blockIdx.y * src_js;
-  const int L = crt->nlimbs;
   const uint64_t q = crt->q;
   const double inv_q = crt->inv_q;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < nwords; i += stride) {
-    uint32_t r[MAX_LIMBS], d[MAX_LIMBS];
-    for (int l = 0; l < L; l++) r[l] = src[(size_t)l * src_ps + i];
-    if (L == 1 && (uint64_t)crt->p[0] == q) { coeffs[i] = r[0]; continue; }
-    // Garner mixed-radix digits
-    d[0] = r[0];
-    for (int a = 1; a < L; a++) {
-      const uint32_t p = crt->p[a];
-      uint32_t t = r[a];
-      for (int b = 0; b < a; b++) {
-        // digits of the other limbs are < 2^30: below 2p for the 30-bit primes, anything for a small last prime
-        const uint32_t db = p > (1u << 29) ? csub(d[b], p) : (uint32_t)mod_u64(d[b], p, crt->inv_p[a]);
-        uint32_t diff = t >= db ? t - db : t + p - db;
-        t = csub(mul_shoup_lazy(diff, crt->ginv[a][b][0], crt->ginv[a][b][1], p), p);
-      }
-      d[a] = t;
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 2;
+  for (; i < nwords; i += stride) {   // nwords is a multiple of 64: the pair (i, i+1) is always in range
+    uint32_t r0[L], r1[L];
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+      const u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(src + (size_t)l * src_ps + i));
+      r0[l] = v.x; r1[l] = v.y;
     }
-    // sign: value > (M-1)/2 ?
-    bool neg = false;
-    for (int a = L - 1; a >= 0; a--) {
-      if (d[a] != crt->half_digits[a]) { neg = d[a] > crt->half_digits[a]; break; }
-    }
-    uint64_t acc = d[0] < q ? d[0] : mod_u64(d[0], q, inv_q);
-    for (int a = 1; a < L; a++) {
-      acc += mulmod_q(d[a], crt->prefix_mod_q[a], q, inv_q);
-      acc -= acc >= q ? q : 0;
-    }
-    if (neg) acc = acc >= crt->m_mod_q ? acc - crt->m_mod_q : acc + q - crt->m_mod_q;
-    coeffs[i] = acc;
+    ulonglong2 o;
+    o.x = crt_one<L>(r0, crt, q, inv_q);
+    o.y = crt_one<L>(r1, crt, q, inv_q);
+    *reinterpret_cast<ulonglong2*>(coeffs + i) = o;
   }
 }
 
 hipError_t launch_crt_to_u64_jobs(ConstHatView src, size_t src_js, const JobPtrs& coeffs, size_t count, const CrtTable* crt,
-                                  size_t njobs, hipStream_t s) {
+                                  int nlimbs, size_t njobs, hipStream_t s) {
   if (count == 0 || njobs == 0) return hipSuccess;
+  if ((src.plane_stride | src_js) & 1) return hipErrorInvalidValue;
   size_t nwords = count * D;
-  unsigned blocks = (unsigned)((nwords + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(k_crt_to_u64, dim3(blocks, (unsigned)njobs), dim3(256), 0, s, src.base, src.plane_stride, coeffs, nwords, crt,
-                     src_js);
+  unsigned blocks = (unsigned)((nwords / 2 + 255) / 256);
+  if (blocks > 16384) blocks = 16384;
+  const dim3 g(blocks, (unsigned)njobs);
+#define LAB_CRT_CASE(LL) \
+  case LL: hipLaunchKernelGGL(k_crt_to_u64<LL>, g, dim3(256), 0, s, src.base, src.plane_stride, coeffs, nwords, crt, src_js); break;
+  switch (nlimbs) {
+    LAB_CRT_CASE(1) LAB_CRT_CASE(2) LAB_CRT_CASE(3) LAB_CRT_CASE(4)
+    default: return hipErrorInvalidValue;
+  }
+#undef LAB_CRT_CASE
   return hipGetLastError();
 }
 
-hipError_t launch_crt_to_u64(ConstHatView src, uint64_t* coeffs, size_t count, const CrtTable* crt, hipStream_t s) {
+hipError_t launch_crt_to_u64(ConstHatView src, uint64_t* coeffs, size_t count, const CrtTable* crt, int nlimbs, hipStream_t s) {
   JobPtrs t;
   t.p[0] = coeffs;
-  return launch_crt_to_u64_jobs(src, 0, t, count, crt, 1, s);
+  return launch_crt_to_u64_jobs(src, 0, t, count, crt, nlimbs, 1, s);
 }
 
 __global__ void __launch_bounds__(256)

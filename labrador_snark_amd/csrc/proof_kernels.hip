@@ -39,14 +39,14 @@ k_decompose(const JobPtrs outp, const JobPtrs inp, size_t nwords, uint64_t q, ui
       if (v != 0) {
         // r0 = (v % base) % q ; r = r0 > half ? ((base - r0) % base) % q : r0 ; v = ((v - r mod q) / base) % q
         // v < q < 2^40 and base >= 2: quotients by `base` through mod_u64/div_u64 (no integer division)
-        uint64_t r0 = mod_u64(v, base, inv_base);
+        uint64_t r0 = mod_u64_near(v, base, inv_base);
         if (small_q) r0 %= q;
         r = r0;
         if (r0 > half) {
           r = base - r0;                  // 0 < r0 < base here, so (base - r0) % base == base - r0
           if (small_q) r %= q;
         }
-        v = div_u64(submod(v, r, q), base, inv_base);
+        v = div_u64_near(submod(v, r, q), base, inv_base);
         if (small_q) v %= q;
       }
       const size_t e = i / D;

@@ -244,7 +244,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     HatView src = darena ? HD(0, off) : HV(0, off);
     HatView t{dense_tmp, count * D};
     LAB_HIP(c, launch_ntt(false, src, t, count, basis_nlimbs(c, basis), basis_tabs(c, basis), 0, s, np, darena ? jsd : js, tmp_js));
-    LAB_HIP(c, launch_crt_to_u64_jobs(t, tmp_js, dst, count, basis_crt(c, basis), np, s));
+    LAB_HIP(c, launch_crt_to_u64_jobs(t, tmp_js, dst, count, basis_crt(c, basis), basis_nlimbs(c, basis), np, s));
     return LAB_OK;
   };
   auto gram_jobs = [&](size_t out_off, size_t p_off, size_t s_off) -> int {   // out[i][k] = sum_x P[x][i] S[x][k]

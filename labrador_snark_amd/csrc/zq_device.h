@@ -61,6 +61,26 @@ __device__ __forceinline__ uint64_t div_u64(uint64_t x, uint64_t m, double inv_m
   return qh;
 }
 
+// the same when x / m < 2^50 (the quotient estimate is then off by less than 3): branch-free fix-ups
+__device__ __forceinline__ uint64_t mod_u64_near(uint64_t x, uint64_t m, double inv_m) {
+  const uint64_t qh = (uint64_t)((double)x * inv_m);
+  int64_t r = (int64_t)(x - qh * m);
+  r += r < 0 ? (int64_t)m : 0;
+  r += r < 0 ? (int64_t)m : 0;
+  r -= r >= (int64_t)m ? (int64_t)m : 0;
+  r -= r >= (int64_t)m ? (int64_t)m : 0;
+  return (uint64_t)r;
+}
+__device__ __forceinline__ uint64_t div_u64_near(uint64_t x, uint64_t m, double inv_m) {
+  uint64_t qh = (uint64_t)((double)x * inv_m);
+  int64_t r = (int64_t)(x - qh * m);
+#pragma unroll
+  for (int k = 0; k < 2; k++) { const bool f = r < 0; r += f ? (int64_t)m : 0; qh -= f ? 1 : 0; }
+#pragma unroll
+  for (int k = 0; k < 2; k++) { const bool f = r >= (int64_t)m; r -= f ? (int64_t)m : 0; qh += f ? 1 : 0; }
+  return qh;
+}
+
 __device__ __forceinline__ uint32_t csub(uint32_t x, uint32_t m) {  // x in [0,2m) -> [0,m)
   return min(x, x - m);
 }
