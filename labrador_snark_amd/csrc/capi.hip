@@ -818,7 +818,7 @@ extern "C" int lab_gram(lab_ctx* c, lab_vec* out, size_t out_off, const lab_vec*
 }
 
 int lab::gram_impl(lab_ctx* c, HatView out, ConstHatView P, ConstHatView S, size_t n, size_t r, HatView partial) {
-  const size_t chunks = gram_num_chunks(n);
+  const size_t chunks = gram_chunks(n, r, c->nlimbs, 1);
   if (chunks == 1) {
     LAB_HIP(c, launch_gram_tiled(out, P, S, n, r, c->nlimbs, c->d_tabs, c->stream));
     return LAB_OK;

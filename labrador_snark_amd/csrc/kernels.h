@@ -135,8 +135,9 @@ hipError_t launch_slot_transpose(uint32_t* out_plane, size_t out_set_stride, siz
                                  size_t rows, size_t rows_pad, size_t ns, size_t ns_valid, size_t njobs, size_t nsub, hipStream_t s);
 int gemm_i8_waves(int planes, size_t rt_count, size_t nt);   // waves per block (4 or 8) the launcher will use
 hipError_t launch_gemm_i8(const Gemm8Args& a, size_t nt, int waves, hipStream_t s);
-// tiled Gram: partial[chunk][i][k], gram_num_chunks(n) chunks, to be summed with launch_sum_terms(rows = r*r)
+// tiled Gram: partial[chunk][i][k], gram_chunks(..) <= gram_num_chunks(n) chunks, to be summed with launch_sum_terms(rows = r*r)
 size_t gram_num_chunks(size_t n);
+size_t gram_chunks(size_t n, size_t r, int nlimbs, size_t njobs);
 hipError_t launch_gram_tiled(HatView partial, ConstHatView P, ConstHatView S, size_t n, size_t r, int nlimbs,
                              const LimbTable* tabs, hipStream_t s, size_t njobs = 1, size_t js = 0);
 // partial[chunk*len + rho] = sum_{m in chunk} G[m] * C[m*len + rho]; axpy_num_chunks(nterms) chunks

@@ -1265,96 +1265,137 @@ namespace lab {
 
 // ------------------------------------------------ tiled Gram product with split reduction
 // partial[chunk][i][k][j] = sum_{x in chunk} P[x][i][j] * S[x][k][j]
-// Same register tile as k_matmul_t (lane = slot, 4 x 8 accumulators) so each loaded value feeds 8 (P) or 4 (S)
-// multiply-adds; the reduction over x is cut into GR_CHUNK-long pieces for parallelism and summed by k_sum_terms.
-constexpr int GR_CHUNK = 64;
+// Block = 8 waves = a 16 x 32 tile of outputs (lane = slot j, wave = 8 x 8 accumulators).  The 48 polynomials of a
+// step x (16 rows of P, 32 columns of S) are fetched ONCE per block and shared through LDS, GL_XS steps per stage,
+// double buffered: 16 LDS reads feed 64 multiply-adds, so the kernel runs at the v_mad_u64_u32 issue rate instead of
+// the L2 -> L1 rate that a register-tile-only version (12 global loads per 32 multiply-adds) was bound by.  When
+// P == S and one column tile covers all of S the rows are read from the column stage (no second fetch).  The reduction
+// over x is cut into chunks for parallelism and summed by k_sum_terms.
+constexpr int GR_CHUNK = 64;     // smallest chunk: gram_num_chunks(n) bounds the number of partial results
+constexpr int GL_XS = 4, GL_TI = 16, GL_TK = 32, GL_NP = GL_TI + GL_TK;
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3)))
-k_gram_tiled(uint32_t* __restrict__ partial, size_t partial_ps, const uint32_t* __restrict__ P, size_t p_ps,
-             const uint32_t* __restrict__ S, size_t s_ps, unsigned n, unsigned r, unsigned nchunks,
-             const LimbTable* __restrict__ tabs, unsigned nlimbs, size_t js) {
+template <bool SAME>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_gram_lds(uint32_t* __restrict__ partial, size_t partial_ps, const uint32_t* __restrict__ P, size_t p_ps,
+           const uint32_t* __restrict__ S, size_t s_ps, unsigned n, unsigned r, unsigned nchunks, unsigned xchunk,
+           const LimbTable* __restrict__ tabs, unsigned nlimbs, size_t js) {
+  constexpr int NP = SAME ? GL_TK : GL_NP;                 // polynomials staged per step
+  constexpr int QPT = GL_XS * NP * (D / 4) / 512;          // 16-byte pieces per thread and stage
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2][GL_XS * NP * D];
   const unsigned limb = (blockIdx.z / nchunks) % nlimbs, chunk = blockIdx.z % nchunks;
   const size_t job = blockIdx.z / (nchunks * nlimbs);
-  partial += job * js; P += job * js; S += job * js;
+  partial += job * js + (size_t)limb * partial_ps;
+  P += job * js + (size_t)limb * p_ps;
+  S += job * js + (size_t)limb * s_ps;
   const uint32_t p = tabs[limb].p, p2 = tabs[limb].p2, pinv = tabs[limb].pinv, r2 = tabs[limb].r2;
-  const int j = threadIdx.x;
-  const unsigned i0 = blockIdx.x * MM_RT;
-  const unsigned k0 = (blockIdx.y * blockDim.y + threadIdx.y) * MM_CT;
-  if (k0 >= r) return;
-  const uint32_t* Pp = P + (size_t)limb * p_ps + j;
-  const uint32_t* Sp = S + (size_t)limb * s_ps + j;
-  unsigned pi[MM_RT], sk[MM_CT];
+  const int t = threadIdx.x, j = t & 63, w = t >> 6, wi = w >> 2, wk = w & 3;
+  const unsigned i0 = blockIdx.x * GL_TI, k0 = blockIdx.y * GL_TK;
+  const unsigned xbeg = chunk * xchunk, xend = min(xbeg + xchunk, n);
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+  // this thread's pieces of a stage: piece e = t + 512*q -> step e / (NP*16), polynomial (e / 16) % NP, quad e % 16
+  const uint32_t* srcp[QPT];
+  unsigned xs_of[QPT];
 #pragma unroll
-  for (int a = 0; a < MM_RT; a++) pi[a] = min(i0 + a, r - 1) * D;
+  for (int q = 0; q < QPT; q++) {
+    const unsigned e = t + 512 * q, slot = (e / 16) % NP;
+    xs_of[q] = e / (NP * 16);
+    srcp[q] = slot < GL_TK ? S + (size_t)min(k0 + slot, r - 1) * D + (e % 16) * 4
+                           : P + (size_t)min(i0 + slot - GL_TK, r - 1) * D + (e % 16) * 4;
+  }
+  u32x4_t pre[QPT];
+  auto fetch = [&](unsigned x0) {
 #pragma unroll
-  for (int b = 0; b < MM_CT; b++) sk[b] = min(k0 + b, r - 1) * D;
-  uint64_t acc[MM_RT][MM_CT];
-#pragma unroll
-  for (int a = 0; a < MM_RT; a++)
-#pragma unroll
-    for (int b = 0; b < MM_CT; b++) acc[a][b] = 0;
-  unsigned x = chunk * GR_CHUNK;
-  const unsigned xend = min(x + GR_CHUNK, n);
-  for (; x + 8 <= xend; x += 8) {
-#pragma unroll
-    for (int half = 0; half < 4; half++) {
-      uint32_t pv[2][MM_RT], sv[2][MM_CT];
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const size_t base = (size_t)(x + half * 2 + u) * r * D;
-#pragma unroll
-        for (int a = 0; a < MM_RT; a++) pv[u][a] = Pp[base + pi[a]];
-#pragma unroll
-        for (int b = 0; b < MM_CT; b++) sv[u][b] = Sp[base + sk[b]];
-      }
-#pragma unroll
-      for (int u = 0; u < 2; u++)
-#pragma unroll
-        for (int a = 0; a < MM_RT; a++)
-#pragma unroll
-          for (int b = 0; b < MM_CT; b++) acc[a][b] += (uint64_t)pv[u][a] * sv[u][b];
+    for (int q = 0; q < QPT; q++) {
+      const unsigned x = x0 + xs_of[q];
+      const u32x4_t z = {0, 0, 0, 0};
+      pre[q] = x < xend ? *reinterpret_cast<const u32x4_t*>(srcp[q] + (size_t)x * r * D) : z;
     }
+  };
+  auto park = [&](int buf) {
 #pragma unroll
-    for (int a = 0; a < MM_RT; a++)
+    for (int q = 0; q < QPT; q++) *reinterpret_cast<u32x4_t*>(&lds[buf][(t + 512 * q) * 4]) = pre[q];
+  };
+  // LDS word offsets of this wave's 8 rows and 8 columns inside one step of a stage
+  unsigned prow[8], scol[8];
 #pragma unroll
-      for (int b = 0; b < MM_CT; b++) acc[a][b] = acc_fold(acc[a][b], p, p2);
+  for (int a = 0; a < 8; a++) {
+    prow[a] = (SAME ? min(i0 + wi * 8 + a, r - 1) : GL_TK + wi * 8 + a) * D + j;
+    scol[a] = (wk * 8 + a) * D + j;
   }
-  for (; x < xend; x++) {  // fewer than 8 terms left
-    const size_t base = (size_t)x * r * D;
-    uint32_t pv[MM_RT], sv[MM_CT];
+  uint64_t acc[8][8];
 #pragma unroll
-    for (int a = 0; a < MM_RT; a++) pv[a] = Pp[base + pi[a]];
+  for (int a = 0; a < 8; a++)
 #pragma unroll
-    for (int b = 0; b < MM_CT; b++) sv[b] = Sp[base + sk[b]];
+    for (int b = 0; b < 8; b++) acc[a][b] = 0;
+
+  fetch(xbeg);
+  park(0);
+  __syncthreads();
+  int buf = 0;
+  unsigned since_fold = 0;
+  for (unsigned x = xbeg; x < xend; x += GL_XS, buf ^= 1) {
+    const bool more = x + GL_XS < xend;
+    if (more) fetch(x + GL_XS);
 #pragma unroll
-    for (int a = 0; a < MM_RT; a++)
+    for (int xs = 0; xs < GL_XS; xs++) {
+      uint32_t pv[8], sv[8];
 #pragma unroll
-      for (int b = 0; b < MM_CT; b++) acc[a][b] += (uint64_t)pv[a] * sv[b];
+      for (int a = 0; a < 8; a++) pv[a] = lds[buf][xs * NP * D + prow[a]];
+#pragma unroll
+      for (int b = 0; b < 8; b++) sv[b] = lds[buf][xs * NP * D + scol[b]];
+#pragma unroll
+      for (int a = 0; a < 8; a++)
+#pragma unroll
+        for (int b = 0; b < 8; b++) acc[a][b] += (uint64_t)pv[a] * sv[b];
+    }
+    since_fold += GL_XS;
+    if (since_fold >= 8) {     // at most 8 products (< 2^60 each) on top of a folded accumulator
+      since_fold = 0;
+#pragma unroll
+      for (int a = 0; a < 8; a++)
+#pragma unroll
+        for (int b = 0; b < 8; b++) acc[a][b] = acc_fold(acc[a][b], p, p2);
+    }
+    if (more) park(buf ^ 1);
+    __syncthreads();
   }
 #pragma unroll
-  for (int a = 0; a < MM_RT; a++)
+  for (int a = 0; a < 8; a++)
 #pragma unroll
-    for (int b = 0; b < MM_CT; b++) acc[a][b] = acc_fold(acc[a][b], p, p2);
-#pragma unroll
-  for (int a = 0; a < MM_RT; a++)
-#pragma unroll
-    for (int b = 0; b < MM_CT; b++)
-      if (i0 + a < r && k0 + b < r)
-        partial[(size_t)limb * partial_ps + (((size_t)chunk * r + i0 + a) * r + k0 + b) * D + j] =
-            mont_mul(redc64(acc[a][b], p, pinv), r2, p, pinv);
+    for (int b = 0; b < 8; b++) {
+      const unsigned i = i0 + wi * 8 + a, k = k0 + wk * 8 + b;
+      if (i < r && k < r)
+        partial[(((size_t)chunk * r + i) * r + k) * D + j] = mont_mul(redc64(acc_fold(acc[a][b], p, p2), p, pinv), r2, p, pinv);
+    }
 }
 
 size_t gram_num_chunks(size_t n) { return (n + GR_CHUNK - 1) / GR_CHUNK; }
 
+// chunks actually used for a launch: enough blocks for three rounds over the CUs, never more than gram_num_chunks(n)
+size_t gram_chunks(size_t n, size_t r, int nlimbs, size_t njobs) {
+  const size_t tiles = ((r + GL_TI - 1) / GL_TI) * ((r + GL_TK - 1) / GL_TK) * (size_t)nlimbs * njobs;
+  size_t want = (768 + tiles - 1) / tiles, most = gram_num_chunks(n);
+  if (want > most) want = most;
+  if (want < 1) want = 1;
+  const size_t xchunk = ((n + want - 1) / want + 7) / 8 * 8;
+  return (n + xchunk - 1) / xchunk;
+}
+
 hipError_t launch_gram_tiled(HatView partial, ConstHatView P, ConstHatView S, size_t n, size_t r, int nlimbs,
                              const LimbTable* tabs, hipStream_t s, size_t njobs, size_t js) {
   if (r == 0 || n == 0 || njobs == 0) return hipSuccess;
-  const unsigned nchunks = (unsigned)gram_num_chunks(n);
-  unsigned kgroups = (unsigned)((r + MM_CT - 1) / MM_CT);
-  unsigned wy = kgroups < 4 ? kgroups : 4;
-  dim3 grid((unsigned)((r + MM_RT - 1) / MM_RT), (kgroups + wy - 1) / wy, (unsigned)(nlimbs * nchunks * njobs));
-  hipLaunchKernelGGL(k_gram_tiled, grid, dim3(64, wy), 0, s, partial.base, partial.plane_stride, P.base,
-                     P.plane_stride, S.base, S.plane_stride, (unsigned)n, (unsigned)r, nchunks, tabs, (unsigned)nlimbs, js);
+  const size_t nchunks = gram_chunks(n, r, nlimbs, njobs);
+  const size_t want = nchunks;
+  const unsigned xchunk = (unsigned)(((n + want - 1) / want + 7) / 8 * 8);
+  dim3 grid((unsigned)((r + GL_TI - 1) / GL_TI), (unsigned)((r + GL_TK - 1) / GL_TK), (unsigned)(nlimbs * nchunks * njobs));
+  const bool same = P.base == S.base && P.plane_stride == S.plane_stride && r <= (size_t)GL_TK;
+  if (same)
+    hipLaunchKernelGGL(k_gram_lds<true>, grid, dim3(512), 0, s, partial.base, partial.plane_stride, P.base, P.plane_stride, S.base,
+                       S.plane_stride, (unsigned)n, (unsigned)r, (unsigned)nchunks, xchunk, tabs, (unsigned)nlimbs, js);
+  else
+    hipLaunchKernelGGL(k_gram_lds<false>, grid, dim3(512), 0, s, partial.base, partial.plane_stride, P.base, P.plane_stride, S.base,
+                       S.plane_stride, (unsigned)n, (unsigned)r, (unsigned)nchunks, xchunk, tabs, (unsigned)nlimbs, js);
   return hipGetLastError();
 }
 

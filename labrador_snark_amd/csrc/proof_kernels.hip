@@ -49,8 +49,9 @@ k_decompose(const JobPtrs outp, const JobPtrs inp, size_t nwords, uint64_t q, ui
         v = div_u64_near(submod(v, r, q), base, inv_base);
         if (small_q) v %= q;
       }
-      const size_t e = i / D;
-      out[(((e / group) * exp + k) * group + e % group) * D + i % D] = r;
+      // element counts are below 2^32 (launch_decompose_jobs checks): 32-bit quotient instead of a 64-bit division
+      const uint32_t e = (uint32_t)(i / D), g = (uint32_t)group, eg = e / g;
+      out[(((size_t)eg * exp + k) * g + (e - eg * g)) * D + i % D] = r;
     }
   }
 }
@@ -58,9 +59,10 @@ k_decompose(const JobPtrs outp, const JobPtrs inp, size_t nwords, uint64_t q, ui
 hipError_t launch_decompose_jobs(const JobPtrs& out, const JobPtrs& in, size_t count, uint64_t q, uint64_t base, int exp,
                                  size_t group, size_t njobs, hipStream_t s) {
   if (count == 0 || exp == 0 || njobs == 0) return hipSuccess;
+  if (count >> 32 || group >> 32 || group == 0) return hipErrorInvalidValue;
   size_t nwords = count * D;
   unsigned blocks = (unsigned)((nwords + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(k_decompose, dim3(blocks, (unsigned)njobs), dim3(256), 0, s, out, in, nwords, q, base, exp, group);
   return hipGetLastError();
 }

@@ -248,7 +248,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     return LAB_OK;
   };
   auto gram_jobs = [&](size_t out_off, size_t p_off, size_t s_off) -> int {   // out[i][k] = sum_x P[x][i] S[x][k]
-    const size_t chunks = gram_num_chunks(n);
+    const size_t chunks = gram_chunks(n, r, L, np);
     if (chunks == 1) {
       LAB_HIP(c, launch_gram_tiled(HV(0, out_off), HV(0, p_off), HV(0, s_off), n, r, L, tabs, s, np, js));
     } else {
