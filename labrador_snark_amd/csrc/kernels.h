@@ -129,6 +129,7 @@ struct Gemm8Args {
   uint32_t p;
   const LimbTable* tab;     // this limb's table (device): Montgomery constants for the recombination
   uint32_t pw[7];           // 256^e mod p, e = 0..6 (recombination weights)
+  uint32_t bias;            // 2^31 * (sum_{i<planes} 256^i)^2 mod p: what entering every D as D + 2^31 adds to the sum
   uint32_t* stage;          // non-null: results go to stage[job][slot][row][set] (full-line stores), see k_slot_transpose
 };
 hipError_t launch_slot_transpose(uint32_t* out_plane, size_t out_set_stride, size_t out_job_stride, const uint32_t* stage,

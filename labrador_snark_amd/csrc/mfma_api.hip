@@ -89,6 +89,12 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
     g.tab = (m->basis ? c->dg_tabs : c->d_tabs) + l;
     g.pw[0] = 1 % primes[l];
     for (int e = 1; e < 7; e++) g.pw[e] = (uint32_t)(((uint64_t)g.pw[e - 1] * 256) % primes[l]);
+    {
+      uint64_t sum = 0;
+      for (int i = 0; i < pl; i++) sum += g.pw[i];
+      sum %= primes[l];
+      g.bias = (uint32_t)((sum * sum % primes[l]) * ((1ull << 31) % primes[l]) % primes[l]);
+    }
     g.stage = stage;
     const bool prof = timed && c->prof_on && pl == 4;   // `timed`: the outer commitment (the measurement hook's kernel)
     if (prof && c->prof_used == c->prof_events.size()) {

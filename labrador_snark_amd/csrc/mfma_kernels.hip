@@ -333,21 +333,22 @@ k_gemm_i8(const Gemm8Args a) {
     const unsigned g = (row & 3) | ((row >> 3) << 2), lh = ((row >> 2) & 1) * 32;
     uint32_t res;
     if (big) {
-      uint32_t ct[7] = {0, 0, 0, 0, 0, 0, 0};
+      // every int32 D enters as the unsigned D + 2^31 (one xor), so the whole sum is unsigned multiply-adds with the
+      // weights 256^(i+i') mod p in scalar registers; the surplus 2^31 * sum 256^(i+i') mod p (a.bias, from the host) is
+      // taken off at the end.  A product is < 2^32 * p: it adds less than p (+ a carry) to the high word, which a lazy
+      // fold keeps below 2p: three products after the start, two after every fold stay below 4p < 2^32.
+      uint64_t acc = 0;                             // a 30-bit prime always has 4 digit planes (mfma_planes)
 #pragma unroll
       for (unsigned pi = 0; pi < 4; pi++)
 #pragma unroll
         for (unsigned pv = 0; pv < 4; pv++) {
-          if (pi < planes && pv < planes) {
-            const unsigned n = pv * ns + s;
-            const int32_t d = dl[(((tl * planes + pi) * RN + (n / 32) / HALVES) * 16 + g) * 64 + lh + (n % 32)];
-            ct[pi + pv] += csub(csub((uint32_t)d + p2, p2), p);      // canonical residue; at most 4 per c_t: < 4p < 2^32
-          }
+          const unsigned n = pv * ns + s, seq = pi * 4 + pv;
+          const int32_t d = dl[(((tl * 4 + pi) * RN + (n / 32) / HALVES) * 16 + g) * 64 + lh + (n % 32)];
+          acc += (uint64_t)((uint32_t)d ^ 0x80000000u) * pw[pi + pv];
+          if (seq >= 2 && seq % 2 == 0) acc = acc_fold_lazy(acc, p2);
         }
-      uint64_t acc = 0;
-#pragma unroll
-      for (int e = 0; e < 7; e++) acc += (uint64_t)csub(csub(ct[e], p2), p) * pw[e];   // 7 products < 2^60
-      res = mont_mul(redc64(acc_fold(acc, p, p2), p, pinv), r2, p, pinv);
+      const uint32_t v = mont_mul(redc64(acc_fold(acc, p, p2), p, pinv), r2, p, pinv);
+      res = csub(v + p - a.bias, p);
     } else {
       auto modp = [&](int64_t v) -> int64_t {      // |v| < 2^40: floor(v / p) from one double multiply is off by at most 1
         const int64_t qq = (int64_t)__builtin_floor((double)v * inv_p);
