@@ -135,6 +135,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-compact-crs", action="store_true", help="keep B, C, D in the main RNS basis (12 B/coefficient at the 33-bit q)")
+    ap.add_argument("--digit-basis", choices=["auto", "u16", "mfma23"], default="auto",
+                    help="digit basis of B, C, D: u16 = a prefix of the main primes plus one prime below 2^16 (10 B per coefficient, "
+                         "the single-proof path streams it); mfma23 = primes below 2^23 (three signed byte planes per residue on "
+                         "the matrix cores); auto = mfma23 on the matrix-core path, else u16")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -185,8 +189,9 @@ def main():
                            psi=tape["psi"], omega=dev64(tape["omega"]),
                            alpha=dev64(tape["alpha"]), beta=dev64(tape["beta"]), c=dev64(tape["c"])))
     # B, C, D are only ever multiplied by decomposition digits: keep them in the digit basis (u16 small limb)
-    crs = lab.ResidentCRS(ctx, k, compact=not args.no_compact_crs).fill_synthetic(1000 + 10 * rank)
     use_mfma = args.step3 == "mfma" or (args.step3 == "auto" and nbatch > 8)
+    basis23 = not args.no_compact_crs and (args.digit_basis == "mfma23" or (args.digit_basis == "auto" and use_mfma))
+    crs = lab.ResidentCRS(ctx, k, compact=not args.no_compact_crs, mfma_basis=basis23).fill_synthetic(1000 + 10 * rank)
     if use_mfma:
         crs.pack_mfma(drop_B=True)     # one-time, like the CRS expansion: outside every timed region
     torch.cuda.synchronize()
@@ -236,6 +241,7 @@ def main():
             try:
                 rec = json.load(open(pmc))
                 if rec.get("workload_key") == [q, n, r, kappa, ctx.nlimbs, bool(crs.compact), nbatch] and \
+                        rec.get("digit_primes") == getattr(ctx, "digit_primes", None) and \
                         rec.get("step3", "valu") == ("mfma" if use_mfma else "valu"):
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
@@ -250,18 +256,22 @@ def main():
                                    "CRS resident in transform domain, CRS expansion excluded; %d independent proofs per step share the CRS"
                                    % (n, r, kappa, q, ctx.nlimbs, nbatch),
                        "q": q, "n": n, "r": r, "kappa": kappa, "t1": k.T_1, "t2": k.T_2, "b1": k.B_1, "b2": k.B_2,
-                       "nlimbs": ctx.nlimbs, "crs_basis": ("digit basis %s, u16 last limb" % getattr(ctx, "digit_primes", None))
-                       if crs.compact else "main basis", "proofs_per_step_per_gpu": nbatch,
+                       "nlimbs": ctx.nlimbs, "crs_basis": ("digit basis %s%s" % (getattr(ctx, "digit_primes", None), ", u16 last limb" if ctx.digit_small else
+                                                          " (three signed byte planes per residue)"))
+                       if crs.compact else "main basis", "digit_primes": getattr(ctx, "digit_primes", None) if crs.compact else None, "proofs_per_step_per_gpu": nbatch,
                        "step3": "int8 MFMA GEMMs (signed base-256 digit planes, int32 accumulation, exact)" if use_mfma
                        else "64-bit multiply-add kernels", "parallelism": "%d independent proofs per gpu x %d gpus" % (nbatch, world)},
             "ms_per_proof": elapsed / (args.steps * nbatch) * 1e3,
             "proofs_per_s": value, "witness_Rq_elems_per_s": value * n * r,
             "ring_products_per_proof": sum(counts.values()),
             "checksum_u1_u2": int(chk.item()),
-            "roofline": {"bound": "hbm", "kernel": ("lab::%s — one 30-bit limb (4 digit planes) of the outer commitment "
-                                                    "sum_ik B_ik t_i^(k) (src/proofgen.rs:101-132) for the %d proofs of a step, "
-                                                    "one launch per limb; the 257 limb (2 planes) is a smaller launch of the "
-                                                    "same template" if use_mfma else
+            "roofline": {"bound": "hbm", "kernel": (("lab::%s — one 23-bit limb (3 digit planes) of the outer commitment "
+                                                     "sum_ik B_ik t_i^(k) (src/proofgen.rs:101-132) for the %d proofs of a step, "
+                                                     "one launch per limb" if basis23 else
+                                                     "lab::%s — one 30-bit limb (4 digit planes) of the outer commitment "
+                                                     "sum_ik B_ik t_i^(k) (src/proofgen.rs:101-132) for the %d proofs of a step, "
+                                                     "one launch per limb; the 257 limb (2 planes) is a smaller launch of the "
+                                                     "same template") if use_mfma else
                                                     "lab::%s — the u32 limbs of the outer commitment sum_ik B_ik t_i^(k) "
                                                     "(src/proofgen.rs:101-132) for the %d proofs of a step; the u16 limb runs as a "
                                                     "second launch of the same kernel template") % (step3_kernel, nbatch),
@@ -271,10 +281,11 @@ def main():
                          "kernel_share_of_step": (kernel_ms / 1e3) / elapsed if elapsed > 0 else None},
         }
         if use_mfma and launches:
-            # the same launch against the matrix-core roofline: int8 multiply-adds of one limb's GEMMs (64 slots x 4 matrix
-            # planes x kappa1 rows x r*t1*kappa terms x (padded sets x 4 vector planes) columns), dense int8 peak 5 PFLOP/s
+            # the same launch against the matrix-core roofline: int8 multiply-adds of one limb's GEMMs (64 slots x pl matrix
+            # planes x kappa1 rows x r*t1*kappa terms x (padded sets x pl vector planes) columns), dense int8 peak 5 PFLOP/s
             ns_pad = 64 if nbatch > 32 else 32 if nbatch > 16 else 16 if nbatch > 8 else 8
-            ops = 2.0 * D * 4 * kappa * (r * k.T_1 * kappa) * (ns_pad * 4)
+            pl = 3 if basis23 else 4
+            ops = 2.0 * D * pl * kappa * (r * k.T_1 * kappa) * (ns_pad * pl)
             result["roofline"].update({"mfma_int8_ops_per_launch": ops, "mfma_achieved_TOPs": ops / per_launch_s / 1e12,
                                        "mfma_peak_TOPs": 5000.0, "mfma_frac": ops / per_launch_s / 1e12 / 5000.0})
 

@@ -116,6 +116,10 @@ const char *lab_ctx_profile_kernel(const lab_ctx *ctx);
  * digit_bound) and by lab_prove_core / lab_verify_core for B, C, D.  Fails with LAB_ERR_RANGE when no smaller
  * basis exists (e.g. q is its own NTT prime). */
 int lab_ctx_enable_digit_basis(lab_ctx *ctx, uint64_t max_terms, uint64_t digit_bound);
+/* The same, with a basis made for the matrix-core path (lab_mat8_pack): primes below 2^23, whose residues are three
+ * signed bytes (9 instead of 16 byte products per modular product, 3 bytes of packed matrix per limb and
+ * coefficient).  No u16 limb; works for every q, also a directly NTT-friendly one.  One of the two per context. */
+int lab_ctx_enable_digit_basis_mfma(lab_ctx *ctx, uint64_t max_terms, uint64_t digit_bound);
 /* nlimbs/primes of the digit basis; max_len = max_terms; device = 1 when the last limb is a u16-storable prime */
 int lab_ctx_digit_info(const lab_ctx *ctx, lab_info *out);
 int lab_vec_create_digit(lab_ctx *ctx, size_t count, int compact, lab_vec **out);

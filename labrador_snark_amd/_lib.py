@@ -83,6 +83,7 @@ SIGNATURES = {
                                       C.POINTER(C.c_double)]),
     "lab_ctx_profile_kernel": (C.c_char_p, [C.c_void_p]),
     "lab_ctx_enable_digit_basis": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
+    "lab_ctx_enable_digit_basis_mfma": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
     "lab_ctx_digit_info": (C.c_int, [C.c_void_p, C.POINTER(lab_info)]),
     "lab_vec_create_digit": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
     "lab_vec_basis": (C.c_int, [C.c_void_p]),

@@ -87,10 +87,13 @@ class Context:
         import torch
         self._check(self._lib.lab_ctx_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
-    def enable_digit_basis(self, max_terms, digit_bound):
+    def enable_digit_basis(self, max_terms, digit_bound, mfma=False):
         """Second, smaller RNS basis for reductions whose vector operand is a decomposition digit (< digit_bound):
-        see lab_ctx_enable_digit_basis.  Returns (primes, last_limb_is_u16, bytes_per_coefficient)."""
-        self._check(self._lib.lab_ctx_enable_digit_basis(self._h, int(max_terms), int(digit_bound)))
+        see lab_ctx_enable_digit_basis.  mfma=True picks primes below 2^23 instead (three signed byte planes per
+        residue on the matrix cores, lab_ctx_enable_digit_basis_mfma).  Returns (primes, last_limb_is_u16,
+        bytes_per_coefficient)."""
+        fn = self._lib.lab_ctx_enable_digit_basis_mfma if mfma else self._lib.lab_ctx_enable_digit_basis
+        self._check(fn(self._h, int(max_terms), int(digit_bound)))
         return self.digit_info()
 
     def digit_info(self):

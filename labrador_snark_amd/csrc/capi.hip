@@ -303,6 +303,42 @@ extern "C" int lab_ctx_enable_digit_basis(lab_ctx* c, uint64_t max_terms, uint64
   return LAB_OK;
 }
 
+// The digit basis for the matrix-core path: primes below 2^23 - 0x8080, whose residues are three signed bytes — 9
+// instead of 16 byte products per modular product and 3 instead of 4 bytes of matrix per limb and coefficient.
+extern "C" int lab_ctx_enable_digit_basis_mfma(lab_ctx* c, uint64_t max_terms, uint64_t digit_bound) {
+  if (!c) return LAB_ERR_ARG;
+  if (max_terms == 0 || digit_bound < 2 || digit_bound > c->q) return fail(c, LAB_ERR_ARG, "lab_ctx_enable_digit_basis_mfma: bad bounds");
+  if (c->dg_nlimbs) return fail(c, LAB_ERR_ARG, "lab_ctx_enable_digit_basis_mfma: a digit basis is already enabled");
+  const u128 need = (u128)max_terms * D * (u128)(c->q - 1) * (u128)(digit_bound - 1);
+  // NTT-friendly (p == 1 mod 128) primes, descending from the largest residue three signed digits can hold
+  const uint32_t top = (1u << 23) - 0x8080;
+  int L = 0;
+  u128 M = 1;
+  for (uint32_t p = top / (2 * D) * (2 * D) + 1; p > (1u << 22) && L < MAX_LIMBS; p -= 2 * D) {
+    if (p > top || !is_prime_u64(p)) continue;
+    c->dg_primes[L++] = p;
+    M *= p;
+    if ((M - 1) / 2 >= need) break;
+  }
+  if ((M - 1) / 2 < need) {
+    for (int l = 0; l < MAX_LIMBS; l++) c->dg_primes[l] = 0;
+    return fail(c, LAB_ERR_RANGE, "lab_ctx_enable_digit_basis_mfma: %d primes below 2^23 do not cover these bounds", MAX_LIMBS);
+  }
+  c->dg_nlimbs = L;
+  c->dg_small = false;
+  c->dg_terms = max_terms;
+  c->dg_vmax = digit_bound - 1;
+  for (int l = 0; l < c->dg_nlimbs; l++)
+    if (!build_limb_table(c->dg_primes[l], &c->dg_h_tabs[l])) { c->dg_nlimbs = 0; return fail(c, LAB_ERR_ARG, "digit basis: no root of unity"); }
+  build_crt_table(c->q, c->dg_nlimbs, c->dg_primes, &c->dg_h_crt);
+  LAB_HIP(c, hipSetDevice(c->device));
+  LAB_HIP(c, hipMalloc(&c->dg_tabs, sizeof(LimbTable) * c->dg_nlimbs));
+  LAB_HIP(c, hipMalloc(&c->dg_crt, sizeof(CrtTable)));
+  LAB_HIP(c, hipMemcpy(c->dg_tabs, c->dg_h_tabs, sizeof(LimbTable) * c->dg_nlimbs, hipMemcpyHostToDevice));
+  LAB_HIP(c, hipMemcpy(c->dg_crt, &c->dg_h_crt, sizeof(CrtTable), hipMemcpyHostToDevice));
+  return LAB_OK;
+}
+
 extern "C" int lab_ctx_digit_info(const lab_ctx* c, lab_info* out) {
   if (!c || !out) return LAB_ERR_ARG;
   out->q = c->q;

@@ -23,13 +23,13 @@ namespace lab {
 int mfma_planes(uint32_t p) {   // digits d_i in [-128,127] (the last one unrestricted within i8) covering [0, p)
   int bits = 0;
   while (bits < 32 && ((uint64_t)1 << bits) < p) bits++;   // p - 1 < 2^bits
-  const int pl = (bits + 1 + 7) / 8;
-  return pl == 3 ? 4 : pl;                                  // the GEMM block holds 4 / planes row tiles
+  return (bits + 1 + 7) / 8;                                // 2 below 2^15, 3 below 2^23, else 4
 }
 
 // column tiles for ns sets whose residues need `planes_v` digit planes
 static size_t nt_for(int ns, int planes_v) {
   const size_t nt = ((size_t)ns * planes_v + 31) / 32;
+  if (planes_v == 3) return nt > 3 ? 6 : nt;                // 3-plane limbs: 1, 2, 3, 6 column tiles
   return nt == 3 ? 4 : (nt > 4 ? 8 : nt);                   // the GEMM is instantiated for 1, 2, 4, 8 column tiles
 }
 
@@ -63,9 +63,9 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
   static const bool no_pair = getenv("LAB_GEMM_NO_PAIR") != nullptr;
   bool paired = false;
   if (!no_pair && njobs >= 2 && njobs % 2 == 0 && ns == 32) {
-    bool all4 = true;
-    for (int l = 0; l < m->nlimbs; l++) all4 = all4 && m->planes[l] == 4;
-    if (all4) {
+    bool same = m->planes[0] >= 3;                           // every limb with 4 (or every limb with 3) planes
+    for (int l = 1; l < m->nlimbs; l++) same = same && m->planes[l] == m->planes[0];
+    if (same) {
       paired = true;
       sub_stride_v = v_job_stride;
       njobs /= 2; ns = 64; v_job_stride *= 2;
@@ -96,7 +96,7 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
       g.bias = (uint32_t)((sum * sum % primes[l]) * ((1ull << 31) % primes[l]) % primes[l]);
     }
     g.stage = stage;
-    const bool prof = timed && c->prof_on && pl == 4;   // `timed`: the outer commitment (the measurement hook's kernel)
+    const bool prof = timed && c->prof_on && pl >= 3;   // `timed`: the outer commitment (the measurement hook's kernel)
     if (prof && c->prof_used == c->prof_events.size()) {
       hipEvent_t a, b;
       LAB_HIP(c, hipEventCreate(&a));
@@ -139,11 +139,6 @@ extern "C" int lab_mat8_pack(lab_ctx* c, const lab_vec* M, size_t m_off, size_t 
   m->kt_count = ((nmat * cols + 31) / 32 + 11) / 12 * 12;   // the GEMM walks K in stages of 4 k-tiles, 3 stages per loop trip
   const uint32_t* primes = M->basis ? c->dg_primes : c->primes;
   const int nfull = M->planes32();
-  for (int l = 0; l < m->nlimbs; l++)   // the 32-bit recombination adds 2p to an int32 sum of K byte products: K * 2^14 < 2p
-    if (primes[l] > (1u << 29) && (uint64_t)nmat * cols * 16384 >= 2ull * primes[l]) {
-      delete m;
-      return fail(c, LAB_ERR_RANGE, "lab_mat8_pack: %zu products per sum are too many for limb prime %u", nmat * cols, primes[l]);
-    }
   for (int l = 0; l < m->nlimbs; l++) {
     m->planes[l] = mfma_planes(primes[l]);
     const size_t bytes = (size_t)D * m->planes[l] * m->rt_count * m->kt_count * 1024;

@@ -178,13 +178,16 @@ constexpr int G8_KS = 4;
 
 // WAVES = 4 or 8 waves per block: with 8 the block owns two 32-row tiles (of a 4-plane limb) that share every B stage,
 // which halves the L2 -> LDS operand traffic per multiply and the B staging registers per thread.
+// A limb whose prime is below 2^23 has 3 digit planes: blocks of 3 or 6 waves (one or two row tiles), 3 or 6 column tiles
+// for 32 or 64 sets, 9 instead of 16 byte products per modular product.
 template <int NT, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES)
 k_gemm_i8(const Gemm8Args a) {
-  // B staging during the K loop (2 x KS*NT KiB), afterwards the int32 tiles of four waves at a time (4 x RN*4 KiB)
+  // B staging during the K loop (2 x KS*NT KiB), afterwards the int32 tiles of one wave group at a time (GW x RN*4 KiB)
   constexpr int NTHR = 64 * WAVES;
-  constexpr int RN = NT > 4 ? 4 : NT;              // column tiles recombined per pass (NT = 8: two passes of 4)
-  constexpr int LQ = 2 * G8_KS * NT * 64 > 4 * RN * 16 * 64 / 4 ? 2 * G8_KS * NT * 64 : 4 * RN * 16 * 64 / 4;
+  constexpr int GW = WAVES % 3 == 0 ? 3 : 4;       // waves that recombine together: the planes of one row tile (4 or 3 planes) or of two (2 planes)
+  constexpr int RN = NT > 4 ? NT / 2 : NT;         // column tiles recombined per pass (NT = 8, 6: two passes of 4, 3)
+  constexpr int LQ = 2 * G8_KS * NT * 64 > GW * RN * 16 * 64 / 4 ? 2 * G8_KS * NT * 64 : GW * RN * 16 * 64 / 4;
   __shared__ u32x4_t lds[LQ];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;   // LDS byte address
@@ -199,8 +202,8 @@ k_gemm_i8(const Gemm8Args a) {
   const u32x4_t* A = reinterpret_cast<const u32x4_t*>(a.M8) + ((size_t)ji * rt_count + min(rt, rt_count - 1)) * kt_count * 64 + lane;
   const u32x4_t* B = reinterpret_cast<const u32x4_t*>(a.V8 + (size_t)job * a.v8_job_stride) + (size_t)j * kt_count * NT * 64;
   constexpr int BQ = G8_KS * NT * 64;              // B quads per stage
-  constexpr int BPT = BQ / NTHR;                   // per thread
-  static_assert(BQ % NTHR == 0, "a stage's B operands are a whole number of quads per thread");
+  constexpr int BPT = (BQ + NTHR - 1) / NTHR;      // per thread (the last one guarded when 64*WAVES does not divide BQ)
+  constexpr bool BEVEN = BQ % NTHR == 0;
 
   i32x16_t acc[NT];
 #pragma unroll
@@ -214,7 +217,7 @@ k_gemm_i8(const Gemm8Args a) {
   // B operands on their way to LDS: up to 4 column tiles a ring of 3 stages like A (two stages in flight: sums as
   // short as K = 1024 are 8 stages, there is no steady state to hide a one-stage prefetch behind); with 8 column
   // tiles (long sums only) one stage, for the registers
-  constexpr bool BRING = NT * 4 / WAVES <= 4;      // i.e. BPT <= 4
+  constexpr bool BRING = BPT <= 4;
   u32x4_t b0[BPT], b1[BRING ? BPT : 1], b2[BRING ? BPT : 1];
   auto loadA = [&](unsigned st, u32x4_t (&dst)[G8_KS]) {
 #pragma unroll
@@ -223,11 +226,13 @@ k_gemm_i8(const Gemm8Args a) {
   };
   auto loadB = [&](unsigned st, u32x4_t (&dst)[BPT]) {
 #pragma unroll
-    for (int q = 0; q < BPT; q++) dst[q] = B[(size_t)st * BQ + t + q * NTHR];
+    for (int q = 0; q < BPT; q++)
+      if (BEVEN || t + q * NTHR < BQ) dst[q] = B[(size_t)st * BQ + t + q * NTHR];
   };
   auto parkB = [&](int buf, const u32x4_t (&src)[BPT]) {
 #pragma unroll
-    for (int q = 0; q < BPT; q++) lds[buf * BQ + t + q * NTHR] = src[q];
+    for (int q = 0; q < BPT; q++)
+      if (BEVEN || t + q * NTHR < BQ) lds[buf * BQ + t + q * NTHR] = src[q];
   };
   // one stage: multiply stage st (A operands in `cur`, B operands in LDS buffer st & 1) while later stages' operands
   // are fetched: A of stage st+2 into `nxt` (the ring slot stage st-1 used); B of stage st+2 into `bld` with the ring
@@ -294,8 +299,8 @@ k_gemm_i8(const Gemm8Args a) {
   // tiles of its half.
   int32_t* dl = reinterpret_cast<int32_t*>(lds);
   constexpr int HALVES = NT / RN;
-  constexpr int WG = WAVES / 4;                     // groups of four waves take turns in the buffer
-  const unsigned tiles_per_pass = 4 / planes;       // row tiles whose planes sit in one group of four waves
+  constexpr int WG = WAVES / GW;                    // the wave groups take turns in the buffer
+  const unsigned tiles_per_pass = GW / planes;      // row tiles whose planes sit in one wave group
   bool first_pass = true;
 #pragma unroll
   for (int wg = 0; wg < WG; wg++)
@@ -303,12 +308,12 @@ k_gemm_i8(const Gemm8Args a) {
   for (int half = 0; half < HALVES; half++) {
   if (!first_pass) __syncthreads();               // everybody finished reading the previous pass
   first_pass = false;
-  if (w / 4 == wg) {
+  if (w / GW == wg) {
 #pragma unroll
     for (int n = 0; n < NT; n++)
       if (n % HALVES == half) {
 #pragma unroll
-        for (int g = 0; g < 16; g++) dl[(((w % 4) * RN + n / HALVES) * 16 + g) * 64 + lane] = acc[n][g];
+        for (int g = 0; g < 16; g++) dl[(((w % GW) * RN + n / HALVES) * 16 + g) * 64 + lane] = acc[n][g];
       }
   }
   __syncthreads();
@@ -319,7 +324,7 @@ k_gemm_i8(const Gemm8Args a) {
   const uint32_t p = a.p;
   const LimbTable* tab = a.tab;
   const uint32_t p2 = tab->p2, pinv = tab->pinv, r2 = tab->r2;
-  const bool big = p > (1u << 29);
+  const bool big = GW != 3 && p > (1u << 29);
   uint32_t pw[7];                                 // 256^e mod p, from the host
 #pragma unroll
   for (int e = 0; e < 7; e++) pw[e] = a.pw[e];
@@ -348,6 +353,22 @@ k_gemm_i8(const Gemm8Args a) {
           if (seq >= 2 && seq % 2 == 0) acc = acc_fold_lazy(acc, p2);
         }
       const uint32_t v = mont_mul(redc64(acc_fold(acc, p, p2), p, pinv), r2, p, pinv);
+      res = csub(v + p - a.bias, p);
+    } else if (GW == 3) {
+      // a prime in [2^15, 2^23) with 3 planes: the same unsigned sum, 9 products < 2^32 * p each, no folds on the way
+      // (the high word stays below 9p < 2^27); it is brought below p by conditional subtractions of 8p, 4p, 2p, p
+      uint64_t acc = 0;
+#pragma unroll
+      for (unsigned pi = 0; pi < 3; pi++)
+#pragma unroll
+        for (unsigned pv = 0; pv < 3; pv++) {
+          const unsigned n = pv * ns + s;
+          const int32_t d = dl[(((tl * 3 + pi) * RN + (n / 32) / HALVES) * 16 + g) * 64 + lh + (n % 32)];
+          acc += (uint64_t)((uint32_t)d ^ 0x80000000u) * pw[pi + pv];
+        }
+      uint32_t hi = (uint32_t)(acc >> 32);
+      hi = min(hi, hi - 8 * p); hi = min(hi, hi - 4 * p); hi = min(hi, hi - p2); hi = min(hi, hi - p);
+      const uint32_t v = mont_mul(redc64(((uint64_t)hi << 32) | (uint32_t)acc, p, pinv), r2, p, pinv);
       res = csub(v + p - a.bias, p);
     } else {
       auto modp = [&](int64_t v) -> int64_t {      // |v| < 2^40: floor(v / p) from one double multiply is off by at most 1
@@ -413,6 +434,7 @@ hipError_t launch_slot_transpose(uint32_t* out_plane, size_t out_set_stride, siz
 // tiles; the caller derives rgroups from gemm_i8_waves().  LAB_GEMM_WAVES=4 in the environment keeps 4-wave blocks.
 int gemm_i8_waves(int planes, size_t rt_count, size_t nt) {
   static const int env = getenv("LAB_GEMM_WAVES") ? atoi(getenv("LAB_GEMM_WAVES")) : 0;
+  if (planes == 3) return rt_count >= 2 ? 6 : 3;
   if (env == 4) return 4;
   return planes == 4 && rt_count >= 2 && nt >= 2 ? 8 : 4;
 }
@@ -422,6 +444,21 @@ hipError_t launch_gemm_i8(const Gemm8Args& a, size_t nt, int waves, hipStream_t 
 #define LAB_G8(NTV)                                                                                   \
   if (waves == 8) hipLaunchKernelGGL((k_gemm_i8<NTV, 8>), g, dim3(512), 0, s, a);                     \
   else hipLaunchKernelGGL((k_gemm_i8<NTV, 4>), g, dim3(256), 0, s, a)
+#define LAB_G6(NTV)                                                                                   \
+  if (waves == 6) hipLaunchKernelGGL((k_gemm_i8<NTV, 6>), g, dim3(384), 0, s, a);                     \
+  else hipLaunchKernelGGL((k_gemm_i8<NTV, 3>), g, dim3(192), 0, s, a)
+  if (a.planes == 3) {                              // 3-plane limbs: blocks of 3 or 6 waves
+    if (waves != 3 && waves != 6) return hipErrorInvalidValue;
+    switch (nt) {
+      case 1: LAB_G6(1); break;
+      case 2: LAB_G6(2); break;
+      case 3: LAB_G6(3); break;
+      case 6: LAB_G6(6); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
+  if (waves != 4 && waves != 8) return hipErrorInvalidValue;
   switch (nt) {
     case 1:
       if (waves != 4) return hipErrorInvalidValue;
@@ -432,6 +469,7 @@ hipError_t launch_gemm_i8(const Gemm8Args& a, size_t nt, int waves, hipStream_t 
     case 8: LAB_G8(8); break;
     default: return hipErrorInvalidValue;
   }
+#undef LAB_G6
 #undef LAB_G8
   return hipGetLastError();
 }

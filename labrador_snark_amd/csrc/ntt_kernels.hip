@@ -73,11 +73,11 @@ k_reduce_u64(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, size_
   }
 }
 
-// v < 2^40 mod a prime p < 2^16 (the small limb of the digit basis): Barrett with m ~ 2^32 / p, all in 32 bits.
-// umulhi(x, m) underestimates floor(x / p) by at most 2, so the remainder is below 3p < 2^18.
+// v < 2^40 mod a prime p < 2^23 (the limbs of a digit basis that are not main-basis primes): Barrett with m ~ 2^32 / p,
+// all in 32 bits.  umulhi(x, m) underestimates floor(x / p) by at most 2, so the remainder is below 3p < 2^25.
 __device__ __forceinline__ uint32_t reduce_small16(uint32_t hi8, uint32_t lo, uint32_t p, uint32_t m, uint32_t r1) {
   uint32_t b = lo - __umulhi(lo, m) * p;          // lo mod p, in [0, 3p)
-  uint32_t s = hi8 * r1 + b;                       // hi * (2^32 mod p) + ...: < 2^8 * 2^16 + 2^18
+  uint32_t s = hi8 * r1 + b;                       // hi * (2^32 mod p) + ...: < 2^8 * 2^23 + 2^25 < 2^32
   s -= __umulhi(s, m) * p;
   return csub(csub(s, 2 * p), p);
 }
@@ -90,7 +90,7 @@ __device__ __forceinline__ uint32_t reduce_small16(uint32_t hi8, uint32_t lo, ui
 // conflict-free) and stay in registers while each limb is reduced, transformed and stored.
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_to_hat_fused(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, size_t dst_js, size_t count, int nlimbs,
-               const LimbTable* __restrict__ tabs) {
+               const LimbTable* __restrict__ tabs, uint64_t in_bound) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[TILE_WORDS];
   const uint64_t* __restrict__ coeffs = static_cast<const uint64_t*>(src.p[blockIdx.y]);
   dst += (size_t)blockIdx.y * dst_js;
@@ -131,10 +131,13 @@ k_to_hat_fused(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, siz
   for (int l = 0; l < nlimbs; l++) {
     const LimbTable* tab = tabs + l;
     uint32_t x[D];
-    if (tab->p > (1u << 29)) {
+    if (in_bound <= tab->p) {            // the caller vouches for coefficients below in_bound (decomposition digits): nothing to reduce
+#pragma unroll
+      for (int k = 0; k < D; k++) x[k] = clo[k];
+    } else if (tab->p > (1u << 29)) {
 #pragma unroll
       for (int k = 0; k < D; k++) x[k] = reduce_u40(((uint64_t)((chi[k / 4] >> (8 * (k & 3))) & 0xFFu) << 32) | clo[k], *tab);
-    } else {   // the small limb of the digit basis (p < 2^16)
+    } else {   // a digit-basis limb below 2^23 (the u16 limb, the matrix-core basis), or q itself as the only prime (v < p)
       const uint32_t p = tab->p, m = (uint32_t)(4294967296.0 * tab->inv_p) - 1, r1 = tab->r1;
 #pragma unroll
       for (int k = 0; k < D; k++) x[k] = reduce_small16((chi[k / 4] >> (8 * (k & 3))) & 0xFFu, clo[k], p, m, r1);
@@ -145,10 +148,10 @@ k_to_hat_fused(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, siz
 }
 
 hipError_t launch_to_hat_fused(const JobPtrs& coeffs, HatView dst, size_t dst_js, size_t count, int nlimbs, const LimbTable* tabs,
-                               size_t njobs, hipStream_t s) {
+                               size_t njobs, hipStream_t s, uint64_t in_bound) {
   if (count == 0 || njobs == 0) return hipSuccess;
   hipLaunchKernelGGL(k_to_hat_fused, dim3((unsigned)((count + 63) / 64), (unsigned)njobs), dim3(64), 0, s, coeffs, dst.base,
-                     dst.plane_stride, dst_js, count, nlimbs, tabs);
+                     dst.plane_stride, dst_js, count, nlimbs, tabs, in_bound);
   return hipGetLastError();
 }
 

@@ -49,15 +49,21 @@ class RuntimeConstants:
 class ResidentCRS:
     """A, B_ik, C_ijk, D_ijk as transform-domain device matrices (stand-in for CRS::fetch_*, src/structs.rs:55-144)."""
 
-    def __init__(self, ctx, constants, compact=False):
+    def __init__(self, ctx, constants, compact=False, mfma_basis=False):
         """compact=True keeps B, C, D in the context's digit basis with the small limb as u16 (they are only ever
         multiplied by decomposition digits < B_1, B_2): fewer bytes per coefficient on the HBM-bound kernel.
-        Falls back to the main basis when no smaller basis exists (q its own NTT prime)."""
+        Falls back to the main basis when no smaller basis exists (q its own NTT prime).
+        mfma_basis=True keeps them in the digit basis made for the matrix cores instead (primes below 2^23: three byte
+        planes per residue once packed by pack_mfma)."""
         k = constants
         pairs = k.R * (k.R + 1) // 2
         self.ctx, self.constants = ctx, k
         self.compact = False
-        if compact and ctx.nlimbs > 1:
+        if mfma_basis:
+            if not getattr(ctx, "digit_primes", None):
+                ctx.enable_digit_basis(k.R * k.T_1 * k.KAPPA + pairs * max(k.T_1, k.T_2), max(k.B_1, k.B_2), mfma=True)
+            self.compact = True
+        elif compact and ctx.nlimbs > 1:
             if not getattr(ctx, "digit_primes", None):
                 try:
                     ctx.enable_digit_basis(k.R * k.T_1 * k.KAPPA + pairs * max(k.T_1, k.T_2), max(k.B_1, k.B_2))

@@ -359,6 +359,39 @@ def test_matvec_sum_mfma_digit_basis(ns, nmat, rows, cols, compact):
     ctx.close()
 
 
+@pytest.mark.parametrize("ns", [8, 16, 32, 64])
+@pytest.mark.parametrize("nmat,rows,cols", [(3, 40, 37), (2, 64, 64), (1, 100, 200), (5, 31, 7)])
+def test_matvec_sum_mfma_three_plane_basis(ns, nmat, rows, cols):
+    # the digit basis made for the matrix cores: primes below 2^23, residues as three signed byte planes, GEMM blocks of
+    # 3 (one row tile) or 6 waves, 1/2/3/6 column tiles; bit-identical to lab_matvec_sum and the oracle
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    q = Q_REF33
+    ctx = lab.Context(q, 0)
+    bound = 1625
+    primes, small, nbytes = ctx.enable_digit_basis(5000, bound, mfma=True)
+    assert not small and all(pr < (1 << 23) - 0x8080 and pr % 128 == 1 for pr in primes) and nbytes == 4 * len(primes)
+    rng = np.random.default_rng(ns + rows)
+    M = rp(rng, q, nmat, rows, cols)
+    V = rng.integers(0, bound, size=(ns, nmat, cols, D), dtype=np.uint64)
+    M[0, :2] = q - 1
+    V[ns - 1] = bound - 1
+    hM = ctx.vec(nmat * rows * cols, digit=True).load(M)
+    hV = ctx.vec(ns * nmat * cols, digit=True).load(V)
+    M8 = lab.Mat8(ctx, hM, nmat, rows, cols)
+    got = lab.matvec_sum_mfma(ctx, M8, hV, ns).store().reshape(ns, rows, D)
+    for b in range(ns):
+        one = lab.matvec_sum(ctx, hM, hV, nmat, rows, cols, v_off=b * nmat * cols).store()
+        assert np.array_equal(got[b], one), (b,)
+    for b, r_ in ((0, 0), (ns - 1, rows - 1)):
+        want = np.zeros(D, np.uint64)
+        for m in range(nmat):
+            want = co.poly_add(q, want, co.inner_product(q, M[m, r_], V[b, m]))
+        assert np.array_equal(got[b, r_], want)
+    M8.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("q", ALL_Q)
 def test_matvec_sum_mfma_main_basis_full_residues(contexts, q):
     # operands in the context's main basis with full-range residues (every byte value, -128 included, occurs in the

@@ -211,7 +211,7 @@ def test_prove_core_batch_equals_separate_proofs(nb, kappa1, compact):
 
 
 @pytest.mark.parametrize("nb,kappa1", [(1, 20), (5, 20), (9, 64), (20, 40), (33, 20), (64, 20), (66, 20)])
-@pytest.mark.parametrize("compact", [False, True])
+@pytest.mark.parametrize("compact", [False, True, "mfma23"])
 def test_prove_core_batch_on_matrix_cores(nb, kappa1, compact):
     # step 3 as exact int8 GEMMs (B packed with lab_mat8_pack, up to 32 proofs per pass, groups padded to 8/16/32
     # sets): transcripts bit-identical to the VALU path and the oracle; B itself can be dropped afterwards
@@ -220,7 +220,10 @@ def test_prove_core_batch_on_matrix_cores(nb, kappa1, compact):
     ctx = lab.Context(q, 0)
     p = cases.Params(q, n, r, kappa, kappa1)
     k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
-    crs = lab.ResidentCRS(ctx, k, compact=compact).fill_synthetic(1000)
+    # "mfma23": B, C, D in the digit basis of primes below 2^23 (three byte planes, 3- and 6-wave GEMM blocks)
+    crs = lab.ResidentCRS(ctx, k, compact=compact is True, mfma_basis=compact == "mfma23").fill_synthetic(1000)
+    if compact == "mfma23":
+        assert all(pr < (1 << 23) for pr in ctx.digit_primes) and not ctx.digit_small
     ws, sts, tapes = [], [], []
     want0 = None
     for j in range(nb):
@@ -260,8 +263,9 @@ def test_verifier_needs_the_unpacked_B():
     ctx.close()
 
 
+@pytest.mark.parametrize("mfma_basis", [False, True])
 @pytest.mark.parametrize("nb", [2, 4, 5])
-def test_prove_core_batch_matrix_cores_r32(nb):
+def test_prove_core_batch_matrix_cores_r32(nb, mfma_basis):
     # r = 32 witness columns: the Ajtai product of an even number of proofs multiplies two proofs as one 64-set job
     # (paired jobs), an odd number keeps one 32-set job per proof; both equal the multiply-add path and the oracle
     import labrador_snark_amd as lab
@@ -269,7 +273,7 @@ def test_prove_core_batch_matrix_cores_r32(nb):
     ctx = lab.Context(q, 0)
     p = cases.Params(q, n, r, kappa, kappa1)
     k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
-    crs = lab.ResidentCRS(ctx, k, compact=True).fill_synthetic(1000)
+    crs = lab.ResidentCRS(ctx, k, compact=True, mfma_basis=mfma_basis).fill_synthetic(1000)
     ws, sts, tapes = [], [], []
     want_last = None
     for j in range(nb):
