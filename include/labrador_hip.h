@@ -103,6 +103,9 @@ int lab_ctx_profile_begin(lab_ctx *ctx);
 int lab_ctx_profile_end(lab_ctx *ctx, double *kernel_ms, uint64_t *launches, double *algorithmic_bytes);
 /* name (template arguments included) of the kernel the most recent launch timed by the hook was dispatched to */
 const char *lab_ctx_profile_kernel(const lab_ctx *ctx);
+/* how the most recent lab_prove_core[_batch] call ran: 1 = step 1 in the digit basis (lab_prove_input.A8d), 2 = that was tried,
+ * a witness exceeded beta_bound and the batch was redone in the main basis; 0 = main basis from the start */
+int lab_ctx_prove_flags(const lab_ctx *ctx);
 
 /* Digit basis (no reference counterpart; a storage/bandwidth optimisation).  The outer commitments multiply CRS
  * matrices by decomposition DIGITS (< b_1, b_2 ~ 2^11, src/util.rs:389-442), so their exact integer results need
@@ -282,6 +285,12 @@ typedef struct {
   const struct lab_mat8 *A8; /* optional: lab_mat8_pack(A, a_off, 1, kappa, n): step 1 (t_i = A s_i) as int8 GEMMs */
   const struct lab_mat8 *C8; /* optional: lab_mat8_pack(C, c_off, pairs*t2, kappa2, 1): step 4 (sum g^(k) C) as int8 GEMMs */
   const struct lab_mat8 *D8; /* optional: lab_mat8_pack(Dm, d_off, pairs*t1, kappa2, 1): step 9 (sum h^(k) D) likewise */
+  const struct lab_mat8 *A8d; /* optional: A packed from a copy in the digit basis of B, C, D (same kappa x n elements).  Step 1 of
+                               * a batch then runs in that basis whenever sqrt(64 n) (q-1) beta_bound is inside its CRT range
+                               * (|A s| <= |A|_2 |s|_2): with the matrix-core basis 9 instead of 16 byte products per modular
+                               * product.  The pass that transforms S also sums its squared norm; a witness above beta_bound
+                               * (never produced by generate_witness, src/proofgen.rs:460-518) makes the call redo the batch
+                               * in the main basis, so results never depend on this field */
 } lab_prove_input;
 
 /* The computed fields of `Transcript` (src/structs.rs:192-209); pi_i_all, psi, omega, alpha, beta, c are the tape.

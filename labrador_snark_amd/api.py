@@ -104,6 +104,10 @@ class Context:
         self.digit_primes, self.digit_small = primes, small
         return primes, small, (4 * (len(primes) - 1) + 2 if small else 4 * len(primes))
 
+    def prove_flags(self):
+        """How the last prove_core[_batch] ran: 1 = step 1 in the digit basis, 2 = tried and redone in the main basis, 0 = main basis."""
+        return int(self._lib.lab_ctx_prove_flags(self._h))
+
     def profile_begin(self):
         """Start bracketing every launch of the streaming mat-vec kernel with HIP events on the context's stream."""
         self._check(self._lib.lab_ctx_profile_begin(self._h))

@@ -380,6 +380,8 @@ extern "C" const char* lab_ctx_profile_kernel(const lab_ctx* c) {
   return c ? c->prof_kernel : "";
 }
 
+extern "C" int lab_ctx_prove_flags(const lab_ctx* c) { return c ? c->prove_flags : 0; }
+
 extern "C" int lab_ctx_profile_end(lab_ctx* c, double* kernel_ms, uint64_t* launches, double* algorithmic_bytes) {
   if (!c) return LAB_ERR_ARG;
   LAB_HIP(c, hipStreamSynchronize(c->stream));

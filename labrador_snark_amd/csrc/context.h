@@ -46,6 +46,7 @@ struct lab_ctx {
   size_t prof_used = 0;
   double prof_bytes = 0.0;
   const char* prof_kernel = "";   // kernel the last profiled mat-vec launch was dispatched to
+  int prove_flags = 0;            // last lab_prove_core[_batch]: 1 = step 1 ran in the digit basis, 2 = tried and redone in the main basis
 };
 
 struct lab_vec {

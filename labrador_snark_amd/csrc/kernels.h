@@ -58,7 +58,8 @@ hipError_t launch_reduce_u64_jobs(const JobPtrs& coeffs, HatView dst, size_t dst
                                   const LimbTable* tabs, size_t njobs, hipStream_t s);
 // reduce + forward NTT in one pass (to_hat), njobs polynomials vectors at once
 hipError_t launch_to_hat_fused(const JobPtrs& coeffs, HatView dst, size_t dst_js, size_t count, int nlimbs, const LimbTable* tabs,
-                               size_t njobs, hipStream_t s, uint64_t in_bound = ~0ull /* coefficients are below this */);
+                               size_t njobs, hipStream_t s, uint64_t in_bound = ~0ull /* coefficients are below this */,
+                               unsigned long long* norm_sum = nullptr /* [njobs], += saturating sum of squares */, uint64_t norm_limit = 0);
 hipError_t launch_crt_to_u64(ConstHatView src, uint64_t* coeffs, size_t count, const CrtTable* crt, int nlimbs, hipStream_t s);
 hipError_t launch_crt_to_u64_jobs(ConstHatView src, size_t src_js, const JobPtrs& coeffs, size_t count, const CrtTable* crt,
                                   int nlimbs, size_t njobs, hipStream_t s);

@@ -7,6 +7,7 @@
 #include "kernels.h"
 
 namespace lab {
+typedef unsigned __int128 u128;
 
 // One polynomial per thread, one wave per block: the wave's 64 polynomials
 // (16 KiB) are fetched with 16-byte coalesced loads, transposed through LDS,
@@ -88,9 +89,15 @@ __device__ __forceinline__ uint32_t reduce_small16(uint32_t hi8, uint32_t lo, ui
 // coefficients through the LDS tile (lane l, iteration i fetches the 16-byte piece i*64 + l of the half: polynomial
 // (i*64 + l) / 16, piece % 16 — 256 B contiguous per polynomial), are read back transposed (row pitch 68 words:
 // conflict-free) and stay in registers while each limb is reduced, transformed and stored.
+// NORM: the pass also adds the squared Euclidean norm of the job's coefficients (raw residues, like poly_norm,
+// src/util.rs:195-202) to norm_sum[job] — saturating: a polynomial with a coefficient above norm_vmax or a partial sum
+// above norm_limit counts as norm_limit + 1, so the total exceeds norm_limit exactly when the true norm does and never
+// overflows ((blocks + 1) * (norm_limit + 1) < 2^64 is the caller's business).
+template <bool NORM>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_to_hat_fused(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, size_t dst_js, size_t count, int nlimbs,
-               const LimbTable* __restrict__ tabs, uint64_t in_bound) {
+               const LimbTable* __restrict__ tabs, uint64_t in_bound, unsigned long long* __restrict__ norm_sum,
+               uint64_t norm_limit, uint32_t norm_vmax) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[TILE_WORDS];
   const uint64_t* __restrict__ coeffs = static_cast<const uint64_t*>(src.p[blockIdx.y]);
   dst += (size_t)blockIdx.y * dst_js;
@@ -127,6 +134,21 @@ k_to_hat_fused(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, siz
     }
     __syncthreads();
   }
+  if constexpr (NORM) {
+    uint64_t ss = 0;
+    bool over = false;
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+      over = over || clo[k] > norm_vmax;
+      ss += (uint64_t)clo[k] * clo[k];               // clo <= norm_vmax < 2^24 when it counts: 64 terms < 2^54
+    }
+#pragma unroll
+    for (int k = 0; k < D / 4; k++) over = over || chi[k] != 0;
+    if (over || ss > norm_limit) ss = norm_limit + 1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off);   // <= 64 * (2^48 + 1)
+    if (lane == 0) atomicAdd(&norm_sum[blockIdx.y], ss > norm_limit ? norm_limit + 1 : ss);
+  }
 #pragma unroll 1
   for (int l = 0; l < nlimbs; l++) {
     const LimbTable* tab = tabs + l;
@@ -134,6 +156,10 @@ k_to_hat_fused(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, siz
     if (in_bound <= tab->p) {            // the caller vouches for coefficients below in_bound (decomposition digits): nothing to reduce
 #pragma unroll
       for (int k = 0; k < D; k++) x[k] = clo[k];
+    } else if (in_bound <= 4ull * tab->p) {   // ... or only a little above p (a witness within its norm bound)
+      const uint32_t p = tab->p;
+#pragma unroll
+      for (int k = 0; k < D; k++) x[k] = csub(csub(clo[k], 2 * p), p);
     } else if (tab->p > (1u << 29)) {
 #pragma unroll
       for (int k = 0; k < D; k++) x[k] = reduce_u40(((uint64_t)((chi[k / 4] >> (8 * (k & 3))) & 0xFFu) << 32) | clo[k], *tab);
@@ -148,10 +174,21 @@ k_to_hat_fused(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, siz
 }
 
 hipError_t launch_to_hat_fused(const JobPtrs& coeffs, HatView dst, size_t dst_js, size_t count, int nlimbs, const LimbTable* tabs,
-                               size_t njobs, hipStream_t s, uint64_t in_bound) {
+                               size_t njobs, hipStream_t s, uint64_t in_bound, unsigned long long* norm_sum, uint64_t norm_limit) {
   if (count == 0 || njobs == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_to_hat_fused, dim3((unsigned)((count + 63) / 64), (unsigned)njobs), dim3(64), 0, s, coeffs, dst.base,
-                     dst.plane_stride, dst_js, count, nlimbs, tabs, in_bound);
+  const dim3 g((unsigned)((count + 63) / 64), (unsigned)njobs);
+  if (norm_sum) {
+    // exactness of the saturating sum: coefficients that count are <= floor(sqrt(norm_limit)) < 2^24
+    if (norm_limit >= (1ull << 48) || (u128)(g.x + 1) * (norm_limit + 1) >= ((u128)1 << 64)) return hipErrorInvalidValue;
+    uint32_t vmax = (uint32_t)sqrt((double)norm_limit);
+    while ((uint64_t)vmax * vmax > norm_limit) vmax--;
+    while ((uint64_t)(vmax + 1) * (vmax + 1) <= norm_limit) vmax++;
+    hipLaunchKernelGGL(k_to_hat_fused<true>, g, dim3(64), 0, s, coeffs, dst.base, dst.plane_stride, dst_js, count, nlimbs, tabs,
+                       in_bound, norm_sum, norm_limit, vmax);
+  } else {
+    hipLaunchKernelGGL(k_to_hat_fused<false>, g, dim3(64), 0, s, coeffs, dst.base, dst.plane_stride, dst_js, count, nlimbs, tabs,
+                       in_bound, nullptr, (uint64_t)0, (uint32_t)0);
+  }
   return hipGetLastError();
 }
 
@@ -199,8 +236,8 @@ __device__ __forceinline__ uint64_t crt_one(const uint32_t (&r)[L], const CrtTab
     uint32_t t = r[a];
 #pragma unroll
     for (int b = 0; b < a; b++) {
-      // digits of the other limbs are < 2^30: below 2p for the 30-bit primes, anything for a small last prime
-      const uint32_t db = p > (1u << 29) ? csub(d[b], p) : (uint32_t)mod_u64_near(d[b], p, crt->inv_p[a]);
+      // a digit of limb b is below p_b: one conditional subtraction when p_b < 2p (primes of one size), else a full reduction
+      const uint32_t db = crt->p[b] < 2 * p ? csub(d[b], p) : (uint32_t)mod_u64_near(d[b], p, crt->inv_p[a]);
       const uint32_t diff = t >= db ? t - db : t + p - db;
       t = csub(mul_shoup_lazy(diff, crt->ginv[a][b][0], crt->ginv[a][b][1], p), p);
     }

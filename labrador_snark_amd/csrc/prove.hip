@@ -62,7 +62,8 @@ struct Job {  // device pointers of one proof of the batch
 // Prover::proof_gen for `np` independent proofs that share one common reference string.  Per-proof work is issued
 // proof by proof; the outer commitment (step 3), whose cost is streaming the CRS matrices B_ik from HBM, is issued
 // once per group of up to 8 proofs with the multi-set mat-vec, so B is read once per group instead of once per proof.
-static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const* ins, lab_transcript* const* outs, int* status) {
+static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const* ins, lab_transcript* const* outs, int* status,
+                            bool allow_digit_ajtai = true) {
   if (!c) return LAB_ERR_ARG;
   if (np == 0) return LAB_OK;
   PtrCacheScope ptr_cache;   // every boundary pointer is classified host/device once per call
@@ -73,7 +74,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     int first = LAB_OK;
     for (size_t j0 = 0; j0 < np; j0 += MAX_JOBS) {
       const size_t m = np - j0 < (size_t)MAX_JOBS ? np - j0 : (size_t)MAX_JOBS;
-      const int e = prove_batch_impl(c, m, ins + j0, outs + j0, status ? status + j0 : nullptr);
+      const int e = prove_batch_impl(c, m, ins + j0, outs + j0, status ? status + j0 : nullptr, allow_digit_ajtai);
       if (e != LAB_OK && first == LAB_OK) first = e;
       if (e != LAB_OK && e != LAB_ERR_JL_REJECTED && e != LAB_ERR_BPP_CHECK) return e;
     }
@@ -92,7 +93,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     if (!x->S || !x->phi || !x->a || !x->Pi || !x->omega || !x->alpha || !x->beta || !x->c)
       return fail(c, LAB_ERR_ARG, "lab_prove_core: null input array");
     if (x->n != n || x->r != r || x->kappa != kappa || x->kappa1 != k1 || x->kappa2 != k2 || x->t1 != t1 || x->t2 != t2 ||
-        x->b1 != in->b1 || x->b2 != in->b2 || x->beta_bound != in->beta_bound || x->A != in->A || x->B != in->B || x->B8 != in->B8 || x->A8 != in->A8 || x->C8 != in->C8 || x->D8 != in->D8 ||
+        x->b1 != in->b1 || x->b2 != in->b2 || x->beta_bound != in->beta_bound || x->A != in->A || x->B != in->B || x->B8 != in->B8 || x->A8 != in->A8 || x->C8 != in->C8 || x->D8 != in->D8 || x->A8d != in->A8d ||
         x->C != in->C || x->Dm != in->Dm || x->a_off != in->a_off || x->b_off != in->b_off || x->c_off != in->c_off ||
         x->d_off != in->d_off)
       return fail(c, LAB_ERR_ARG, "lab_prove_core_batch: all proofs of a batch must share dimensions, constants and the CRS");
@@ -113,6 +114,24 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   const lab_mat8* a8 = in->A8;
   if (a8 && !mat8_matches(a8, 0, 1, kappa, n))
     return fail(c, LAB_ERR_ARG, "lab_prove_core: A8 was not packed from the kappa x n matrix A in the main basis");
+  // Step 1 in the basis of B, C, D (lab_prove_input.A8d): |<A row, s_i>| <= |A row|_2 |s_i|_2 <= sqrt(64 n) (q-1) beta_bound must
+  // lie inside that basis' CRT range; the witness norm is summed (saturating, exact) by the pass that transforms S and
+  // checked at the end of the call — a witness above beta_bound makes the call start over without this shortcut.
+  const lab_mat8* a8d = allow_digit_ajtai ? in->A8d : nullptr;
+  uint64_t norm_limit = 0;
+  if (in->A8d && (!bdig || !mat8_matches(in->A8d, bdig, 1, kappa, n)))
+    return fail(c, LAB_ERR_ARG, "lab_prove_core: A8d was not packed from the kappa x n matrix A in the basis of B, C, D");
+  if (a8d) {
+    long double M = 1.0L;
+    for (int l = 0; l < c->dg_nlimbs; l++) M *= (long double)c->dg_primes[l];
+    const long double need = sqrtl((long double)n * D) * (long double)(c->q - 1) * (long double)in->beta_bound * 1.0001L;
+    const size_t blocks = (nr + 63) / 64 + 1;
+    if (in->beta_bound <= 0 || in->beta_bound >= (int64_t)1 << 24 || need >= M / 2 ||
+        (u128)blocks * ((u128)in->beta_bound * in->beta_bound + 1) >= ((u128)1 << 64))
+      a8d = nullptr;
+    else
+      norm_limit = (uint64_t)in->beta_bound * (uint64_t)in->beta_bound;
+  }
   // C and D packed the same way: element (rho, m) of the "matrix" is C[m][rho], i.e. pairs*t matrices of kappa2 x 1
   const lab_mat8 *c8 = in->C8, *d8 = in->D8;
   if ((c8 && !mat8_matches(c8, bdig, pairs * (size_t)t2, k2, 1)) || (d8 && !mat8_matches(d8, bdig, pairs * (size_t)t1, k2, 1)))
@@ -152,6 +171,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if (axpy_partial_elems(pairs * t2, k2) > partd_elems) partd_elems = axpy_partial_elems(pairs * t2, k2);
   if (axpy_partial_elems(pairs * t1, k2) > partd_elems) partd_elems = axpy_partial_elems(pairs * t1, k2);
   const size_t hpartd = hd.take(partd_elems);
+  const size_t hSd = a8d ? hd.take(nr) : 0, hTd = a8d ? hd.take(rk) : 0;   // witness and t = A s in the digit basis
   const int Ld = basis_nlimbs(c, bdig);
   const LimbTable* tabsd = basis_tabs(c, bdig);
   const size_t per = ha.total, perd = hd.total;
@@ -179,6 +199,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   size_t mf_bytes = b8 ? mfma_scratch_bytes(b8, mf_ns, 1) + 4096 : 0;
   const int a8_ns = r <= 8 ? 8 : r <= 16 ? 16 : 32;       // witness columns per Ajtai GEMM pass
   if (a8 && mfma_scratch_bytes(a8, a8_ns, np) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(a8, a8_ns, np) + 4096;
+  if (a8d && mfma_scratch_bytes(a8d, a8_ns, np) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(a8d, a8_ns, np) + 4096;
   if (c8 && mfma_scratch_bytes(c8, mf_ns, 1) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(c8, mf_ns, 1) + 4096;
   if (d8 && mfma_scratch_bytes(d8, mf_ns, 1) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(d8, mf_ns, 1) + 4096;
   bytes += mf_bytes;
@@ -196,7 +217,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   auto OUT = [&](uint64_t* user, size_t elems) { return (user && is_device_pointer(user)) ? user : CO(elems); };
   std::vector<Job> jobs(np);
   // [np][256] integer projections | [np][256] omega | [np][64] b'': contiguous, so the host-side checks need ONE copy
-  uint64_t* host_stage = cv.take<uint64_t>(np * (256 + 256 + D));
+  uint64_t* host_stage = cv.take<uint64_t>(np * (256 + 256 + D + 1));   // ... | [np] squared witness norms (digit-basis step 1)
   int64_t* proj_all = reinterpret_cast<int64_t*>(host_stage);
   Staging st(c, &cv);  // inputs only (no pending outputs are registered on it)
   for (size_t j = 0; j < np; j++) {
@@ -276,7 +297,18 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if ((rc = to_hat_jobs(JP(&Job::dc), hc, r, false))) return rc;
   // ================= step 1 (src/proofgen.rs:41-49): t_i = A s_i for every column of every proof; A is shared, so the
   // whole batch is one (kappa x n)(n x np*r) product (falls back to one launch per proof for shapes it does not take)
-  if (a8) {   // matrix cores: per proof, its r witness columns as the vector sets (element x of column i at S[x][i])
+  uint64_t* norm_sums = host_stage + np * (256 + 256 + D);
+  if (a8d) {  // matrix cores, in the basis of B, C, D (see a8d above): S once more into that basis, its norm summed on the way
+    LAB_HIP(c, hipMemsetAsync(norm_sums, 0, np * 8, s));
+    // (coefficients above beta_bound are caught by the norm sum and the batch is redone: the transform may assume the bound)
+    LAB_HIP(c, launch_to_hat_fused(JP(&Job::dS), HD(0, hSd), jsd, nr, Ld, tabsd, np, s, (uint64_t)in->beta_bound + 1,
+                                   reinterpret_cast<unsigned long long*>(norm_sums), norm_limit));
+    for (size_t i0 = 0; i0 < r; i0 += 32) {
+      const int valid = (int)(r - i0 < 32 ? r - i0 : 32);
+      if ((rc = matvec_mfma_impl(c, HD(0, hTd + i0 * kappa), kappa * D, a8d, HD(0, hSd + i0), D, a8_ns, valid, mf_scratch, r * D, np,
+                                 perd * D, perd * D))) return rc;
+    }
+  } else if (a8) {   // matrix cores: per proof, its r witness columns as the vector sets (element x of column i at S[x][i])
     // one launch per limb and 32 columns: the proofs are the kernel's jobs and share the A stream through L2
     for (size_t i0 = 0; i0 < r; i0 += 32) {
       const int valid = (int)(r - i0 < 32 ? r - i0 : 32);
@@ -293,7 +325,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
       LAB_HIP(c, e);
     }
   }
-  if ((rc = from_hat_jobs(hT, rk, JP(&Job::cT), false))) return rc;
+  if ((rc = a8d ? from_hat_jobs(hTd, rk, JP(&Job::cT), true) : from_hat_jobs(hT, rk, JP(&Job::cT), false))) return rc;
   // step 2 (:59-70): G = S^T S
   if ((rc = gram_jobs(hG, hS, hS))) return rc;
   if ((rc = from_hat_jobs(hG, rr, JP(&Job::cG), false))) return rc;
@@ -409,7 +441,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if ((rc = from_hat_jobs(hz, n, JP(&Job::cz), false))) return rc;
 
   // ================= copy-out and the two verifier callbacks that can reject
-  std::vector<uint64_t> hst(np * (256 + 256 + D));
+  std::vector<uint64_t> hst(np * (256 + 256 + D + 1));
   const int64_t* hproj = reinterpret_cast<const int64_t*>(hst.data());
   const uint64_t* homega = hst.data() + np * 256;
   const uint64_t* hbpp_st = hst.data() + np * 512;
@@ -436,6 +468,17 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   }
   LAB_HIP(c, hipMemcpyAsync(hst.data(), host_stage, hst.size() * 8, hipMemcpyDeviceToHost, s));
   LAB_HIP(c, hipStreamSynchronize(s));
+  if (a8d) {   // a witness above the declared norm bound: step 1 may have left the CRT range; redo the batch in the main basis
+    const uint64_t* hnorm = hst.data() + np * (256 + 256 + D);
+    bool over = false;
+    for (size_t j = 0; j < np; j++) over = over || hnorm[j] > norm_limit;
+    if (over) {
+      const int e = prove_batch_impl(c, np, ins, outs, status, false);
+      c->prove_flags |= 2;
+      return e;
+    }
+  }
+  c->prove_flags = a8d ? 1 : 0;
   for (size_t j = 0; j < np; j++) {
     void* u = outs[j]->projection_int;
     if (u && !is_device_pointer(u)) memcpy(u, hproj + j * 256, 256 * 8);

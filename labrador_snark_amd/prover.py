@@ -99,6 +99,17 @@ class ResidentCRS:
         pairs = k.R * (k.R + 1) // 2
         self.C8 = Mat8(self.ctx, self.C, pairs * k.T_2, k.KAPPA_2, 1)      # element (rho, m) = C[m][rho]
         self.D8 = Mat8(self.ctx, self.Dm, pairs * k.T_1, k.KAPPA_2, 1)
+        if self.compact and not self.ctx.digit_small and all(p < (1 << 23) for p in self.ctx.digit_primes):
+            # matrix-core digit basis: A once more in that basis (3 byte planes); step 1 of a batch runs there whenever the
+            # witness norm bound keeps |A s| inside its CRT range (lab_prove_input.A8d)
+            Ad = HatVec(self.ctx, k.KAPPA * k.N, digit=True)
+            step = 1 << 15
+            for off in range(0, k.KAPPA * k.N, step):
+                cnt = min(step, k.KAPPA * k.N - off)
+                Ad.load(self.A.store(off, cnt), off)
+            self.A8d = Mat8(self.ctx, Ad, 1, k.KAPPA, k.N)
+            self.ctx.synchronize()
+            Ad.close()
         if drop_B:
             self.ctx.synchronize()
             self.B.close()
@@ -107,7 +118,7 @@ class ResidentCRS:
 
     def close(self):
         for v in (self.A, self.B, self.C, self.Dm, getattr(self, "B8", None), getattr(self, "A8", None),
-                  getattr(self, "C8", None), getattr(self, "D8", None)):
+                  getattr(self, "C8", None), getattr(self, "D8", None), getattr(self, "A8d", None)):
             if v is not None:
                 v.close()
 
@@ -251,7 +262,7 @@ def _io_template(k, crs):
     pin.n, pin.r, pin.kappa, pin.kappa1, pin.kappa2 = k.N, k.R, k.KAPPA, k.KAPPA_1, k.KAPPA_2
     pin.b1, pin.b2, pin.t1, pin.t2, pin.beta_bound = k.B_1, k.B_2, k.T_1, k.T_2, k.BETA_BOUND
     pin.A, pin.B, pin.C, pin.Dm = crs.A._h, (crs.B._h if crs.B is not None else None), crs.C._h, crs.Dm._h
-    for name in ("B8", "A8", "C8", "D8"):
+    for name in ("B8", "A8", "C8", "D8", "A8d"):
         m = getattr(crs, name, None)
         setattr(pin, name, m._h if m is not None else None)
     pin.a_off = pin.b_off = pin.c_off = pin.d_off = 0
@@ -365,6 +376,7 @@ def verify_core(ctx, k, st, b_poly, crs, T, tape=None):
     pin.A8 = crs.A8._h if getattr(crs, "A8", None) is not None else None
     pin.C8 = crs.C8._h if getattr(crs, "C8", None) is not None else None
     pin.D8 = crs.D8._h if getattr(crs, "D8", None) is not None else None
+    pin.A8d = crs.A8d._h if getattr(crs, "A8d", None) is not None else None
     pin.a_off = pin.b_off = pin.c_off = pin.d_off = 0
     Pi = tape["Pi"]
     if isinstance(Pi, np.ndarray):

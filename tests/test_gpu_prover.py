@@ -243,6 +243,44 @@ def test_prove_core_batch_on_matrix_cores(nb, kappa1, compact):
     ctx.close()
 
 
+def test_digit_basis_ajtai_and_its_fallback():
+    # with the matrix-core digit basis step 1 (t = A s) runs in that basis as long as the witness keeps its norm bound
+    # (checked on the device by the pass that transforms S); a witness above beta_bound makes the call redo the batch in
+    # the main basis — either way every transcript equals the multiply-add path's
+    import labrador_snark_amd as lab
+    q, n, r, kappa, kappa1 = Q_REF33, 4, 8, 64, 20
+    ctx = lab.Context(q, 0)
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
+    crs = lab.ResidentCRS(ctx, k, mfma_basis=True).fill_synthetic(1000)
+    ws, sts, tapes = [], [], []
+    for j in range(3):
+        case, (S, phi, a, tape) = cases.oracle_case(p, seed=900 + j)
+        ws.append(S); sts.append(lab.State(phi, a, case.b_prime)); tapes.append(tape)
+    ref, _ = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes, raise_on_reject=False)
+    assert ctx.prove_flags() == 0
+    crs.pack_mfma()
+    assert crs.A8d.nbytes > 0
+    got, _ = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes, raise_on_reject=False)
+    assert ctx.prove_flags() == 1
+    for j in range(3):
+        for f in ("t_i_all", "g_mat", "h_mat", "u_1", "u_2", "z", "b_prime_prime", "projection_int"):
+            assert np.array_equal(getattr(got[j], f), getattr(ref[j], f)), (j, f)
+    # one coefficient of proof 1's witness far above beta_bound: |A s| no longer fits the digit basis
+    big = [w.copy() for w in ws]
+    big[1][2, 3, 5] = q - 1
+    bad = [sts[0], lab.State(sts[1].phi, sts[1].a, 0), sts[2]]
+    crs_plain = lab.ResidentCRS(ctx, k, mfma_basis=True).fill_synthetic(1000)
+    ref2, codes_ref = lab.prove_core_batch(ctx, k, big, bad, crs_plain, tapes, raise_on_reject=False)
+    got2, codes = lab.prove_core_batch(ctx, k, big, bad, crs, tapes, raise_on_reject=False)
+    assert ctx.prove_flags() == 2 and list(codes) == list(codes_ref)
+    for j in range(3):
+        for f in ("t_i_all", "g_mat", "h_mat", "u_1", "u_2", "z"):
+            assert np.array_equal(getattr(got2[j], f), getattr(ref2[j], f)), (j, f)
+    crs.close(); crs_plain.close()
+    ctx.close()
+
+
 def test_verifier_needs_the_unpacked_B():
     # a prover-only process may drop B after packing it for the matrix cores; lab_verify_core then refuses cleanly
     import labrador_snark_amd as lab
