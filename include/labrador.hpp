@@ -40,6 +40,10 @@ class Context {  // stands for the lazy statics Q and PLAN (src/constants.rs:193
   lab_ctx* handle() const { return h_; }
   uint64_t q() const { return info_.q; }
   int nlimbs() const { return info_.nlimbs; }
+  // second RNS basis for B, C, D (and a copy of A): primes below 2^23, three byte planes per residue on the matrix cores
+  void enable_matrix_core_basis(uint64_t max_terms, uint64_t digit_bound) const {
+    check(lab_ctx_enable_digit_basis_mfma(h_, max_terms, digit_bound));
+  }
   void check(int rc) const {
     if (rc == LAB_OK) return;
     std::string msg = lab_last_error(h_);
@@ -55,6 +59,10 @@ class Context {  // stands for the lazy statics Q and PLAN (src/constants.rs:193
 class HatVec {  // device-resident ring elements in the transform domain
  public:
   HatVec(const Context& c, size_t count) : c_(c), count_(count) { c_.check(lab_vec_create(c_.handle(), count, &h_)); }
+  // in the context's digit basis (Context::enable_matrix_core_basis)
+  HatVec(const Context& c, size_t count, bool digit) : c_(c), count_(count) {
+    c_.check(digit ? lab_vec_create_digit(c_.handle(), count, 0, &h_) : lab_vec_create(c_.handle(), count, &h_));
+  }
   HatVec(const Context& c, const std::vector<Rq>& v) : HatVec(c, v.size()) {
     c_.check(lab_vec_load_u64(c_.handle(), h_, 0, v.empty() ? nullptr : v[0].data(), v.size()));
   }
@@ -211,16 +219,36 @@ class PackedMatrix {
 
 struct ResidentCRS {  // A, B_ik, C_ijk, D_ijk in the transform domain (stand-in for CRS::fetch_*, src/structs.rs:55-144)
   HatVec A, B, C, Dm;
-  PackedMatrix A8, B8, C8, D8;   // optional (pack_mfma): the CRS-streaming steps of a batch then run on the matrix cores
-  ResidentCRS(const Context& c, const RuntimeConstants& k)
-      : A(c, k.KAPPA * k.N), B(c, k.R * (size_t)k.T_1 * k.KAPPA_1 * k.KAPPA), C(c, k.R * (k.R + 1) / 2 * (size_t)k.T_2 * k.KAPPA_2),
-        Dm(c, k.R * (k.R + 1) / 2 * (size_t)k.T_1 * k.KAPPA_2) {}
+  PackedMatrix A8, B8, C8, D8, A8d;   // optional (pack_mfma): the CRS-streaming steps of a batch then run on the matrix cores
+  bool digit = false;                 // B, C, D live in the context's digit basis
+  // matrix_core_basis: B, C, D in the digit basis of primes below 2^23 (enabled on the context here if it is not yet)
+  ResidentCRS(const Context& c, const RuntimeConstants& k, bool matrix_core_basis = false)
+      : A(c, k.KAPPA * k.N), B(c, k.R * (size_t)k.T_1 * k.KAPPA_1 * k.KAPPA, enable(c, k, matrix_core_basis)),
+        C(c, k.R * (k.R + 1) / 2 * (size_t)k.T_2 * k.KAPPA_2, matrix_core_basis),
+        Dm(c, k.R * (k.R + 1) / 2 * (size_t)k.T_1 * k.KAPPA_2, matrix_core_basis), digit(matrix_core_basis) {}
   void pack_mfma(const Context& c, const RuntimeConstants& k) {
     const size_t pairs = k.R * (k.R + 1) / 2;
     B8 = PackedMatrix(c, B, k.R * (size_t)k.T_1, k.KAPPA_1, k.KAPPA);
     A8 = PackedMatrix(c, A, 1, k.KAPPA, k.N);
     C8 = PackedMatrix(c, C, pairs * (size_t)k.T_2, k.KAPPA_2, 1);   // element (rho, m) = C[m][rho]
     D8 = PackedMatrix(c, Dm, pairs * (size_t)k.T_1, k.KAPPA_2, 1);
+    if (digit) {   // A once more in the basis of B, C, D: step 1 of a batch runs there while the witness keeps its norm bound
+      HatVec Ad(c, k.KAPPA * k.N, true);
+      const std::vector<Rq> coeffs = A.to_host();
+      c.check(lab_vec_load_u64(c.handle(), Ad.handle(), 0, coeffs[0].data(), coeffs.size()));
+      A8d = PackedMatrix(c, Ad, 1, k.KAPPA, k.N);
+      c.check(lab_ctx_synchronize(c.handle()));
+    }
+  }
+
+ private:
+  static bool enable(const Context& c, const RuntimeConstants& k, bool on) {
+    lab_info di{};
+    if (on && (lab_ctx_digit_info(c.handle(), &di) != LAB_OK || di.nlimbs == 0)) {
+      const size_t pairs = k.R * (k.R + 1) / 2;
+      c.enable_matrix_core_basis(k.R * (size_t)k.T_1 * k.KAPPA + pairs * (size_t)std::max(k.T_1, k.T_2), (uint64_t)std::max(k.B_1, k.B_2));
+    }
+    return on;
   }
 };
 
@@ -292,6 +320,7 @@ class Prover {  // src/proofgen.rs:14-28
     in.S = witness[0].data(); in.phi = st.phi[0].data(); in.a = st.a[0].data(); in.b_prime = st.b_prime;
     in.A = crs.A.handle(); in.B = crs.B.handle(); in.C = crs.C.handle(); in.Dm = crs.Dm.handle();
     in.A8 = crs.A8.handle(); in.B8 = crs.B8.handle(); in.C8 = crs.C8.handle(); in.D8 = crs.D8.handle();
+    in.A8d = crs.A8d.handle();
     in.Pi = tape.Pi.data(); in.psi = tape.psi; in.omega = tape.omega.data();
     in.alpha = tape.alpha.data(); in.beta = tape.beta.data(); in.c = tape.c[0].data();
     return in;

@@ -184,6 +184,32 @@ static void prover_test(uint64_t q) {
       }
     }
   }
+  // the same CRS kept in the matrix-core digit basis (primes below 2^23, three byte planes; step 1 in that basis while the
+  // witness keeps its norm bound): identical transcripts
+  if (ctx.nlimbs() > 1) {
+    ResidentCRS crs23(ctx, k, true);
+    ctx.check(lab_vec_fill_synthetic(ctx.handle(), crs23.A.handle(), 0, crs23.A.size(), 1000, 0, q));
+    ctx.check(lab_vec_fill_synthetic(ctx.handle(), crs23.B.handle(), 0, crs23.B.size(), 1001, 0, q));
+    ctx.check(lab_vec_fill_synthetic(ctx.handle(), crs23.C.handle(), 0, crs23.C.size(), 1002, 0, q));
+    ctx.check(lab_vec_fill_synthetic(ctx.handle(), crs23.Dm.handle(), 0, crs23.Dm.size(), 1003, 0, q));
+    crs23.pack_mfma(ctx, k);
+    CHECK(crs23.A8d.bytes() > 0);
+    std::vector<const std::vector<Rq>*> ws = {&S, &S};
+    std::vector<const State*> sts = {&st, &st};
+    std::vector<const ChallengeTape*> tps = {&tape, &tape};
+    std::vector<int> status;
+    std::vector<Transcript> Tb = Prover::prove_batch(ctx, k, ws, sts, crs23, tps, status);
+    CHECK(status.size() == 2 && status[0] == LAB_OK && status[1] == LAB_OK);
+    const int flags = lab_ctx_prove_flags(ctx.handle());   // 1: step 1 in the digit basis; 2: witness above the norm bound, redone
+    CHECK(flags == 1 || flags == 2);
+    printf("matrix-core basis pass: prove flags %d\n", flags);
+    for (int j : {0, 1}) {
+      CHECK(memcmp(Tb[j].u_1[0].data(), ou1.data(), ou1.size() * 8) == 0);
+      CHECK(memcmp(Tb[j].u_2[0].data(), ou2.data(), ou2.size() * 8) == 0);
+      CHECK(memcmp(Tb[j].t_i_all[0].data(), ot.data(), ot.size() * 8) == 0);
+      CHECK(memcmp(Tb[j].z[0].data(), oz.data(), oz.size() * 8) == 0);
+    }
+  }
   // a wrong b' trips verify_b_prime_prime (src/verification.rs:550)
   State bad = st;
   bad.b_prime = (st.b_prime + 1) % q;
