@@ -50,7 +50,7 @@ bool exact_ok(const lab_ctx* c, u128 terms, u128 vmax) {
 namespace {
 
 struct Job {  // device pointers of one proof of the batch
-  uint64_t *cT, *cTdec, *cG, *cGup, *cGdec, *cW, *cphipp, *capp, *cphif, *cX, *cH, *cHup, *cHdec, *cu1, *cu2, *cz, *cbpp, *cab;
+  uint64_t *cT, *cTdec, *cG, *cGup, *cGdec, *cW, *cphipp, *capp, *cX1, *cX2, *cX, *cH, *cHup, *cHdec, *cu1, *cu2, *cz, *cbpp, *cab;
   int64_t* dproj_int;
   uint64_t* dproj;
   const uint64_t *dS, *dphi, *da, *domega, *dalpha, *dbeta, *dc;
@@ -158,7 +158,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   const int L = c->nlimbs;
   HatArena ha;
   const size_t hS = ha.take(nr), hphi = ha.take(nr), hT = ha.take(rk), hG = ha.take(rr), hphipp = ha.take(nr),
-               happ = ha.take(rr), hGc = ha.take(rr), hbpp = ha.take(2), hphif = ha.take(nr), hbphi = ha.take(nr),
+               happ = ha.take(rr), hGc = ha.take(rr), hbpp = ha.take(2), hX1 = ha.take(rr), hX2 = ha.take(rr),
                hX = ha.take(rr), hc = ha.take(r), hz = ha.take(n), hab = ha.take(2);
   size_t part_elems = 512;  // inner_product_impl splits a long inner product into <= 512 partials
   if (gram_num_chunks(n) * rr > part_elems) part_elems = gram_num_chunks(n) * rr;
@@ -182,7 +182,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if (rr > tmp_elems) tmp_elems = rr;
 
   const size_t coef_elems = rk /*cT*/ + rk * t1 /*cTdec*/ + rr /*cG*/ + pairs /*cGup*/ + pairs * t2 /*cGdec*/ +
-                            nr /*cW*/ + nr /*cphipp*/ + rr /*capp*/ + nr /*cphif*/ + rr /*cX*/ + rr /*cH*/ +
+                            nr /*cW*/ + nr /*cphipp*/ + rr /*capp*/ + 2 * rr /*cX1, cX2*/ + rr /*cX*/ + rr /*cH*/ +
                             pairs /*cHup*/ + pairs * t1 /*cHdec*/ + k1 /*cu1*/ + k2 /*cu2*/ + n /*cz*/ + 1 /*cbpp*/ +
                             2 /*cab*/;
   size_t bytes = Carver::padded((size_t)L * hat_words * 4) + Carver::padded((size_t)Ld * hatd_words * 4) +
@@ -225,7 +225,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     const lab_prove_input* x = ins[j];
     lab_transcript* o = outs[j];
     J.cT = OUT(o->t_i_all, rk); J.cTdec = CO(rk * t1); J.cG = OUT(o->g_mat, rr); J.cGup = CO(pairs); J.cGdec = CO(pairs * t2);
-    J.cW = CO(nr); J.cphipp = CO(nr); J.capp = CO(rr); J.cphif = CO(nr); J.cX = CO(rr); J.cH = OUT(o->h_mat, rr);
+    J.cW = CO(nr); J.cphipp = CO(nr); J.capp = CO(rr); J.cX1 = CO(rr); J.cX2 = CO(rr); J.cX = CO(rr); J.cH = OUT(o->h_mat, rr);
     J.cHup = CO(pairs); J.cHdec = CO(pairs * t1); J.cu1 = OUT(o->u_1, k1); J.cu2 = OUT(o->u_2, k2); J.cz = OUT(o->z, n);
     J.cbpp = OUT(o->b_prime_prime, 1); J.cab = CO(2);
     J.dproj_int = proj_all + j * 256;
@@ -414,17 +414,21 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   LAB_HIP(c, launch_pointwise(PW_ADD, HV(0, hbpp), HV(0, hbpp), HV(0, hbpp + 1), 1, L, tabs, s, np, js, js, js));
   if ((rc = from_hat_jobs(hbpp, 1, JP(&Job::cbpp), false))) return rc;
 
-  // ================= step 7 (:301-314): phi_i = alpha phi^(F)_i + beta phi''_i  (layout [n][r] like phi')
-  LAB_HIP(c, launch_poly_by_vec(HV(0, hphif), HV(0, hab), HV(0, hphi), nr, L, tabs, s, np, js));
-  LAB_HIP(c, launch_poly_by_vec(HV(0, hbphi), HV(0, hab + 1), HV(0, hphipp), nr, L, tabs, s, np, js));
-  LAB_HIP(c, launch_pointwise(PW_ADD, HV(0, hphif), HV(0, hphif), HV(0, hbphi), nr, L, tabs, s, np, js, js, js));
-  if (!c->direct) {  // canonicalise before the next product (see header comment)
-    if ((rc = from_hat_jobs(hphif, nr, JP(&Job::cphif), false))) return rc;
-    if ((rc = to_hat_jobs(JP(&Job::cphif), hphif, nr, false))) return rc;
+  // ================= steps 7 and 8 (:301-314, :320-358): phi_i = alpha phi^(F)_i + beta phi''_i is only ever used in
+  // Phi^T S, and <alpha f + beta g, s> = alpha <f, s> + beta <g, s> in R_q: two Gram products with the operands already
+  // in the transform domain, then the r x r results are scaled — the n*r polynomials phi_i are never formed.
+  // (The Gram results are brought back to [0, q) before the scaling: see the header comment on CRT range.)
+  if ((rc = gram_jobs(hX1, hphi, hS))) return rc;
+  if ((rc = gram_jobs(hX2, hphipp, hS))) return rc;
+  if (!c->direct) {
+    if ((rc = from_hat_jobs(hX1, rr, JP(&Job::cX1), false))) return rc;
+    if ((rc = to_hat_jobs(JP(&Job::cX1), hX1, rr, false))) return rc;
+    if ((rc = from_hat_jobs(hX2, rr, JP(&Job::cX2), false))) return rc;
+    if ((rc = to_hat_jobs(JP(&Job::cX2), hX2, rr, false))) return rc;
   }
-
-  // ================= step 8 (:320-358): H = 2^-1 (Phi^T S + S^T Phi)
-  if ((rc = gram_jobs(hX, hphif, hS))) return rc;
+  LAB_HIP(c, launch_poly_by_vec(HV(0, hX1), HV(0, hab), HV(0, hX1), rr, L, tabs, s, np, js));
+  LAB_HIP(c, launch_poly_by_vec(HV(0, hX2), HV(0, hab + 1), HV(0, hX2), rr, L, tabs, s, np, js));
+  LAB_HIP(c, launch_pointwise(PW_ADD, HV(0, hX), HV(0, hX1), HV(0, hX2), rr, L, tabs, s, np, js, js, js));
   if ((rc = from_hat_jobs(hX, rr, JP(&Job::cX), false))) return rc;
   LAB_HIP(c, launch_symmetrize_half_jobs(JP(&Job::cH), JP(&Job::cX), r, q, inv2_mod(q), np, s));
   // digits of the upper triangle of H for step 9
