@@ -180,6 +180,8 @@ hipError_t launch_pi_fused(int64_t* proj, uint64_t* W, const int8_t* Pi, const u
                            size_t n, size_t r, uint64_t q, hipStream_t s);
 hipError_t launch_compare_u64(unsigned int* flag, const uint64_t* a, const uint64_t* b, size_t nwords, hipStream_t s);
 hipError_t launch_symmetry_u64(unsigned int* flag, const uint64_t* X, size_t r, hipStream_t s);
+hipError_t launch_add_trace_jobs(const JobPtrs& out, const JobPtrs& base, const JobPtrs& X, size_t r, uint64_t q, size_t njobs,
+                                 hipStream_t s);
 hipError_t launch_check18(uint64_t* res, const uint64_t* s1, const uint64_t* H, const uint64_t* b, size_t r, uint64_t q,
                           hipStream_t s);
 

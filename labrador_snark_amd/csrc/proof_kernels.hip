@@ -403,6 +403,24 @@ __global__ void k_check18(uint64_t* __restrict__ res, const uint64_t* __restrict
   res[c] = submod(acc, b[c], q);
 }
 
+// out[c] = base[c] + sum_i X[i][i][c] mod q per job (the <phi''_i, s_i> part of b'' read off the diagonal of phi''^T S)
+__global__ void k_add_trace_jobs(const JobPtrs outp, const JobPtrs basep, const JobPtrs Xp, unsigned r, uint64_t q) {
+  uint64_t* __restrict__ out = static_cast<uint64_t*>(outp.p[blockIdx.x]);
+  const uint64_t* __restrict__ base = static_cast<const uint64_t*>(basep.p[blockIdx.x]);
+  const uint64_t* __restrict__ X = static_cast<const uint64_t*>(Xp.p[blockIdx.x]);
+  const unsigned c = threadIdx.x;
+  uint64_t acc = base[c];
+  for (unsigned i = 0; i < r; i++) acc = addmod(acc, X[((size_t)i * r + i) * D + c], q);
+  out[c] = acc;
+}
+
+hipError_t launch_add_trace_jobs(const JobPtrs& out, const JobPtrs& base, const JobPtrs& X, size_t r, uint64_t q, size_t njobs,
+                                 hipStream_t s) {
+  if (njobs == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_add_trace_jobs, dim3((unsigned)njobs), dim3(64), 0, s, out, base, X, (unsigned)r, q);
+  return hipGetLastError();
+}
+
 hipError_t launch_check18(uint64_t* res, const uint64_t* s1, const uint64_t* H, const uint64_t* b, size_t r, uint64_t q,
                           hipStream_t s) {
   hipLaunchKernelGGL(k_check18, dim3(1), dim3(64), 0, s, res, s1, H, b, (unsigned)r, q);

@@ -50,7 +50,7 @@ bool exact_ok(const lab_ctx* c, u128 terms, u128 vmax) {
 namespace {
 
 struct Job {  // device pointers of one proof of the batch
-  uint64_t *cT, *cTdec, *cG, *cGup, *cGdec, *cW, *cphipp, *capp, *cX1, *cX2, *cX, *cH, *cHup, *cHdec, *cu1, *cu2, *cz, *cbpp, *cab;
+  uint64_t *cT, *cTdec, *cG, *cGup, *cGdec, *cW, *capp, *cX1, *cX2, *cX, *cH, *cHup, *cHdec, *cu1, *cu2, *cz, *cbpp, *cab;
   int64_t* dproj_int;
   uint64_t* dproj;
   const uint64_t *dS, *dphi, *da, *domega, *dalpha, *dbeta, *dc;
@@ -182,7 +182,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if (rr > tmp_elems) tmp_elems = rr;
 
   const size_t coef_elems = rk /*cT*/ + rk * t1 /*cTdec*/ + rr /*cG*/ + pairs /*cGup*/ + pairs * t2 /*cGdec*/ +
-                            nr /*cW*/ + nr /*cphipp*/ + rr /*capp*/ + 2 * rr /*cX1, cX2*/ + rr /*cX*/ + rr /*cH*/ +
+                            nr /*cW*/ + rr /*capp*/ + 2 * rr /*cX1, cX2*/ + rr /*cX*/ + rr /*cH*/ +
                             pairs /*cHup*/ + pairs * t1 /*cHdec*/ + k1 /*cu1*/ + k2 /*cu2*/ + n /*cz*/ + 1 /*cbpp*/ +
                             2 /*cab*/;
   size_t bytes = Carver::padded((size_t)L * hat_words * 4) + Carver::padded((size_t)Ld * hatd_words * 4) +
@@ -225,7 +225,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     const lab_prove_input* x = ins[j];
     lab_transcript* o = outs[j];
     J.cT = OUT(o->t_i_all, rk); J.cTdec = CO(rk * t1); J.cG = OUT(o->g_mat, rr); J.cGup = CO(pairs); J.cGdec = CO(pairs * t2);
-    J.cW = CO(nr); J.cphipp = CO(nr); J.capp = CO(rr); J.cX1 = CO(rr); J.cX2 = CO(rr); J.cX = CO(rr); J.cH = OUT(o->h_mat, rr);
+    J.cW = CO(nr); J.capp = CO(rr); J.cX1 = CO(rr); J.cX2 = CO(rr); J.cX = CO(rr); J.cH = OUT(o->h_mat, rr);
     J.cHup = CO(pairs); J.cHdec = CO(pairs * t1); J.cu1 = OUT(o->u_1, k1); J.cu2 = OUT(o->u_2, k2); J.cz = OUT(o->z, n);
     J.cbpp = OUT(o->b_prime_prime, 1); J.cab = CO(2);
     J.dproj_int = proj_all + j * 256;
@@ -398,34 +398,33 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   LAB_HIP(c, launch_pi_fused_jobs(JP(&Job::dproj_int), JP(&Job::cW), JP(&Job::dPi), JP(&Job::dS), JP(&Job::domega), n, r, q, np, s));
   LAB_HIP(c, launch_lift_i64_jobs(JP(&Job::dproj), JP(&Job::dproj_int), 256, q, np, s));
 
-  // ================= step 6 (:205-289): a'' = psi a', phi'' = psi phi' + sum_m omega_m sigma_inv(pi^(m)), b''
+  // ================= steps 6-8 (:205-289, :301-314, :320-358).  phi''_i = psi phi'_i + W_i and phi_i = alpha phi'_i + beta phi''_i
+  // are only ever used inside inner products with the witness, which are linear in them:
+  //   phi'^T S =: X1,  W^T S =: XW           two Gram products on operands already in the transform domain
+  //   phi''^T S = psi X1 + XW =: X2          (r x r polynomials, coefficient domain)
+  //   sum_i <phi''_i, s_i> = trace(X2)       the second term of b''
+  //   Phi^T S = alpha X1 + beta X2           step 8's product
+  // so the n*r polynomials phi'' and phi are never formed.  (Gram results are brought back to [0, q) before they are
+  // multiplied again: see the header comment on CRT range.)
+  JobU64 psi;
   {
-    JobU64 psi;
     JobPtrs none;
     for (size_t j = 0; j < np; j++) { psi.v[j] = ins[j]->psi % q; none.p[j] = nullptr; }
-    LAB_HIP(c, launch_coef_elementwise_jobs(JP(&Job::capp), JP(&Job::da), none, rr, q, psi, 0, np, s));
-    LAB_HIP(c, launch_coef_elementwise_jobs(JP(&Job::cphipp), JP(&Job::dphi), JP(&Job::cW), nr, q, psi, 1, np, s));
+    LAB_HIP(c, launch_coef_elementwise_jobs(JP(&Job::capp), JP(&Job::da), none, rr, q, psi, 0, np, s));   // a'' = psi a'
   }
   if ((rc = to_hat_jobs(JP(&Job::capp), happ, rr, false))) return rc;
-  if ((rc = to_hat_jobs(JP(&Job::cphipp), hphipp, nr, false))) return rc;
+  if ((rc = to_hat_jobs(JP(&Job::cW), hphipp, nr, false))) return rc;          // W in the transform domain
   if ((rc = to_hat_jobs(JP(&Job::cG), hGc, rr, false))) return rc;
-  if ((rc = inner_product_jobs(hbpp, happ, hGc, rr))) return rc;
-  if ((rc = inner_product_jobs(hbpp + 1, hphipp, hS, nr))) return rc;
-  LAB_HIP(c, launch_pointwise(PW_ADD, HV(0, hbpp), HV(0, hbpp), HV(0, hbpp + 1), 1, L, tabs, s, np, js, js, js));
-  if ((rc = from_hat_jobs(hbpp, 1, JP(&Job::cbpp), false))) return rc;
-
-  // ================= steps 7 and 8 (:301-314, :320-358): phi_i = alpha phi^(F)_i + beta phi''_i is only ever used in
-  // Phi^T S, and <alpha f + beta g, s> = alpha <f, s> + beta <g, s> in R_q: two Gram products with the operands already
-  // in the transform domain, then the r x r results are scaled — the n*r polynomials phi_i are never formed.
-  // (The Gram results are brought back to [0, q) before the scaling: see the header comment on CRT range.)
+  if ((rc = inner_product_jobs(hbpp, happ, hGc, rr))) return rc;               // sum a''_ij g_ij
+  if ((rc = from_hat_jobs(hbpp, 1, JP(&Job::cab), false))) return rc;
   if ((rc = gram_jobs(hX1, hphi, hS))) return rc;
   if ((rc = gram_jobs(hX2, hphipp, hS))) return rc;
-  if (!c->direct) {
-    if ((rc = from_hat_jobs(hX1, rr, JP(&Job::cX1), false))) return rc;
-    if ((rc = to_hat_jobs(JP(&Job::cX1), hX1, rr, false))) return rc;
-    if ((rc = from_hat_jobs(hX2, rr, JP(&Job::cX2), false))) return rc;
-    if ((rc = to_hat_jobs(JP(&Job::cX2), hX2, rr, false))) return rc;
-  }
+  if ((rc = from_hat_jobs(hX1, rr, JP(&Job::cX1), false))) return rc;
+  if ((rc = from_hat_jobs(hX2, rr, JP(&Job::cX), false))) return rc;           // XW
+  LAB_HIP(c, launch_coef_elementwise_jobs(JP(&Job::cX2), JP(&Job::cX1), JP(&Job::cX), rr, q, psi, 1, np, s));   // X2 = psi X1 + XW
+  LAB_HIP(c, launch_add_trace_jobs(JP(&Job::cbpp), JP(&Job::cab), JP(&Job::cX2), r, q, np, s));                  // b''
+  if ((rc = to_hat_jobs(JP(&Job::cX1), hX1, rr, false))) return rc;
+  if ((rc = to_hat_jobs(JP(&Job::cX2), hX2, rr, false))) return rc;
   LAB_HIP(c, launch_poly_by_vec(HV(0, hX1), HV(0, hab), HV(0, hX1), rr, L, tabs, s, np, js));
   LAB_HIP(c, launch_poly_by_vec(HV(0, hX2), HV(0, hab + 1), HV(0, hX2), rr, L, tabs, s, np, js));
   LAB_HIP(c, launch_pointwise(PW_ADD, HV(0, hX), HV(0, hX1), HV(0, hX2), rr, L, tabs, s, np, js, js, js));
