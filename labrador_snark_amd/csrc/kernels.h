@@ -59,7 +59,8 @@ hipError_t launch_reduce_u64_jobs(const JobPtrs& coeffs, HatView dst, size_t dst
 // reduce + forward NTT in one pass (to_hat), njobs polynomials vectors at once
 hipError_t launch_to_hat_fused(const JobPtrs& coeffs, HatView dst, size_t dst_js, size_t count, int nlimbs, const LimbTable* tabs,
                                size_t njobs, hipStream_t s, uint64_t in_bound = ~0ull /* coefficients are below this */,
-                               unsigned long long* norm_sum = nullptr /* [njobs], += saturating sum of squares */, uint64_t norm_limit = 0);
+                               unsigned long long* norm_sum = nullptr /* [njobs], += saturating sum of squares */, uint64_t norm_limit = 0,
+                               bool src_u16 = false /* coefficients are 16-bit words (digits from launch_decompose_jobs) */);
 hipError_t launch_crt_to_u64(ConstHatView src, uint64_t* coeffs, size_t count, const CrtTable* crt, int nlimbs, hipStream_t s);
 hipError_t launch_crt_to_u64_jobs(ConstHatView src, size_t src_js, const JobPtrs& coeffs, size_t count, const CrtTable* crt,
                                   int nlimbs, size_t njobs, hipStream_t s);
@@ -155,7 +156,7 @@ hipError_t launch_decompose(uint64_t* out, const uint64_t* in, size_t count, uin
 hipError_t launch_gather_upper(uint64_t* out, const uint64_t* in, size_t r, hipStream_t s);
 // the same kernels serving njobs independent proofs per launch (per-job pointers by value, see JobPtrs)
 hipError_t launch_decompose_jobs(const JobPtrs& out, const JobPtrs& in, size_t count, uint64_t q, uint64_t base, int exp,
-                                 size_t group, size_t njobs, hipStream_t s);
+                                 size_t group, size_t njobs, hipStream_t s, bool out_u16 = false /* digits as 16-bit words */);
 hipError_t launch_gather_upper_jobs(const JobPtrs& out, const JobPtrs& in, size_t r, size_t njobs, hipStream_t s);
 hipError_t launch_gather_jobs(uint64_t* dst, const JobPtrs& src, size_t words, size_t njobs, hipStream_t s);
 hipError_t launch_scatter_jobs(const JobPtrs& dst, const uint64_t* src, size_t words, size_t njobs, hipStream_t s);

@@ -93,7 +93,7 @@ __device__ __forceinline__ uint32_t reduce_small16(uint32_t hi8, uint32_t lo, ui
 // src/util.rs:195-202) to norm_sum[job] — saturating: a polynomial with a coefficient above norm_vmax or a partial sum
 // above norm_limit counts as norm_limit + 1, so the total exceeds norm_limit exactly when the true norm does and never
 // overflows ((blocks + 1) * (norm_limit + 1) < 2^64 is the caller's business).
-template <bool NORM>
+template <bool NORM, bool SRC16>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_to_hat_fused(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, size_t dst_js, size_t count, int nlimbs,
                const LimbTable* __restrict__ tabs, uint64_t in_bound, unsigned long long* __restrict__ norm_sum,
@@ -108,6 +108,32 @@ k_to_hat_fused(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, siz
 #pragma unroll
   for (int k = 0; k < D / 4; k++) chi[k] = 0;
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  if constexpr (SRC16) {
+    // 16-bit coefficients (decomposition digits): the wave's 64 polynomials are 8 KiB contiguous, 8 pieces of 16 bytes
+    // (8 coefficients) per polynomial; LDS row pitch 36 words
+    const uint16_t* __restrict__ c16 = static_cast<const uint16_t*>(src.p[blockIdx.y]);
+    u32x4_t v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int idx = i * 64 + lane, poly = idx >> 3, piece = idx & 7;
+      const u32x4_t z = {0, 0, 0, 0};
+      v[i] = base + poly < count ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(c16 + (base + poly) * D) + piece) : z;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int idx = i * 64 + lane, poly = idx >> 3, piece = idx & 7;
+      *reinterpret_cast<u32x4_t*>(lds + poly * 36 + piece * 4) = v[i];
+    }
+    __syncthreads();   // block == one wave
+#pragma unroll
+    for (int piece = 0; piece < 8; piece++) {
+      const u32x4_t t = *reinterpret_cast<const u32x4_t*>(lds + lane * 36 + piece * 4);
+      const int k = piece * 8;
+      clo[k] = t.x & 0xFFFFu; clo[k + 1] = t.x >> 16; clo[k + 2] = t.y & 0xFFFFu; clo[k + 3] = t.y >> 16;
+      clo[k + 4] = t.z & 0xFFFFu; clo[k + 5] = t.z >> 16; clo[k + 6] = t.w & 0xFFFFu; clo[k + 7] = t.w >> 16;
+    }
+    __syncthreads();
+  } else {
 #pragma unroll
   for (int half = 0; half < 2; half++) {
     u32x4_t v[16];
@@ -133,6 +159,7 @@ k_to_hat_fused(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, siz
       chi[k / 4] |= ((t.y & 0xFFu) << (8 * (k & 3))) | ((t.w & 0xFFu) << (8 * ((k + 1) & 3)));
     }
     __syncthreads();
+  }
   }
   if constexpr (NORM) {
     uint64_t ss = 0;
@@ -174,7 +201,8 @@ k_to_hat_fused(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, siz
 }
 
 hipError_t launch_to_hat_fused(const JobPtrs& coeffs, HatView dst, size_t dst_js, size_t count, int nlimbs, const LimbTable* tabs,
-                               size_t njobs, hipStream_t s, uint64_t in_bound, unsigned long long* norm_sum, uint64_t norm_limit) {
+                               size_t njobs, hipStream_t s, uint64_t in_bound, unsigned long long* norm_sum, uint64_t norm_limit,
+                               bool src_u16) {
   if (count == 0 || njobs == 0) return hipSuccess;
   const dim3 g((unsigned)((count + 63) / 64), (unsigned)njobs);
   if (norm_sum) {
@@ -183,10 +211,14 @@ hipError_t launch_to_hat_fused(const JobPtrs& coeffs, HatView dst, size_t dst_js
     uint32_t vmax = (uint32_t)sqrt((double)norm_limit);
     while ((uint64_t)vmax * vmax > norm_limit) vmax--;
     while ((uint64_t)(vmax + 1) * (vmax + 1) <= norm_limit) vmax++;
-    hipLaunchKernelGGL(k_to_hat_fused<true>, g, dim3(64), 0, s, coeffs, dst.base, dst.plane_stride, dst_js, count, nlimbs, tabs,
+    if (src_u16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_to_hat_fused<true, false>), g, dim3(64), 0, s, coeffs, dst.base, dst.plane_stride, dst_js, count, nlimbs, tabs,
                        in_bound, norm_sum, norm_limit, vmax);
+  } else if (src_u16) {
+    hipLaunchKernelGGL((k_to_hat_fused<false, true>), g, dim3(64), 0, s, coeffs, dst.base, dst.plane_stride, dst_js, count, nlimbs, tabs,
+                       in_bound, nullptr, (uint64_t)0, (uint32_t)0);
   } else {
-    hipLaunchKernelGGL(k_to_hat_fused<false>, g, dim3(64), 0, s, coeffs, dst.base, dst.plane_stride, dst_js, count, nlimbs, tabs,
+    hipLaunchKernelGGL((k_to_hat_fused<false, false>), g, dim3(64), 0, s, coeffs, dst.base, dst.plane_stride, dst_js, count, nlimbs, tabs,
                        in_bound, nullptr, (uint64_t)0, (uint32_t)0);
   }
   return hipGetLastError();

@@ -23,9 +23,11 @@ __device__ __forceinline__ uint64_t submod(uint64_t a, uint64_t b, uint64_t q) {
 // Output element (e, digit k) goes to index ((e/group)*exp + k)*group + e%group:
 // group = count gives the reference's [exp][count] layout, group = 1 gives
 // [count][exp], group = kappa gives [i][k][rho] for the t_i decomposition.
+// OT = uint16_t: digits (< base <= 2^16) stored as 16-bit words for consumers inside the library (to_hat of the digits)
+template <typename OT>
 __global__ void __launch_bounds__(256)
 k_decompose(const JobPtrs outp, const JobPtrs inp, size_t nwords, uint64_t q, uint64_t base, int exp, size_t group) {
-  uint64_t* __restrict__ out = static_cast<uint64_t*>(outp.p[blockIdx.y]);
+  OT* __restrict__ out = static_cast<OT*>(outp.p[blockIdx.y]);
   const uint64_t* __restrict__ in = static_cast<const uint64_t*>(inp.p[blockIdx.y]);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -51,19 +53,24 @@ k_decompose(const JobPtrs outp, const JobPtrs inp, size_t nwords, uint64_t q, ui
       }
       // element counts are below 2^32 (launch_decompose_jobs checks): 32-bit quotient instead of a 64-bit division
       const uint32_t e = (uint32_t)(i / D), g = (uint32_t)group, eg = e / g;
-      out[(((size_t)eg * exp + k) * g + (e - eg * g)) * D + i % D] = r;
+      out[(((size_t)eg * exp + k) * g + (e - eg * g)) * D + i % D] = (OT)r;
     }
   }
 }
 
 hipError_t launch_decompose_jobs(const JobPtrs& out, const JobPtrs& in, size_t count, uint64_t q, uint64_t base, int exp,
-                                 size_t group, size_t njobs, hipStream_t s) {
+                                 size_t group, size_t njobs, hipStream_t s, bool out_u16) {
   if (count == 0 || exp == 0 || njobs == 0) return hipSuccess;
   if (count >> 32 || group >> 32 || group == 0) return hipErrorInvalidValue;
   size_t nwords = count * D;
   unsigned blocks = (unsigned)((nwords + 255) / 256);
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(k_decompose, dim3(blocks, (unsigned)njobs), dim3(256), 0, s, out, in, nwords, q, base, exp, group);
+  if (out_u16) {
+    if (base > 65536) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_decompose<uint16_t>, dim3(blocks, (unsigned)njobs), dim3(256), 0, s, out, in, nwords, q, base, exp, group);
+  } else {
+    hipLaunchKernelGGL(k_decompose<uint64_t>, dim3(blocks, (unsigned)njobs), dim3(256), 0, s, out, in, nwords, q, base, exp, group);
+  }
   return hipGetLastError();
 }
 
@@ -72,7 +79,7 @@ hipError_t launch_decompose(uint64_t* out, const uint64_t* in, size_t count, uin
   JobPtrs o, i;
   o.p[0] = out;
   i.p[0] = const_cast<uint64_t*>(in);
-  return launch_decompose_jobs(o, i, count, q, base, exp, group, 1, s);
+  return launch_decompose_jobs(o, i, count, q, base, exp, group, 1, s, false);
 }
 
 // ---- poly_norm (src/util.rs:195-202): exact sum of squares of the RAW residues

@@ -253,11 +253,13 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     return t;
   };
   // `darena`: the offset lives in the second arena (operands of the digit reductions, in the basis `bdig` of B/C/D)
-  auto to_hat_jobs = [&](const JobPtrs& src, size_t off, size_t count, bool darena, uint64_t in_bound = ~0ull) -> int {
+  // decomposition digits travel between k_decompose and to_hat as 16-bit words when both bases allow it
+  const bool dig16 = in->b1 <= 65536 && in->b2 <= 65536;
+  auto to_hat_jobs = [&](const JobPtrs& src, size_t off, size_t count, bool darena, uint64_t in_bound = ~0ull, bool src16 = false) -> int {
     const int basis = darena ? bdig : 0;
     HatView dst = darena ? HD(0, off) : HV(0, off);
     const size_t st = darena ? jsd : js;
-    LAB_HIP(c, launch_to_hat_fused(src, dst, st, count, basis_nlimbs(c, basis), basis_tabs(c, basis), np, s, in_bound));   // reduce + NTT
+    LAB_HIP(c, launch_to_hat_fused(src, dst, st, count, basis_nlimbs(c, basis), basis_tabs(c, basis), np, s, in_bound, nullptr, 0, src16));   // reduce + NTT
     return LAB_OK;
   };
   auto from_hat_jobs = [&](size_t off, size_t count, const JobPtrs& dst, bool darena) -> int {
@@ -330,8 +332,8 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if ((rc = gram_jobs(hG, hS, hS))) return rc;
   if ((rc = from_hat_jobs(hG, rr, JP(&Job::cG), false))) return rc;
   // digits of t in [i][k][rho] order, into the basis of B
-  LAB_HIP(c, launch_decompose_jobs(JP(&Job::cTdec), JP(&Job::cT), rk, q, (uint64_t)in->b1, t1, kappa, np, s));
-  if ((rc = to_hat_jobs(JP(&Job::cTdec), hTdec, rk * t1, true, (uint64_t)in->b1))) return rc;
+  LAB_HIP(c, launch_decompose_jobs(JP(&Job::cTdec), JP(&Job::cT), rk, q, (uint64_t)in->b1, t1, kappa, np, s, dig16));
+  if ((rc = to_hat_jobs(JP(&Job::cTdec), hTdec, rk * t1, true, (uint64_t)in->b1, dig16))) return rc;
 
   // ================= step 3 (:101-132) for the whole batch: lhs_j = sum_{i,k} B_ik t_{j,i}^(k); B streamed once per group
   for (size_t j0 = 0; b8 && j0 < np;) {   // matrix cores: up to 64 proofs per pass over B, result written in place
@@ -368,8 +370,8 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
 
   // ================= step 4 (:137-148): rhs = sum_{i<=j,k} g_ij^(k) C_ijk ; u_1 = lhs + rhs (:153)
   LAB_HIP(c, launch_gather_upper_jobs(JP(&Job::cGup), JP(&Job::cG), r, np, s));
-  LAB_HIP(c, launch_decompose_jobs(JP(&Job::cGdec), JP(&Job::cGup), pairs, q, (uint64_t)in->b2, t2, 1, np, s));  // [pair][k]
-  if ((rc = to_hat_jobs(JP(&Job::cGdec), hGdec, pairs * t2, true, (uint64_t)in->b2))) return rc;
+  LAB_HIP(c, launch_decompose_jobs(JP(&Job::cGdec), JP(&Job::cGup), pairs, q, (uint64_t)in->b2, t2, 1, np, s, dig16));  // [pair][k]
+  if ((rc = to_hat_jobs(JP(&Job::cGdec), hGdec, pairs * t2, true, (uint64_t)in->b2, dig16))) return rc;
   // sum_m digits[m] * Cm[m][rho] for every proof: on the matrix cores when Cm was packed for them (up to 64 proofs per
   // pass), else with the multiply-add kernels in groups of 8
   auto commit_digits = [&](const lab_mat8* m8, const lab_vec* Cm, size_t cm_off, size_t out_off, size_t dig_off, size_t nterms) -> int {
@@ -432,8 +434,8 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   LAB_HIP(c, launch_symmetrize_half_jobs(JP(&Job::cH), JP(&Job::cX), r, q, inv2_mod(q), np, s));
   // digits of the upper triangle of H for step 9
   LAB_HIP(c, launch_gather_upper_jobs(JP(&Job::cHup), JP(&Job::cH), r, np, s));
-  LAB_HIP(c, launch_decompose_jobs(JP(&Job::cHdec), JP(&Job::cHup), pairs, q, (uint64_t)in->b1, t1, 1, np, s));
-  if ((rc = to_hat_jobs(JP(&Job::cHdec), hHdec, pairs * t1, true, (uint64_t)in->b1))) return rc;
+  LAB_HIP(c, launch_decompose_jobs(JP(&Job::cHdec), JP(&Job::cHup), pairs, q, (uint64_t)in->b1, t1, 1, np, s, dig16));
+  if ((rc = to_hat_jobs(JP(&Job::cHdec), hHdec, pairs * t1, true, (uint64_t)in->b1, dig16))) return rc;
 
   // ================= step 9 (:364-378): u_2 = sum_{i<=j,k} h_ij^(k) D_ijk ; D streamed once per group
   if ((rc = commit_digits(d8, in->Dm, in->d_off, hu2, hHdec, pairs * t1))) return rc;
