@@ -7,6 +7,8 @@
 // reduction starts from canonical residues and stays inside the CRT range.
 // Zq-scalar multiplications (psi, omega, 2^-1) and digit decompositions are
 // coefficient-domain kernels.  Step numbers follow SURVEY.md §3.2.
+// phi'' and the final phi (src/proofgen.rs:236-254, 301-314) are never formed: they only occur inside inner products
+// with the witness, which are linear — see steps 6-8 below.
 #include <math.h>
 #include <string.h>
 
