@@ -23,8 +23,25 @@ __device__ __forceinline__ uint64_t submod(uint64_t a, uint64_t b, uint64_t q) {
 // Output element (e, digit k) goes to index ((e/group)*exp + k)*group + e%group:
 // group = count gives the reference's [exp][count] layout, group = 1 gives
 // [count][exp], group = kappa gives [i][k][rho] for the t_i decomposition.
+// x = hi*2^32 + lo < 2^40 divided by b < 2^16 in 32-bit arithmetic: two steps of long division in base 2^16, each a
+// multiply-high by m = floor(2^32 / b) (underestimates the quotient by at most 2) and two conditional corrections.
+// Returns the remainder; *quot = floor(x / b).
+__device__ __forceinline__ uint32_t divmod_u40_u16(uint32_t hi, uint32_t lo, uint32_t b, uint32_t m, uint64_t* quot) {
+  const uint32_t t1 = (hi << 16) | (lo >> 16);            // < 2^24
+  uint32_t q1 = __umulhi(t1, m), r1 = t1 - q1 * b;
+  { const bool f = r1 >= b; r1 -= f ? b : 0; q1 += f; }
+  { const bool f = r1 >= b; r1 -= f ? b : 0; q1 += f; }
+  const uint32_t t2 = (r1 << 16) | (lo & 0xFFFFu);        // < b * 2^16 <= 2^32
+  uint32_t q2 = __umulhi(t2, m), r2 = t2 - q2 * b;
+  { const bool f = r2 >= b; r2 -= f ? b : 0; q2 += f; }
+  { const bool f = r2 >= b; r2 -= f ? b : 0; q2 += f; }
+  *quot = ((uint64_t)q1 << 16) + q2;
+  return r2;
+}
+
 // OT = uint16_t: digits (< base <= 2^16) stored as 16-bit words for consumers inside the library (to_hat of the digits)
-template <typename OT>
+// FAST: base < 2^16 and base <= q — all quotients by `base` in 32-bit integer arithmetic (divmod_u40_u16)
+template <typename OT, bool FAST>
 __global__ void __launch_bounds__(256)
 k_decompose(const JobPtrs outp, const JobPtrs inp, size_t nwords, uint64_t q, uint64_t base, int exp, size_t group) {
   OT* __restrict__ out = static_cast<OT*>(outp.p[blockIdx.y]);
@@ -34,11 +51,21 @@ k_decompose(const JobPtrs outp, const JobPtrs inp, size_t nwords, uint64_t q, ui
   const uint64_t half = (base / 2) % q;  // `val > b/2` compares with mod_positive(b/2, Q) (algebraic.rs:293-297)
   const double inv_base = 1.0 / (double)base;
   const bool small_q = base > q;         // only then do the reference's `% Q` after `% base` do anything
+  const uint32_t b32 = (uint32_t)base, bm = FAST ? (uint32_t)(0x100000000ull / base) : 0;
   for (; i < nwords; i += stride) {
     uint64_t v = in[i];
+    const uint32_t e = (uint32_t)(i / D), g = (uint32_t)group, eg = e / g;   // element counts are below 2^32 (launch_decompose_jobs checks)
+    OT* const o = out + ((size_t)eg * exp * g + (e - eg * g)) * D + i % D;
     for (int k = 0; k < exp; k++) {
       uint64_t r = 0;
-      if (v != 0) {
+      if (FAST) {
+        // same arithmetic (v = 0 gives r = 0 and stays 0): r0 = v % base; r = r0 > half ? base - r0 : r0; v = (v - r mod q) / base
+        uint64_t qq;
+        const uint32_t r0 = divmod_u40_u16((uint32_t)(v >> 32), (uint32_t)v, b32, bm, &qq);
+        r = r0 > half ? b32 - r0 : r0;
+        const uint64_t w = submod(v, r, q);
+        (void)divmod_u40_u16((uint32_t)(w >> 32), (uint32_t)w, b32, bm, &v);
+      } else if (v != 0) {
         // r0 = (v % base) % q ; r = r0 > half ? ((base - r0) % base) % q : r0 ; v = ((v - r mod q) / base) % q
         // v < q < 2^40 and base >= 2: quotients by `base` through mod_u64/div_u64 (no integer division)
         uint64_t r0 = mod_u64_near(v, base, inv_base);
@@ -51,9 +78,7 @@ k_decompose(const JobPtrs outp, const JobPtrs inp, size_t nwords, uint64_t q, ui
         v = div_u64_near(submod(v, r, q), base, inv_base);
         if (small_q) v %= q;
       }
-      // element counts are below 2^32 (launch_decompose_jobs checks): 32-bit quotient instead of a 64-bit division
-      const uint32_t e = (uint32_t)(i / D), g = (uint32_t)group, eg = e / g;
-      out[(((size_t)eg * exp + k) * g + (e - eg * g)) * D + i % D] = (OT)r;
+      o[(size_t)k * g * D] = (OT)r;
     }
   }
 }
@@ -65,12 +90,13 @@ hipError_t launch_decompose_jobs(const JobPtrs& out, const JobPtrs& in, size_t c
   size_t nwords = count * D;
   unsigned blocks = (unsigned)((nwords + 255) / 256);
   if (blocks > 16384) blocks = 16384;
-  if (out_u16) {
-    if (base > 65536) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_decompose<uint16_t>, dim3(blocks, (unsigned)njobs), dim3(256), 0, s, out, in, nwords, q, base, exp, group);
-  } else {
-    hipLaunchKernelGGL(k_decompose<uint64_t>, dim3(blocks, (unsigned)njobs), dim3(256), 0, s, out, in, nwords, q, base, exp, group);
-  }
+  const bool fast = base < 65536 && base <= q && q < (1ull << 40);
+  const dim3 gr(blocks, (unsigned)njobs);
+  if (out_u16 && base > 65536) return hipErrorInvalidValue;
+#define LAB_DEC(OT, F) hipLaunchKernelGGL((k_decompose<OT, F>), gr, dim3(256), 0, s, out, in, nwords, q, base, exp, group)
+  if (out_u16) { if (fast) LAB_DEC(uint16_t, true); else LAB_DEC(uint16_t, false); }
+  else { if (fast) LAB_DEC(uint64_t, true); else LAB_DEC(uint64_t, false); }
+#undef LAB_DEC
   return hipGetLastError();
 }
 
