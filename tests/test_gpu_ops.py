@@ -83,8 +83,10 @@ def test_amortize_z_pointwise_and_poly_by_vec(contexts, q):
 
 
 @pytest.mark.parametrize("q", ALL_Q)
-@pytest.mark.parametrize("base,exp", [(9, 4), (1625, 3), (14, 2), (638, 4), (2, 13), (3, 1)])
+@pytest.mark.parametrize("base,exp", [(9, 4), (1625, 3), (14, 2), (638, 4), (2, 13), (3, 1), (255, 5), (256, 5), (65535, 3),
+                                      (65536, 3), (100003, 2), (8190, 3), (8191, 2), (8192, 2)])
 def test_decompose_bug_compatible(contexts, q, base, exp):
+    # bases below 2^16 and not above q take the 32-bit long-division path, the others the double-reciprocal one
     import labrador_snark_amd as lab
     from oracle import coracle as co
     ctx = contexts(q)
