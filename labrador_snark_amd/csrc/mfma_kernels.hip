@@ -434,7 +434,7 @@ hipError_t launch_slot_transpose(uint32_t* out_plane, size_t out_set_stride, siz
 // tiles; the caller derives rgroups from gemm_i8_waves().  LAB_GEMM_WAVES=4 in the environment keeps 4-wave blocks.
 int gemm_i8_waves(int planes, size_t rt_count, size_t nt) {
   static const int env = getenv("LAB_GEMM_WAVES") ? atoi(getenv("LAB_GEMM_WAVES")) : 0;
-  if (planes == 3) return rt_count >= 2 ? 6 : 3;
+  if (planes == 3) return rt_count >= 2 && env != 3 ? 6 : 3;
   if (env == 4) return 4;
   return planes == 4 && rt_count >= 2 && nt >= 2 ? 8 : 4;
 }
