@@ -140,9 +140,14 @@ int gram_impl(lab_ctx* c, HatView out, ConstHatView P, ConstHatView S, size_t n,
 int check_range(lab_ctx* c, const lab_vec* v, size_t off, size_t n, const char* what);
 // int8-MFMA outer commitment (mfma_api.hip)
 size_t mfma_scratch_bytes(const lab_mat8* m, int ns, size_t njobs);
+// `coef`: the caller only wants the results as coefficients — when the launch goes through the slot-major staging array
+// (several jobs) the inverse transform reads it directly and writes plane l of the dense array `coef->dense`
+// ([limb][count][64] words, job stride coef->job_stride, set s -> polynomial s * coef->set_stride + row) instead of `out`;
+// coef->done tells whether that happened (else `out` holds the transform-domain results as usual)
+struct MfmaCoefOut { uint32_t* dense; size_t plane_stride, job_stride, set_stride; bool done; };
 int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_mat8* m, ConstHatView V, size_t v_set_stride, int ns,
                      int ns_valid, void* scratch, size_t v_k_stride, size_t njobs, size_t out_job_stride, size_t v_job_stride,
-                     bool timed = false);
+                     bool timed = false, MfmaCoefOut* coef = nullptr);
 bool mat8_matches(const lab_mat8* m, int basis, size_t nmat, size_t rows, size_t cols);
 int mat8_basis(const lab_mat8* m);
 // launch_matvec_partial wrapped in the profiling events when the hook is active

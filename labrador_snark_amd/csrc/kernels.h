@@ -52,6 +52,9 @@ struct CrtTable {
 // njobs > 1: job b works on src + b*src_js / dst + b*dst_js (word strides inside a plane)
 hipError_t launch_ntt(bool forward, ConstHatView src, HatView dst, size_t count, int nlimbs, const LimbTable* tabs,
                       int escale, hipStream_t s, size_t njobs = 1, size_t src_js = 0, size_t dst_js = 0);
+// inverse transform of a multi-job GEMM's slot-major staging array into dense [count][64] planes (see k_intt_from_stage)
+hipError_t launch_intt_from_stage(const uint32_t* stage, size_t rows, size_t rows_pad, size_t ns, size_t ns_valid, size_t nsub,
+                                  size_t gemm_jobs, uint32_t* dst, size_t dst_js, size_t set_stride, const LimbTable* tab, hipStream_t s);
 hipError_t launch_reduce_u64(const uint64_t* coeffs, HatView dst, size_t count, int nlimbs, const LimbTable* tabs,
                              hipStream_t s);
 hipError_t launch_reduce_u64_jobs(const JobPtrs& coeffs, HatView dst, size_t dst_js, size_t count, int nlimbs,

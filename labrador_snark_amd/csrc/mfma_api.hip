@@ -53,7 +53,7 @@ size_t mfma_scratch_bytes(const lab_mat8* m, int ns, size_t njobs) { return v8_j
 // limbs are bracketed by events.
 int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_mat8* m, ConstHatView V, size_t v_set_stride, int ns,
                      int ns_valid, void* scratch, size_t v_k_stride, size_t njobs, size_t out_job_stride, size_t v_job_stride,
-                     bool timed) {
+                     bool timed, MfmaCoefOut* coef) {
   const uint32_t* primes = m->basis ? c->dg_primes : c->primes;
   const size_t ktotal = m->nmat * m->cols;
   // Many 32-set jobs sharing the matrix (the Ajtai product of a batch): two source jobs are multiplied as ONE 64-set job,
@@ -114,10 +114,14 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
       c->prof_bytes += (double)D * pl * m->rt_count * m->kt_count * 1024 + (double)D * m->kt_count * nt * 1024 +
                        (double)ns_valid * m->rows * D * 4;
     }
-    if (stage)
+    if (stage && coef)
+      LAB_HIP(c, launch_intt_from_stage(stage, m->rows, m->rt_count * 32, ns, ns_valid, nsub, njobs, coef->dense + (size_t)l * coef->plane_stride,
+                                        coef->job_stride, coef->set_stride, (m->basis ? c->dg_tabs : c->d_tabs) + l, c->stream));
+    else if (stage)
       LAB_HIP(c, launch_slot_transpose(g.out, out_set_stride, out_job_stride, stage, m->rows, m->rt_count * 32, ns, ns_valid, njobs,
                                        nsub, c->stream));
   }
+  if (coef) coef->done = stage != nullptr;
   return LAB_OK;
 }
 

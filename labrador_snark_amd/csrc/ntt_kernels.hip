@@ -29,6 +29,51 @@ k_ntt64(const uint32_t* __restrict__ src, size_t src_ps, uint32_t* __restrict__ 
   tile_store_u32(x, dst + (size_t)limb * dst_ps + (size_t)blockIdx.z * dst_js, base, count, lds, lane);
 }
 
+// Inverse transform straight from the slot-major staging array a multi-job GEMM leaves behind (k_gemm_i8:
+// stage[gemm job][slot j][row][set s], mfma_kernels.hip): thread (row, s) reads its 64 slots with 64 coalesced 4-byte
+// loads (a wave = 64 neighbouring (row, s): 256 B per slot), transforms, and the wave writes whole 256-byte
+// polynomials into the dense [count][64] plane the CRT kernel reads — polynomial (s % nsub) * set_stride + row of
+// source job gemm_job * (ns / nsub) + s / nsub.  Replaces k_slot_transpose + the tile load of k_ntt64 for results
+// that are only wanted as coefficients (t = A s).
+__global__ void __launch_bounds__(64)
+k_intt_from_stage(const uint32_t* __restrict__ stage, unsigned rows, unsigned rows_pad, unsigned ns, unsigned ns_valid, unsigned nsub,
+                  uint32_t* __restrict__ dst, size_t dst_js, size_t set_stride, const LimbTable* __restrict__ tab) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[TILE_WORDS];
+  const int lane = threadIdx.x;
+  const size_t per_slot = (size_t)rows_pad * ns;
+  const size_t f0 = (size_t)blockIdx.x * 64;
+  const uint32_t* src = stage + (size_t)blockIdx.y * D * per_slot + f0 + lane;
+  uint32_t x[D];
+#pragma unroll
+  for (int j = 0; j < D; j++) x[j] = __builtin_nontemporal_load(src + (size_t)j * per_slot);
+  ntt64_inverse(x, tab, 0);
+#pragma unroll
+  for (int c = 0; c < 16; c++)
+    *reinterpret_cast<uint4*>(lds + lane * TILE_PITCH + c * 4) = make_uint4(x[c * 4 + 0], x[c * 4 + 1], x[c * 4 + 2], x[c * 4 + 3]);
+  __syncthreads();   // block == one wave
+  const unsigned sub = ns / nsub;
+#pragma unroll 4
+  for (int i = 0; i < 16; i++) {
+    const int p = i * 4 + (lane >> 4);
+    const size_t f = f0 + p;
+    const unsigned row = (unsigned)(f / ns), s = (unsigned)(f % ns), sl = s % nsub;
+    if (row < rows && sl < ns_valid) {
+      const uint4 o = *reinterpret_cast<const uint4*>(lds + p * TILE_PITCH + (lane & 15) * 4);
+      uint32_t* d = dst + ((size_t)blockIdx.y * sub + s / nsub) * dst_js + ((size_t)sl * set_stride + row) * D + (lane & 15) * 4;
+      *reinterpret_cast<uint4*>(d) = o;
+    }
+  }
+}
+
+hipError_t launch_intt_from_stage(const uint32_t* stage, size_t rows, size_t rows_pad, size_t ns, size_t ns_valid, size_t nsub,
+                                  size_t gemm_jobs, uint32_t* dst, size_t dst_js, size_t set_stride, const LimbTable* tab, hipStream_t s) {
+  if (rows == 0 || gemm_jobs == 0) return hipSuccess;
+  if ((rows_pad * ns) % 64 || ns % nsub) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_intt_from_stage, dim3((unsigned)(rows_pad * ns / 64), (unsigned)gemm_jobs), dim3(64), 0, s, stage, (unsigned)rows,
+                     (unsigned)rows_pad, (unsigned)ns, (unsigned)ns_valid, (unsigned)nsub, dst, dst_js, set_stride, tab);
+  return hipGetLastError();
+}
+
 hipError_t launch_ntt(bool forward, ConstHatView src, HatView dst, size_t count, int nlimbs, const LimbTable* tabs,
                       int escale, hipStream_t s, size_t njobs, size_t src_js, size_t dst_js) {
   if (count == 0 || njobs == 0) return hipSuccess;

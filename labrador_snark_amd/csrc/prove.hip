@@ -188,7 +188,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
                             pairs /*cHup*/ + pairs * t1 /*cHdec*/ + k1 /*cu1*/ + k2 /*cu2*/ + n /*cz*/ + 1 /*cbpp*/ +
                             2 /*cab*/;
   size_t bytes = Carver::padded((size_t)L * hat_words * 4) + Carver::padded((size_t)Ld * hatd_words * 4) +
-                 Carver::padded(np * (size_t)L * tmp_elems * D * 4) +
+                 Carver::padded(np * (size_t)(L > Ld ? L : Ld) * tmp_elems * D * 4) +
                  np * (coef_elems * (D * 8) + 32 * 256 /*alignment padding of the carves*/ + 3 * 4096 /*proj*/);
   for (size_t j = 0; j < np; j++) {
     const lab_prove_input* x = ins[j];
@@ -211,7 +211,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   uint32_t* hat_base = cv.take<uint32_t>((size_t)L * hat_words);
   uint32_t* hatd_base = cv.take<uint32_t>((size_t)Ld * hatd_words);
   // from_hat scratch: a dense [L][count][64] buffer (its plane stride is count*64, not the arena's)
-  uint32_t* dense_tmp = cv.take<uint32_t>(np * (size_t)L * tmp_elems * D);   // job j: + j * L*tmp_elems*64 words
+  uint32_t* dense_tmp = cv.take<uint32_t>(np * (size_t)(L > Ld ? L : Ld) * tmp_elems * D);   // job j: + j * max(L, Ld)*tmp_elems*64 words
   auto HV = [&](size_t j, size_t off) { return HatView{hat_base + (j * per + off) * D, hat_words}; };
   auto HD = [&](size_t j, size_t off) { return HatView{hatd_base + (j * perd + off) * D, hatd_words}; };
   auto CO = [&](size_t elems) { return cv.take<uint64_t>(elems * D); };
@@ -248,7 +248,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   // Every per-proof kernel below is launched ONCE for all np proofs (a "job" grid dimension): transform-domain operands
   // are addressed with the arena's job stride, coefficient arrays through per-job pointers passed by value.
   const size_t js = per * D, jsd = perd * D;                       // job strides (words inside a plane) of the two arenas
-  const size_t tmp_js = (size_t)L * tmp_elems * D;                 // per-job slice of the from_hat scratch
+  const size_t tmp_js = (size_t)(L > Ld ? L : Ld) * tmp_elems * D;   // per-job slice of the from_hat scratch
   auto JP = [&](auto member) {
     JobPtrs t;
     for (size_t j = 0; j < np; j++) t.p[j] = const_cast<void*>(static_cast<const void*>(jobs[j].*member));
@@ -302,6 +302,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   // ================= step 1 (src/proofgen.rs:41-49): t_i = A s_i for every column of every proof; A is shared, so the
   // whole batch is one (kappa x n)(n x np*r) product (falls back to one launch per proof for shapes it does not take)
   uint64_t* norm_sums = host_stage + np * (256 + 256 + D);
+  bool t_in_dense = false;
   if (a8d) {  // matrix cores, in the basis of B, C, D (see a8d above): S once more into that basis, its norm summed on the way
     LAB_HIP(c, hipMemsetAsync(norm_sums, 0, np * 8, s));
     // (coefficients above beta_bound are caught by the norm sum and the batch is redone: the transform may assume the bound)
@@ -309,15 +310,19 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
                                    reinterpret_cast<unsigned long long*>(norm_sums), norm_limit));
     for (size_t i0 = 0; i0 < r; i0 += 32) {
       const int valid = (int)(r - i0 < 32 ? r - i0 : 32);
+      MfmaCoefOut co{dense_tmp + i0 * kappa * D, rk * D, tmp_js, kappa, false};   // t is only wanted as coefficients
       if ((rc = matvec_mfma_impl(c, HD(0, hTd + i0 * kappa), kappa * D, a8d, HD(0, hSd + i0), D, a8_ns, valid, mf_scratch, r * D, np,
-                                 perd * D, perd * D))) return rc;
+                                 perd * D, perd * D, false, &co))) return rc;
+      t_in_dense = co.done;
     }
   } else if (a8) {   // matrix cores: per proof, its r witness columns as the vector sets (element x of column i at S[x][i])
     // one launch per limb and 32 columns: the proofs are the kernel's jobs and share the A stream through L2
     for (size_t i0 = 0; i0 < r; i0 += 32) {
       const int valid = (int)(r - i0 < 32 ? r - i0 : 32);
+      MfmaCoefOut co{dense_tmp + i0 * kappa * D, rk * D, tmp_js, kappa, false};
       if ((rc = matvec_mfma_impl(c, HV(0, hT + i0 * kappa), kappa * D, a8, HV(0, hS + i0), D, a8_ns, valid, mf_scratch, r * D, np,
-                                 per * D, per * D))) return rc;
+                                 per * D, per * D, false, &co))) return rc;
+      t_in_dense = co.done;
     }
   } else {
     hipError_t e = launch_matmul_bcast(HV(0, hT), kappa * D, per * D, in->A->view(in->a_off), HV(0, hS), D, r * D, per * D, np,
@@ -329,7 +334,12 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
       LAB_HIP(c, e);
     }
   }
-  if ((rc = a8d ? from_hat_jobs(hTd, rk, JP(&Job::cT), true) : from_hat_jobs(hT, rk, JP(&Job::cT), false))) return rc;
+  if (t_in_dense) {   // the inverse transform already ran from the GEMM's staging array: only the CRT is left
+    const int basis = a8d ? bdig : 0;
+    LAB_HIP(c, launch_crt_to_u64_jobs(HatView{dense_tmp, rk * D}, tmp_js, JP(&Job::cT), rk, basis_crt(c, basis), basis_nlimbs(c, basis), np, s));
+  } else if ((rc = a8d ? from_hat_jobs(hTd, rk, JP(&Job::cT), true) : from_hat_jobs(hT, rk, JP(&Job::cT), false))) {
+    return rc;
+  }
   // step 2 (:59-70): G = S^T S
   if ((rc = gram_jobs(hG, hS, hS))) return rc;
   if ((rc = from_hat_jobs(hG, rr, JP(&Job::cG), false))) return rc;
