@@ -281,6 +281,34 @@ def test_digit_basis_ajtai_and_its_fallback():
     ctx.close()
 
 
+@pytest.mark.parametrize("q", [Q_DIRECT, Q_DEFAULT])
+def test_matrix_core_basis_with_other_moduli(q):
+    # the digit basis of primes below 2^23 next to a single-prime main basis (q its own NTT prime: 3 digit limbs, 1 main
+    # limb) and next to a small q: same transcripts as the multiply-add path, whichever basis step 1 ends up in
+    import labrador_snark_amd as lab
+    n, r, kappa, kappa1 = 4, 8, 64, 20
+    ctx = lab.Context(q, 0)
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
+    if k.T_1 < 1 or k.T_2 < 1 or k.B_1 < 2 or k.B_2 < 2:
+        pytest.skip("RuntimeConstants give no usable decomposition at this modulus and size")
+    plain = lab.ResidentCRS(ctx, k).fill_synthetic(1000)
+    ws, sts, tapes = [], [], []
+    for j in range(3):
+        case, (S, phi, a, tape) = cases.oracle_case(p, seed=40 + j)
+        ws.append(S); sts.append(lab.State(phi, a, case.b_prime)); tapes.append(tape)
+    ref, codes_ref = lab.prove_core_batch(ctx, k, ws, sts, plain, tapes, raise_on_reject=False)
+    crs = lab.ResidentCRS(ctx, k, mfma_basis=True).fill_synthetic(1000)
+    crs.pack_mfma(drop_B=True)
+    got, codes = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes, raise_on_reject=False)
+    assert list(codes) == list(codes_ref) and ctx.prove_flags() in (0, 1, 2)
+    for j in range(3):
+        for f in ("t_i_all", "g_mat", "h_mat", "u_1", "u_2", "z", "b_prime_prime", "projection_int"):
+            assert np.array_equal(getattr(got[j], f), getattr(ref[j], f)), (j, f)
+    crs.close(); plain.close()
+    ctx.close()
+
+
 def test_verifier_needs_the_unpacked_B():
     # a prover-only process may drop B after packing it for the matrix cores; lab_verify_core then refuses cleanly
     import labrador_snark_amd as lab
