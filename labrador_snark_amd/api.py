@@ -259,7 +259,7 @@ class Mat8:
 
 
 def matvec_sum_mfma(ctx, M8, V, ns, v_off=0, out=None, out_off=0):
-    """lab_matvec_sum_batched for ns in {8,16,32} vector sets on the matrix cores (exact int8 GEMMs)."""
+    """lab_matvec_sum_batched for ns in {8,16,32,64} vector sets on the matrix cores (exact int8 GEMMs)."""
     if out is None:
         out = HatVec(ctx, ns * M8.rows, digit=M8.digit)
     ctx._check(ctx._lib.lab_matvec_sum_mfma(ctx._h, out._h, out_off, M8._h, V._h, v_off, ns))

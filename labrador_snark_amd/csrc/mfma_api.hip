@@ -47,7 +47,7 @@ size_t mfma_scratch_bytes(const lab_mat8* m, int ns, size_t njobs) { return v8_j
 
 // For every job b < njobs: out_s[rho] (s < ns_valid; hat elements at out.base + b*out_job_stride + s*out_set_stride)
 //   = sum_k M[rho][k] V_s[k],  V_s[k] at V.base + b*v_job_stride + s*v_set_stride + k*v_k_stride
-// (v_k_stride = 64 words for vectors stored set by set).  ns in {8,16,32} is the padded set count the GEMM runs with;
+// (v_k_stride = 64 words for vectors stored set by set).  ns in {8,16,32,64} is the padded set count the GEMM runs with;
 // `scratch` holds mfma_scratch_bytes(m, ns, njobs).  One pack + one GEMM launch per limb; the jobs share the matrix
 // stream through L2.  With `timed` (the outer commitment) and the measurement hook on, the GEMM launches of the 4-plane
 // limbs are bracketed by events.

@@ -3,15 +3,16 @@
 //
 // With 8 or more vector sets the VALU formulation (linalg_kernels.hip) is bound by the issue rate of v_mad_u64_u32
 // (1.65e13 multiply-adds/s chip-wide).  Here every residue x in [0, p) is written in signed base-256 digits
-// x = sum_i d_i 256^i, d_i in [-128, 127] (PL = 4 digit planes for the 30-bit limb primes, 2 for a prime < 2^15), and
-// per NTT slot j and limb the sum over k = (m, c) becomes PL x PLV int8 GEMMs
+// x = sum_i d_i 256^i, d_i in [-128, 127] (PL = 4 digit planes for the 30-bit limb primes, 3 for the primes below 2^23 of
+// the digit basis made for this path (lab_ctx_enable_digit_basis_mfma), 2 for a prime < 2^15), and
+// per NTT slot j and limb the sum over k = (m, c) becomes PL x PL int8 GEMMs
 //     D[i][rho][(i', s)] = sum_k Md_i[rho][k] * Vd_i'[k][s]          (int32, exact: |D| <= K * 2^14 < 2^31 for K < 2^17)
-//     out_s[rho] = sum_{i,i'} 256^(i+i') D[i][rho][(i',s)]  mod p      (epilogue kernel)
-// on v_mfma_i32_32x32x32_i8 (32768 multiply-adds per 32 cycles per SIMD: 16 byte products per modular product still
-// leave ~9x the VALU rate).  The matrix is stored once, at CRS build time, in MFMA A-operand tile order:
+//     out_s[rho] = sum_{i,i'} 256^(i+i') D[i][rho][(i',s)]  mod p      (fused into the GEMM's epilogue)
+// on v_mfma_i32_32x32x32_i8 (32768 multiply-adds per 32 cycles per SIMD: 16 — or 9 — byte products per modular product
+// still leave several times the VALU rate; what limits the long launches is power).  The matrix is stored once, at CRS build time, in MFMA A-operand tile order:
 //     M8[limb][slot j][plane i][row tile rt][k tile kt][lane 64][16 B]
 // (lane l of a tile holds row rt*32 + (l & 31), k = kt*32 + 16*(l >> 5) + 0..15: one wave-wide 16-byte load is one
-// A operand, 1 KiB contiguous), 4 bytes per residue as before.  The vectors are re-packed per batch into B-operand
+// A operand, 1 KiB contiguous), PL bytes per residue.  The vectors are re-packed per batch into B-operand
 // tiles V8[limb][slot j][k tile][col tile][lane][16 B], column n = i' * NS + s.
 #include "kernels.h"
 #include <cstdlib>

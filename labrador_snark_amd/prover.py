@@ -90,7 +90,7 @@ class ResidentCRS:
 
     def pack_mfma(self, drop_B=False):
         """Re-stores the B matrices for the matrix cores (lab_mat8_pack): step 3 of prove_core[_batch] then runs as exact
-        int8 GEMMs over up to 32 proofs per pass over B.  drop_B=True frees the original B (the verifier and
+        int8 GEMMs over up to 64 proofs per pass over B.  drop_B=True frees the original B (the verifier and
         single-proof VALU path need it; a prover-only service does not)."""
         from .api import Mat8
         k = self.constants
