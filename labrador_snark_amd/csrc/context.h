@@ -147,7 +147,12 @@ size_t mfma_scratch_bytes(const lab_mat8* m, int ns, size_t njobs);
 struct MfmaCoefOut { uint32_t* dense; size_t plane_stride, job_stride, set_stride; bool done; };
 int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_mat8* m, ConstHatView V, size_t v_set_stride, int ns,
                      int ns_valid, void* scratch, size_t v_k_stride, size_t njobs, size_t out_job_stride, size_t v_job_stride,
-                     bool timed = false, MfmaCoefOut* coef = nullptr);
+                     bool timed = false, MfmaCoefOut* coef = nullptr, const int8_t* prepacked = nullptr);
+// B-operand tiles of every limb straight from 16-bit decomposition digits (to_hat + packing fused, mfma_kernels.hip);
+// hand the buffer to matvec_mfma_impl as `prepacked` (njobs = 1)
+size_t mfma_prepacked_bytes(const lab_mat8* m, int ns);
+int digits_to_v8_impl(lab_ctx* c, const lab_mat8* m, const JobPtrs& src16, int ns, int ns_valid, int8_t* dst);
+uint32_t mat8_min_prime(const lab_ctx* c, const lab_mat8* m);
 bool mat8_matches(const lab_mat8* m, int basis, size_t nmat, size_t rows, size_t cols);
 int mat8_basis(const lab_mat8* m);
 // launch_matvec_partial wrapped in the profiling events when the hook is active

@@ -141,6 +141,10 @@ hipError_t launch_slot_transpose(uint32_t* out_plane, size_t out_set_stride, siz
                                  size_t rows, size_t rows_pad, size_t ns, size_t ns_valid, size_t njobs, size_t nsub, hipStream_t s);
 int gemm_i8_waves(int planes, size_t rt_count, size_t nt);   // waves per block (4 or 8) the launcher will use
 hipError_t launch_gemm_i8(const Gemm8Args& a, size_t nt, int waves, hipStream_t s);
+// 16-bit decomposition digits ([ktotal][64] per set, src16.p[s]) -> transform -> B-operand tiles of every limb
+// (dst + l*limb_stride), see k_digits_to_v8; digits must be below every limb prime
+hipError_t launch_digits_to_v8(const JobPtrs& src16, size_t ktotal, int8_t* dst, size_t limb_stride, size_t kt_count, int ns,
+                               int ns_valid, int nlimbs, const LimbTable* tabs, const int* planes, const size_t* nt, hipStream_t s);
 // tiled Gram: partial[chunk][i][k], gram_chunks(..) <= gram_num_chunks(n) chunks, to be summed with launch_sum_terms(rows = r*r)
 size_t gram_num_chunks(size_t n);
 size_t gram_chunks(size_t n, size_t r, int nlimbs, size_t njobs);

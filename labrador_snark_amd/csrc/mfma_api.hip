@@ -53,7 +53,7 @@ size_t mfma_scratch_bytes(const lab_mat8* m, int ns, size_t njobs) { return v8_j
 // limbs are bracketed by events.
 int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_mat8* m, ConstHatView V, size_t v_set_stride, int ns,
                      int ns_valid, void* scratch, size_t v_k_stride, size_t njobs, size_t out_job_stride, size_t v_job_stride,
-                     bool timed, MfmaCoefOut* coef) {
+                     bool timed, MfmaCoefOut* coef, const int8_t* prepacked) {
   const uint32_t* primes = m->basis ? c->dg_primes : c->primes;
   const size_t ktotal = m->nmat * m->cols;
   // Many 32-set jobs sharing the matrix (the Ajtai product of a batch): two source jobs are multiplied as ONE 64-set job,
@@ -77,8 +77,10 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
   for (int l = 0; l < m->nlimbs; l++) {
     const int pl = m->planes[l];
     const size_t nt = nt_for(ns, pl);
-    LAB_HIP(c, launch_pack_vectors_i8(ns, ns_valid, v8, V.base + (size_t)l * V.plane_stride, v_set_stride, v_k_stride, ktotal,
-                                      m->kt_count, nt, pl, njobs, v_job_stride, v8_stride, nsub, sub_stride_v, c->stream));
+    if (prepacked) v8 = const_cast<int8_t*>(prepacked) + (size_t)l * v8_stride * njobs;   // digits_to_v8_impl made every limb's tiles
+    else
+      LAB_HIP(c, launch_pack_vectors_i8(ns, ns_valid, v8, V.base + (size_t)l * V.plane_stride, v_set_stride, v_k_stride, ktotal,
+                                        m->kt_count, nt, pl, njobs, v_job_stride, v8_stride, nsub, sub_stride_v, c->stream));
     Gemm8Args g;
     g.out = out.base + (size_t)l * out.plane_stride; g.out_set_stride = out_set_stride; g.out_job_stride = out_job_stride;
     g.M8 = m->d[l]; g.V8 = v8; g.v8_job_stride = v8_stride;
@@ -123,6 +125,26 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
   }
   if (coef) coef->done = stage != nullptr;
   return LAB_OK;
+}
+
+// B-operand tiles of all limbs of `m` from 16-bit decomposition digits (one job of ns sets: set s at src16.p[s], [K][64]
+// words, K = m's sum length): dst holds mfma_prepacked_bytes(m, ns).  Digits must be below every limb prime of m's basis.
+size_t mfma_prepacked_bytes(const lab_mat8* m, int ns) { return v8_job_bytes(m, ns) * m->nlimbs; }
+int digits_to_v8_impl(lab_ctx* c, const lab_mat8* m, const JobPtrs& src16, int ns, int ns_valid, int8_t* dst) {
+  size_t nt[MAX_LIMBS] = {0, 0, 0, 0};
+  for (int l = 0; l < m->nlimbs; l++) nt[l] = nt_for(ns, m->planes[l]);
+  const size_t ktotal = m->nmat * m->cols;
+  if (m->kt_count * 32 > (ktotal + D - 1) / D * D)   // K tiles past the last 64 digits polynomials are padding: zero once
+    LAB_HIP(c, hipMemsetAsync(dst, 0, mfma_prepacked_bytes(m, ns), c->stream));
+  LAB_HIP(c, launch_digits_to_v8(src16, ktotal, dst, v8_job_bytes(m, ns), m->kt_count, ns, ns_valid, m->nlimbs,
+                                 m->basis ? c->dg_tabs : c->d_tabs, m->planes, nt, c->stream));
+  return LAB_OK;
+}
+uint32_t mat8_min_prime(const lab_ctx* c, const lab_mat8* m) {
+  const uint32_t* primes = m->basis ? c->dg_primes : c->primes;
+  uint32_t mn = primes[0];
+  for (int l = 1; l < m->nlimbs; l++) mn = primes[l] < mn ? primes[l] : mn;
+  return mn;
 }
 
 }  // namespace lab

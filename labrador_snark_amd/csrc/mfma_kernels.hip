@@ -149,6 +149,94 @@ k_pack_vectors_i8(int8_t* __restrict__ dst, const uint32_t* __restrict__ src, si
   }
 }
 
+// ---- decomposition digits -> B-operand tiles in one pass (the vectors of the outer commitment: to_hat of the digits
+// and k_pack_vectors_i8 fused, for every limb; the transform-domain copy of the digits never exists).
+// Block = 8 waves = 8 sets (proofs) x 64 consecutive polynomials k0..k0+63 of each set's digit array (16-bit words,
+// [K][64]).  Thread (set, k) loads its polynomial (128 B), and for every limb transforms it in registers (the caller
+// guarantees digits below every limb prime: no reduction), turns the 64 slot values into signed-digit words and hands
+// them to the block through LDS, 16 slots at a time; thread (slot, k block of 16, set) then gathers the 16 words of its
+// 16 k, picks each plane's byte with v_perm and stores 16 bytes per plane — the 8 sets of the block are 8 neighbouring
+// lanes of the B tile, i.e. one 128-byte line per (slot, plane, k block).
+constexpr int DV_ROW = 8 * D + 4;  // words per slot row of the exchange buffer: 8 sets x 64 k (+ padding, 16-byte aligned)
+
+struct PlaneCounts { int n[MAX_LIMBS]; unsigned nt[MAX_LIMBS]; };   // digit planes and column tiles per limb
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_digits_to_v8(const JobPtrs src, size_t ktotal, int8_t* __restrict__ dst, size_t limb_stride, unsigned kt_count, unsigned ns,
+               unsigned ns_valid, int nlimbs, const LimbTable* __restrict__ tabs, const PlaneCounts planes) {
+  __shared__ __attribute__((aligned(16))) uint32_t ex[16 * DV_ROW];   // [slot of the pass][set][k]: writes and reads conflict-free
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const size_t k0 = (size_t)blockIdx.x * D;
+  const unsigned s_mine = blockIdx.y * 8 + w;
+  uint32_t clo[D];
+  {
+    const bool have = s_mine < ns_valid && k0 + lane < ktotal;
+    const uint16_t* p = have ? static_cast<const uint16_t*>(src.p[s_mine]) + (k0 + lane) * D : nullptr;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      u32x4_t v = {0, 0, 0, 0};
+      if (have) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p) + i);
+      clo[8 * i] = v.x & 0xFFFFu; clo[8 * i + 1] = v.x >> 16; clo[8 * i + 2] = v.y & 0xFFFFu; clo[8 * i + 3] = v.y >> 16;
+      clo[8 * i + 4] = v.z & 0xFFFFu; clo[8 * i + 5] = v.z >> 16; clo[8 * i + 6] = v.w & 0xFFFFu; clo[8 * i + 7] = v.w >> 16;
+    }
+  }
+  // gather role: set (fastest: neighbouring lanes of the B tile), k block, slot inside the pass
+  const unsigned g_set = t & 7, g_kb = (t >> 3) & 3, g_jl = t >> 5;
+  const unsigned g_s = blockIdx.y * 8 + g_set;
+#pragma unroll 1
+  for (int l = 0; l < nlimbs; l++) {
+    uint32_t x[D];
+#pragma unroll
+    for (int k = 0; k < D; k++) x[k] = clo[k];
+    ntt64_forward(x, tabs + l);
+    const int pl = planes.n[l];
+    const uint32_t offs = digit_offsets(pl);
+    const unsigned nt_count = planes.nt[l];
+    int8_t* dl = dst + (size_t)l * limb_stride;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) ex[c * DV_ROW + w * D + lane] = signed_digit_word(x[16 * q + c], offs);
+      __syncthreads();
+      uint32_t wd[16];
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&ex[g_jl * DV_ROW + g_set * D + g_kb * 16 + 4 * b]);
+        wd[4 * b] = v.x; wd[4 * b + 1] = v.y; wd[4 * b + 2] = v.z; wd[4 * b + 3] = v.w;
+      }
+      const unsigned j = 16 * q + g_jl;
+      const size_t kt = k0 / 32 + g_kb / 2;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (i >= pl) break;
+        u32x4_t o;
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) {
+          const uint32_t sel = 0x04000400u + 0x01010101u * i;
+          const uint32_t lo = __builtin_amdgcn_perm(wd[4 * qq + 1], wd[4 * qq], sel);
+          const uint32_t hi = __builtin_amdgcn_perm(wd[4 * qq + 3], wd[4 * qq + 2], sel);
+          o[qq] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+        }
+        const unsigned n = i * ns + g_s, nt = n / 32, ln = ((g_kb & 1) << 5) | (n % 32);
+        if (kt < kt_count) *reinterpret_cast<u32x4_t*>(dl + (((size_t)j * kt_count + kt) * nt_count + nt) * 1024 + ln * 16) = o;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// one launch for every limb; sets past ns_valid and polynomials past ktotal come out as zero columns / rows.  K tiles past
+// ceil(ktotal / 64) * 2 (kt_count padding) are NOT written: the caller clears the buffer once.
+hipError_t launch_digits_to_v8(const JobPtrs& src16, size_t ktotal, int8_t* dst, size_t limb_stride, size_t kt_count, int ns,
+                               int ns_valid, int nlimbs, const LimbTable* tabs, const int* planes, const size_t* nt, hipStream_t s) {
+  if (ns % 8 || ns > 64 || nlimbs > MAX_LIMBS) return hipErrorInvalidValue;
+  PlaneCounts pc;
+  for (int l = 0; l < MAX_LIMBS; l++) { pc.n[l] = l < nlimbs ? planes[l] : 0; pc.nt[l] = l < nlimbs ? (unsigned)nt[l] : 0; }
+  hipLaunchKernelGGL(k_digits_to_v8, dim3((unsigned)((ktotal + D - 1) / D), (unsigned)(ns / 8)), dim3(512), 0, s, src16, ktotal, dst,
+                     limb_stride, (unsigned)kt_count, (unsigned)ns, (unsigned)ns_valid, nlimbs, tabs, pc);
+  return hipGetLastError();
+}
+
 // V_s[k] = src + s*set_stride + k*k_stride (words): k_stride = 64 for vectors stored set by set, r*64 for the columns of
 // an [n][r] witness matrix
 hipError_t launch_pack_vectors_i8(int ns, int ns_valid, int8_t* dst, const uint32_t* src, size_t set_stride, size_t k_stride,

@@ -199,6 +199,10 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   // int8-MFMA step 3: padded set count of the largest group and its scratch (B-operand tiles + int32 results)
   const int mf_ns = np > 32 ? 64 : np > 16 ? 32 : np > 8 ? 16 : 8;
   size_t mf_bytes = b8 ? mfma_scratch_bytes(b8, mf_ns, 1) + 4096 : 0;
+  // the digits of t go straight into B-operand tiles of every limb (transform + packing fused) when they are 16-bit words
+  // below every prime of B's basis
+  const bool fuse_t = b8 && in->b1 <= 65536 && in->b2 <= 65536 && (uint64_t)in->b1 <= mat8_min_prime(c, b8);
+  if (fuse_t && mfma_prepacked_bytes(b8, mf_ns) + 4096 > mf_bytes) mf_bytes = mfma_prepacked_bytes(b8, mf_ns) + 4096;
   const int a8_ns = r <= 8 ? 8 : r <= 16 ? 16 : 32;       // witness columns per Ajtai GEMM pass
   if (a8 && mfma_scratch_bytes(a8, a8_ns, np) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(a8, a8_ns, np) + 4096;
   if (a8d && mfma_scratch_bytes(a8d, a8_ns, np) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(a8d, a8_ns, np) + 4096;
@@ -345,13 +349,19 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if ((rc = from_hat_jobs(hG, rr, JP(&Job::cG), false))) return rc;
   // digits of t in [i][k][rho] order, into the basis of B
   LAB_HIP(c, launch_decompose_jobs(JP(&Job::cTdec), JP(&Job::cT), rk, q, (uint64_t)in->b1, t1, kappa, np, s, dig16));
-  if ((rc = to_hat_jobs(JP(&Job::cTdec), hTdec, rk * t1, true, (uint64_t)in->b1, dig16))) return rc;
+  if (!fuse_t && (rc = to_hat_jobs(JP(&Job::cTdec), hTdec, rk * t1, true, (uint64_t)in->b1, dig16))) return rc;
 
   // ================= step 3 (:101-132) for the whole batch: lhs_j = sum_{i,k} B_ik t_{j,i}^(k); B streamed once per group
   for (size_t j0 = 0; b8 && j0 < np;) {   // matrix cores: up to 64 proofs per pass over B, result written in place
     const size_t left = np - j0;
     const int ns = left > 32 ? 64 : left > 16 ? 32 : left > 8 ? 16 : 8, valid = (int)(left < (size_t)ns ? left : (size_t)ns);
-    if ((rc = matvec_mfma_impl(c, HD(j0, hlhs), perd * D, b8, HD(j0, hTdec), perd * D, ns, valid, mf_scratch, D, 1, 0, 0, true))) return rc;
+    if (fuse_t) {
+      JobPtrs dig;
+      for (int i = 0; i < valid; i++) dig.p[i] = jobs[j0 + i].cTdec;
+      if ((rc = digits_to_v8_impl(c, b8, dig, ns, valid, reinterpret_cast<int8_t*>(mf_scratch)))) return rc;
+    }
+    if ((rc = matvec_mfma_impl(c, HD(j0, hlhs), perd * D, b8, HD(j0, hTdec), perd * D, ns, valid, mf_scratch, D, 1, 0, 0, true, nullptr,
+                               fuse_t ? reinterpret_cast<const int8_t*>(mf_scratch) : nullptr))) return rc;
     j0 += valid;
   }
   for (size_t j0 = 0; !b8 && j0 < np;) {
