@@ -145,9 +145,14 @@ size_t mfma_scratch_bytes(const lab_mat8* m, int ns, size_t njobs);
 // ([limb][count][64] words, job stride coef->job_stride, set s -> polynomial s * coef->set_stride + row) instead of `out`;
 // coef->done tells whether that happened (else `out` holds the transform-domain results as usual)
 struct MfmaCoefOut { uint32_t* dense; size_t plane_stride, job_stride, set_stride; bool done; };
+// `gram`: the sets are the (at most 32) witness columns of each job and every limb has 3 planes — also produce
+// G[i][k] = sum_x V_i[x] V_k[x] per source job from the packed tiles (transform domain, basis of m): element i*r + k of
+// gram->out + job * gram->job_stride, plane l at + l * gram->plane_stride; gram->done tells whether that happened
+struct MfmaGramOut { uint32_t* out; size_t plane_stride, job_stride, r; bool done; };
 int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_mat8* m, ConstHatView V, size_t v_set_stride, int ns,
                      int ns_valid, void* scratch, size_t v_k_stride, size_t njobs, size_t out_job_stride, size_t v_job_stride,
-                     bool timed = false, MfmaCoefOut* coef = nullptr, const int8_t* prepacked = nullptr);
+                     bool timed = false, MfmaCoefOut* coef = nullptr, const int8_t* prepacked = nullptr,
+                     MfmaGramOut* gram = nullptr);
 // B-operand tiles of every limb straight from 16-bit decomposition digits (to_hat + packing fused, mfma_kernels.hip);
 // hand the buffer to matvec_mfma_impl as `prepacked` (njobs = 1)
 size_t mfma_prepacked_bytes(const lab_mat8* m, int ns);

@@ -53,7 +53,7 @@ size_t mfma_scratch_bytes(const lab_mat8* m, int ns, size_t njobs) { return v8_j
 // limbs are bracketed by events.
 int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_mat8* m, ConstHatView V, size_t v_set_stride, int ns,
                      int ns_valid, void* scratch, size_t v_k_stride, size_t njobs, size_t out_job_stride, size_t v_job_stride,
-                     bool timed, MfmaCoefOut* coef, const int8_t* prepacked) {
+                     bool timed, MfmaCoefOut* coef, const int8_t* prepacked, MfmaGramOut* gram) {
   const uint32_t* primes = m->basis ? c->dg_primes : c->primes;
   const size_t ktotal = m->nmat * m->cols;
   // Many 32-set jobs sharing the matrix (the Ajtai product of a batch): two source jobs are multiplied as ONE 64-set job,
@@ -71,6 +71,7 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
       njobs /= 2; ns = 64; v_job_stride *= 2;
     }
   }
+  bool gram_ok = true;
   int8_t* v8 = static_cast<int8_t*>(scratch);
   const size_t v8_stride = v8_job_bytes(m, ns);
   uint32_t* stage = (njobs > 1 || paired) ? reinterpret_cast<uint32_t*>(v8 + v8_stride * njobs) : nullptr;
@@ -116,6 +117,11 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
       c->prof_bytes += (double)D * pl * m->rt_count * m->kt_count * 1024 + (double)D * m->kt_count * nt * 1024 +
                        (double)ns_valid * m->rows * D * 4;
     }
+    if (gram && pl == 3 && !prepacked && ns >= 32 && gram->r <= 32 && (size_t)ns_valid == gram->r)   // one tile per plane
+      LAB_HIP(c, launch_gram_v8(v8, v8_stride, m->kt_count, (ktotal + 31) / 32, nt, paired ? 2 : 1, gram->r, njobs * (paired ? 2 : 1),
+                                gram->out + (size_t)l * gram->plane_stride, gram->job_stride, primes[l], g.pw, g.bias,
+                                (m->basis ? c->dg_tabs : c->d_tabs) + l, c->stream));
+    else if (gram) gram_ok = false;
     if (stage && coef)
       LAB_HIP(c, launch_intt_from_stage(stage, m->rows, m->rt_count * 32, ns, ns_valid, nsub, njobs, coef->dense + (size_t)l * coef->plane_stride,
                                         coef->job_stride, coef->set_stride, (m->basis ? c->dg_tabs : c->d_tabs) + l, c->stream));
@@ -124,6 +130,7 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
                                        nsub, c->stream));
   }
   if (coef) coef->done = stage != nullptr;
+  if (gram) gram->done = gram_ok;
   return LAB_OK;
 }
 

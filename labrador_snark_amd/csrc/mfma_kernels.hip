@@ -237,6 +237,73 @@ hipError_t launch_digits_to_v8(const JobPtrs& src16, size_t ktotal, int8_t* dst,
   return hipGetLastError();
 }
 
+// ---- G = S^T S of one proof from the B-operand tiles its witness columns were packed into for step 1 (3-plane limbs).
+// A B-operand tile (lane l: column l & 31, 16 consecutive k of half l >> 5) is byte for byte an A-operand tile with the
+// columns as rows, so the tiles of plane i and plane i' multiply directly: D[i][i'][col][col'] = sum_x S_i[x][col] S_i'[x][col'].
+// One wave per (proof, NTT slot): 3 tiles per k tile, 9 MFMAs, all nine int32 tiles of the wave have the same element
+// in the same register of the same lane, so the recombination needs no LDS.  Blocks of one proof share an XCD (the 64
+// slots of a result line are written by 64 blocks).
+__global__ void __launch_bounds__(64)
+k_gram_v8(const int8_t* __restrict__ V8, size_t v8_job_stride, unsigned kt_count, unsigned kt_real, unsigned nt_count, unsigned sub,
+          unsigned r, uint32_t* __restrict__ out, size_t out_job_stride, uint32_t p, uint32_t pw0, uint32_t pw1, uint32_t pw2,
+          uint32_t pw3, uint32_t pw4, uint32_t bias, const LimbTable* __restrict__ tab) {
+  const unsigned job = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
+  const unsigned g = job / sub, sb = job % sub;
+  const u32x4_t* base = reinterpret_cast<const u32x4_t*>(V8 + (size_t)g * v8_job_stride) + (size_t)j * kt_count * nt_count * 64 + lane;
+  i32x16_t acc[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[a][b][e] = 0;
+  auto load = [&](unsigned kt, u32x4_t (&t)[3]) {
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) t[pl] = base[((size_t)kt * nt_count + pl * sub + sb) * 64];
+  };
+  u32x4_t cur[3], nxt[3];
+  load(0, cur);
+  for (unsigned kt = 0; kt < kt_real; kt++) {
+    if (kt + 1 < kt_real) load(kt + 1, nxt);
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        const i32x4_t af = {(int)cur[a].x, (int)cur[a].y, (int)cur[a].z, (int)cur[a].w};
+        const i32x4_t bf = {(int)cur[b].x, (int)cur[b].y, (int)cur[b].z, (int)cur[b].w};
+        acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[a][b], 0, 0, 0);
+      }
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) cur[pl] = nxt[pl];
+  }
+  const uint32_t pw[5] = {pw0, pw1, pw2, pw3, pw4};
+  const uint32_t p2 = tab->p2, pinv = tab->pinv, r2 = tab->r2;
+  uint32_t* o = out + (size_t)job * out_job_stride + j;
+  const unsigned col = lane & 31;
+#pragma unroll
+  for (int e = 0; e < 16; e++) {
+    const unsigned row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+    uint64_t s64 = 0;                               // 9 products < 2^32 * p: the high word stays below 9p < 2^27
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) s64 += (uint64_t)((uint32_t)acc[a][b][e] ^ 0x80000000u) * pw[a + b];
+    uint32_t hi = (uint32_t)(s64 >> 32);
+    hi = min(hi, hi - 8 * p); hi = min(hi, hi - 4 * p); hi = min(hi, hi - p2); hi = min(hi, hi - p);
+    const uint32_t v = mont_mul(redc64(((uint64_t)hi << 32) | (uint32_t)s64, p, pinv), r2, p, pinv);
+    if (row < r && col < r) o[((size_t)row * r + col) * D] = csub(v + p - bias, p);
+  }
+}
+
+hipError_t launch_gram_v8(const int8_t* V8, size_t v8_job_stride, size_t kt_count, size_t kt_real, size_t nt_count, size_t sub, size_t r,
+                          size_t njobs, uint32_t* out_plane, size_t out_job_stride, uint32_t p, const uint32_t* pw, uint32_t bias,
+                          const LimbTable* tab, hipStream_t s) {
+  if (r > 32 || njobs == 0 || p >= (1u << 23)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_gram_v8, dim3((unsigned)njobs, D), dim3(64), 0, s, V8, v8_job_stride, (unsigned)kt_count, (unsigned)kt_real,
+                     (unsigned)nt_count, (unsigned)sub, (unsigned)r, out_plane, out_job_stride, p, pw[0], pw[1], pw[2], pw[3], pw[4], bias, tab);
+  return hipGetLastError();
+}
+
 // V_s[k] = src + s*set_stride + k*k_stride (words): k_stride = 64 for vectors stored set by set, r*64 for the columns of
 // an [n][r] witness matrix
 hipError_t launch_pack_vectors_i8(int ns, int ns_valid, int8_t* dst, const uint32_t* src, size_t set_stride, size_t k_stride,

@@ -174,6 +174,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if (axpy_partial_elems(pairs * t1, k2) > partd_elems) partd_elems = axpy_partial_elems(pairs * t1, k2);
   const size_t hpartd = hd.take(partd_elems);
   const size_t hSd = a8d ? hd.take(nr) : 0, hTd = a8d ? hd.take(rk) : 0;   // witness and t = A s in the digit basis
+  const size_t hGd = a8d ? hd.take(rr) : 0;                                 // G = S^T S from the same packed operands
   const int Ld = basis_nlimbs(c, bdig);
   const LimbTable* tabsd = basis_tabs(c, bdig);
   const size_t per = ha.total, perd = hd.total;
@@ -306,7 +307,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   // ================= step 1 (src/proofgen.rs:41-49): t_i = A s_i for every column of every proof; A is shared, so the
   // whole batch is one (kappa x n)(n x np*r) product (falls back to one launch per proof for shapes it does not take)
   uint64_t* norm_sums = host_stage + np * (256 + 256 + D);
-  bool t_in_dense = false;
+  bool t_in_dense = false, g_in_digit = false;
   if (a8d) {  // matrix cores, in the basis of B, C, D (see a8d above): S once more into that basis, its norm summed on the way
     LAB_HIP(c, hipMemsetAsync(norm_sums, 0, np * 8, s));
     // (coefficients above beta_bound are caught by the norm sum and the batch is redone: the transform may assume the bound)
@@ -315,9 +316,11 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     for (size_t i0 = 0; i0 < r; i0 += 32) {
       const int valid = (int)(r - i0 < 32 ? r - i0 : 32);
       MfmaCoefOut co{dense_tmp + i0 * kappa * D, rk * D, tmp_js, kappa, false};   // t is only wanted as coefficients
+      MfmaGramOut go{HD(0, hGd).base, hatd_words, perd * D, r, false};            // step 2 (G = S^T S) from the same tiles
       if ((rc = matvec_mfma_impl(c, HD(0, hTd + i0 * kappa), kappa * D, a8d, HD(0, hSd + i0), D, a8_ns, valid, mf_scratch, r * D, np,
-                                 perd * D, perd * D, false, &co))) return rc;
+                                 perd * D, perd * D, false, &co, nullptr, r <= 32 ? &go : nullptr))) return rc;
       t_in_dense = co.done;
+      g_in_digit = go.done;
     }
   } else if (a8) {   // matrix cores: per proof, its r witness columns as the vector sets (element x of column i at S[x][i])
     // one launch per limb and 32 columns: the proofs are the kernel's jobs and share the A stream through L2
@@ -345,8 +348,12 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     return rc;
   }
   // step 2 (:59-70): G = S^T S
-  if ((rc = gram_jobs(hG, hS, hS))) return rc;
-  if ((rc = from_hat_jobs(hG, rr, JP(&Job::cG), false))) return rc;
+  if (g_in_digit) {
+    if ((rc = from_hat_jobs(hGd, rr, JP(&Job::cG), true))) return rc;
+  } else {
+    if ((rc = gram_jobs(hG, hS, hS))) return rc;
+    if ((rc = from_hat_jobs(hG, rr, JP(&Job::cG), false))) return rc;
+  }
   // digits of t in [i][k][rho] order, into the basis of B
   LAB_HIP(c, launch_decompose_jobs(JP(&Job::cTdec), JP(&Job::cT), rk, q, (uint64_t)in->b1, t1, kappa, np, s, dig16));
   if (!fuse_t && (rc = to_hat_jobs(JP(&Job::cTdec), hTdec, rk * t1, true, (uint64_t)in->b1, dig16))) return rc;
