@@ -24,7 +24,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import numpy as np
-import torch
 
 D = 64
 Q_REF33 = (1 << 32) + 15
@@ -96,6 +95,7 @@ def make_inputs(k, q, seed, dev=None):
         for j in range(i):
             a[i, j] = a[j, i]
     if dev is not None:
+        import torch
         # the 512 MiB projection tape is drawn on the device (numpy needs seconds per proof for it): two fair bits
         # per entry, {00 -> -1, 01/10 -> 0, 11 -> 1}
         g = torch.Generator(device=dev)
@@ -113,7 +113,71 @@ def make_inputs(k, q, seed, dev=None):
 
 def checksum_u64(t):
     """Order-independent 64-bit checksum of a device tensor of residues (sum mod 2^63)."""
+    import torch
     return (t.to(torch.int64).sum() & ((1 << 62) - 1)).reshape(1)
+
+
+def build_workload(lab, ctx, k, q, dev, nbatch, seed0, crs_seed, use_mfma=True, basis23=True, compact=True):
+    """The resident inputs of one bench step: `nbatch` instances (seeds seed0 .. seed0+nbatch-1; witness, state, tape as
+    device tensors) and the CRS they share.  tests/test_gpu_bench_config.py builds the same objects and checks the
+    transcripts lab_prove_core_batch returns for them against the oracle."""
+    import torch
+    n, r = k.N, k.R
+
+    def dev64(x):
+        return torch.from_numpy(np.ascontiguousarray(x).view(np.int64)).to(dev)
+
+    dSs, sts, dtapes = [], [], []
+    for j in range(nbatch):
+        S, phi, a, tape = make_inputs(k, q, seed=seed0 + j, dev=dev)
+        # State::gen_f's b (src/structs.rs:320-341, 373) on the product's own kernels: b' = its constant term
+        b_poly = lab.gen_f_b(ctx, S, phi, a, n, r)
+        dSs.append(dev64(S))
+        sts.append(lab.State(dev64(phi), dev64(a), int(b_poly[0])))
+        dtapes.append(dict(Pi=tape["Pi"] if torch.is_tensor(tape["Pi"]) else torch.from_numpy(tape["Pi"]).to(dev),
+                           psi=tape["psi"], omega=dev64(tape["omega"]),
+                           alpha=dev64(tape["alpha"]), beta=dev64(tape["beta"]), c=dev64(tape["c"])))
+    # B, C, D are only ever multiplied by decomposition digits: keep them in the digit basis
+    crs = lab.ResidentCRS(ctx, k, compact=compact, mfma_basis=basis23).fill_synthetic(crs_seed)
+    if use_mfma:
+        crs.pack_mfma(drop_B=True)     # one-time, like the CRS expansion: outside every timed region
+    torch.cuda.synchronize()
+    return dSs, sts, dtapes, crs
+
+
+def launch_ranks(n_gpus, argv):
+    """`bench.py --gpus N` without a launcher around it: start N ranks (one process per GPU) with torch.distributed.run
+    BEFORE this process imports torch or touches the GPU, relay their output (rank 0 prints the JSON line) and exit
+    with the children's status."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def launcher_selftest(args):
+    """LAB_BENCH_SELFTEST=1: the rank side of the launcher without a GPU (tests/test_distributed_cpu.py): rendezvous over
+    gloo, count the ranks with an all-reduce, rank 0 prints a stub line.  LAB_BENCH_SELFTEST=fail: rank 1 exits non-zero."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ["LAB_BENCH_SELFTEST"] == "fail" and rank == world - 1:
+        return 3
+    seen = torch.ones(1, dtype=torch.int64)
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.all_reduce(seen)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ranks_seen": int(seen.item())}))
+    return 0
 
 
 def main():
@@ -141,6 +205,12 @@ def main():
                          "the matrix cores); auto = mfma23 on the matrix-core path, else u16")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if os.environ.get("LAB_BENCH_SELFTEST"):
+        sys.exit(launcher_selftest(args))
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -165,36 +235,12 @@ def main():
     ctx = lab.Context(q, gpu_index, max(65536, n * r + r * r))
     ctx.use_torch_stream()
 
-    def dev64(x):
-        return torch.from_numpy(np.ascontiguousarray(x).view(np.int64)).to(dev)
-
     # instances 50 + rank*batch + j: witness/state/tape resident on the device
     nbatch = max(1, args.batch)
-    dSs, sts, dtapes = [], [], []
-    for j in range(nbatch):
-        S, phi, a, tape = make_inputs(k, q, seed=50 + rank * nbatch + j, dev=dev)
-        # b' = const term of b = sum a_ij<s_i,s_j> + sum <phi_i,s_i> (src/structs.rs:320-341, 373): computed on the
-        # GPU with the product's own kernels (the oracle is not on the product path)
-        hS, hphi, ha = ctx.vec_from(S), ctx.vec_from(phi), ctx.vec_from(a)
-        G = lab.gram(ctx, hS, hS, n, r)
-        Gc = ctx.vec_from(G.store())
-        t1v = lab.polynomial_vec_inner_product(ctx, ha, Gc).store()[0]
-        t2v = lab.polynomial_vec_inner_product(ctx, hphi, hS).store()[0]
-        b_prime = int((int(t1v[0]) + int(t2v[0])) % q)
-        for v in (hS, hphi, ha, G, Gc):
-            v.close()
-        dSs.append(dev64(S))
-        sts.append(lab.State(dev64(phi), dev64(a), b_prime))
-        dtapes.append(dict(Pi=tape["Pi"] if torch.is_tensor(tape["Pi"]) else torch.from_numpy(tape["Pi"]).to(dev),
-                           psi=tape["psi"], omega=dev64(tape["omega"]),
-                           alpha=dev64(tape["alpha"]), beta=dev64(tape["beta"]), c=dev64(tape["c"])))
-    # B, C, D are only ever multiplied by decomposition digits: keep them in the digit basis (u16 small limb)
     use_mfma = args.step3 == "mfma" or (args.step3 == "auto" and nbatch > 8)
     basis23 = not args.no_compact_crs and (args.digit_basis == "mfma23" or (args.digit_basis == "auto" and use_mfma))
-    crs = lab.ResidentCRS(ctx, k, compact=not args.no_compact_crs, mfma_basis=basis23).fill_synthetic(1000 + 10 * rank)
-    if use_mfma:
-        crs.pack_mfma(drop_B=True)     # one-time, like the CRS expansion: outside every timed region
-    torch.cuda.synchronize()
+    dSs, sts, dtapes, crs = build_workload(lab, ctx, k, q, dev, nbatch, 50 + rank * nbatch, 1000 + 10 * rank, use_mfma=use_mfma,
+                                           basis23=basis23, compact=not args.no_compact_crs)
 
     def step():
         if nbatch == 1:

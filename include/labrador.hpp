@@ -315,6 +315,7 @@ class Prover {  // src/proofgen.rs:14-28
   static lab_prove_input input(const RuntimeConstants& k, const std::vector<Rq>& witness, const State& st, const ResidentCRS& crs,
                                const ChallengeTape& tape) {
     lab_prove_input in{};
+    in.struct_size = sizeof(lab_prove_input);
     in.n = k.N; in.r = k.R; in.kappa = k.KAPPA; in.kappa1 = k.KAPPA_1; in.kappa2 = k.KAPPA_2;
     in.b1 = k.B_1; in.b2 = k.B_2; in.t1 = (int)k.T_1; in.t2 = (int)k.T_2; in.beta_bound = k.BETA_BOUND;
     in.S = witness[0].data(); in.phi = st.phi[0].data(); in.a = st.a[0].data(); in.b_prime = st.b_prime;

@@ -261,6 +261,8 @@ int lab_jl_project(lab_ctx *ctx, int64_t *proj, const int8_t *Pi, const uint64_t
  * resident transform-domain matrices.  kappa, kappa1, kappa2 are explicit (the reference hard-wires all three to
  * n*64, src/constants.rs:237-239).  Pair index of (i<=j): i*r - i(i-1)/2 + (j-i) (src/structs.rs:101-106). */
 typedef struct {
+  size_t struct_size;      /* = sizeof(lab_prove_input): any other value is refused with LAB_ERR_ARG, so a binding built
+                            * against an older (shorter) layout is caught instead of being read past its end */
   size_t n, r, kappa, kappa1, kappa2;
   int64_t b1, b2;          /* RuntimeConstants::B_1, B_2 (src/constants.rs:245,247) */
   int t1, t2;              /* RuntimeConstants::T_1, T_2 (src/constants.rs:244,246) */

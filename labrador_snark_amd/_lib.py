@@ -50,7 +50,7 @@ class BppCheckFailed(LabradorError, AssertionError):
 
 
 class lab_prove_input(C.Structure):
-    _fields_ = [("n", C.c_size_t), ("r", C.c_size_t), ("kappa", C.c_size_t), ("kappa1", C.c_size_t),
+    _fields_ = [("struct_size", C.c_size_t), ("n", C.c_size_t), ("r", C.c_size_t), ("kappa", C.c_size_t), ("kappa1", C.c_size_t),
                 ("kappa2", C.c_size_t), ("b1", C.c_int64), ("b2", C.c_int64), ("t1", C.c_int), ("t2", C.c_int),
                 ("beta_bound", C.c_int64), ("S", C.c_void_p), ("phi", C.c_void_p), ("a", C.c_void_p),
                 ("b_prime", C.c_uint64), ("A", C.c_void_p), ("a_off", C.c_size_t), ("B", C.c_void_p),

@@ -377,7 +377,7 @@ extern "C" int lab_ctx_profile_begin(lab_ctx* c) {
 }
 
 extern "C" const char* lab_ctx_profile_kernel(const lab_ctx* c) {
-  return c ? c->prof_kernel : "";
+  return c ? c->prof_kernel.c_str() : "";
 }
 
 extern "C" int lab_ctx_prove_flags(const lab_ctx* c) { return c ? c->prove_flags : 0; }

@@ -45,7 +45,7 @@ struct lab_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   size_t prof_used = 0;
   double prof_bytes = 0.0;
-  const char* prof_kernel = "";   // kernel the last profiled mat-vec launch was dispatched to
+  std::string prof_kernel;        // kernel the last profiled mat-vec launch was dispatched to
   int prove_flags = 0;            // last lab_prove_core[_batch]: 1 = step 1 ran in the digit basis, 2 = tried and redone in the main basis
 };
 

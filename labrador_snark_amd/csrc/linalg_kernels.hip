@@ -754,17 +754,13 @@ k_matvec_bcast_dma(const BcastArgs a) {
 }
 
 static void set_last_matvec_kernel(const char* n);
-// tile shape per matrix type and column count; LAB_BCAST_TC / LAB_BCAST_DEPTH (environment) override it for tuning
+// tile shape per matrix type and column count: 4 columns x 2 ring slots when the column count allows it, else 2 x 3
+// (measured round 1: the other points of {2, 4} x {2, 3} are slower or do not fit the LDS)
 template <typename MT, int NB>
 static hipError_t launch_bcast_dma(const BcastArgs& a, dim3 g, hipStream_t s) {
-  static const int env_tc = getenv("LAB_BCAST_TC") ? atoi(getenv("LAB_BCAST_TC")) : 0;
-  static const int env_depth = getenv("LAB_BCAST_DEPTH") ? atoi(getenv("LAB_BCAST_DEPTH")) : 0;
-  int tc = a.cols % 4 == 0 ? 4 : 2, depth = tc == 4 ? 2 : 3;
-  if (env_tc == 2 || (env_tc == 4 && a.cols % 4 == 0)) { tc = env_tc; depth = tc == 4 ? 2 : 3; }
-  if (env_depth == 2 || env_depth == 3) depth = env_depth;
-  if (tc == 4 && depth == 3 && (sizeof(MT) == 4 || NB * 4 * 256 * 3 + 3 * 33280 > 160 * 1024)) depth = 2;   // LDS budget
+  const int tc = a.cols % 4 == 0 ? 4 : 2, depth = tc == 4 ? 2 : 3;
   if (sizeof(MT) == 4 && a.ngroups == 1 && a.m_cs == (size_t)D) {   // a mat-vec launch (not the Ajtai / C, D shapes)
-    static char name[64];
+    char name[64];
     snprintf(name, sizeof name, "k_matvec_bcast_dma<unsigned int, %d, %d, %d>", NB, tc, depth);
     set_last_matvec_kernel(name);
   }
@@ -915,9 +911,10 @@ static hipError_t launch_matvec_nb(int nb, uint32_t* partial, size_t partial_ps,
 
 // name of the kernel the last u32 mat-vec dispatch chose (for lab_ctx_profile_kernel)
 static void set_last_matvec_kernel(const char* n);
-static const char* g_last_matvec_kernel = "k_matvec_partial<unsigned int, 1>";
+// name of the kernel the calling thread's most recent mat-vec launch went to (copied into the context by the caller)
+static thread_local char g_last_matvec_kernel[64] = "k_matvec_partial<unsigned int, 1>";
 const char* matvec_kernel_name() { return g_last_matvec_kernel; }
-static void set_last_matvec_kernel(const char* n) { g_last_matvec_kernel = n; }
+static void set_last_matvec_kernel(const char* n) { snprintf(g_last_matvec_kernel, sizeof g_last_matvec_kernel, "%s", n); }
 
 hipError_t launch_matvec_partial(HatView partial, ConstHatView M, ConstHatView V, size_t nmat, size_t rows,
                                  size_t cols, int nlimbs, const LimbTable* tabs, hipStream_t s, size_t njobs, size_t js) {

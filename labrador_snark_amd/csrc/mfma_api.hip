@@ -20,10 +20,13 @@ struct lab_mat8 {
 
 namespace lab {
 
-int mfma_planes(uint32_t p) {   // digits d_i in [-128,127] (the last one unrestricted within i8) covering [0, p)
-  int bits = 0;
-  while (bits < 32 && ((uint64_t)1 << bits) < p) bits++;   // p - 1 < 2^bits
-  return (bits + 1 + 7) / 8;                                // 2 below 2^15, 3 below 2^23, else 4
+int mfma_planes(uint32_t p) {   // smallest P such that every residue in [0, p) has P signed base-256 digits in [-128, 127]:
+  uint64_t top = 0;             // the largest such number is 127 * (256^P - 1) / 255 (32639, 8355711, 2139127679): a prime in
+  for (int planes = 1; planes <= 4; planes++) {   // (8355711, 2^23) needs 4 planes although it has 23 bits
+    top = top * 256 + 127;
+    if ((uint64_t)p - 1 <= top) return planes;
+  }
+  return 5;                     // p > 2139127680: not representable in 4 planes (lab_mat8_pack refuses)
 }
 
 // column tiles for ns sets whose residues need `planes_v` digit planes
@@ -60,9 +63,8 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
   // so every matrix tile fetched from L2 feeds 8 column tiles instead of 4 (the launch is bound by that operand traffic).
   const size_t nsub = ns;                                    // sets per source job
   size_t sub_stride_v = 0;
-  static const bool no_pair = getenv("LAB_GEMM_NO_PAIR") != nullptr;
   bool paired = false;
-  if (!no_pair && njobs >= 2 && njobs % 2 == 0 && ns == 32) {
+  if (njobs >= 2 && njobs % 2 == 0 && ns == 32) {
     bool same = m->planes[0] >= 3;                           // every limb with 4 (or every limb with 3) planes
     for (int l = 1; l < m->nlimbs; l++) same = same && m->planes[l] == m->planes[0];
     if (same) {
@@ -110,7 +112,7 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
     LAB_HIP(c, launch_gemm_i8(g, nt, waves, c->stream));
     if (prof) {
       LAB_HIP(c, hipEventRecord(c->prof_events[c->prof_used++].second, c->stream));
-      static char kname[48];
+      char kname[48];
       snprintf(kname, sizeof kname, "k_gemm_i8<%d, %d>", (int)nt, waves);
       c->prof_kernel = kname;
       // the matrix digit planes once, the B-operand tiles once per 32-row block (from L2), the residues out
@@ -171,6 +173,11 @@ extern "C" int lab_mat8_pack(lab_ctx* c, const lab_vec* M, size_t m_off, size_t 
   m->rt_count = (rows + 31) / 32;
   m->kt_count = ((nmat * cols + 31) / 32 + 11) / 12 * 12;   // the GEMM walks K in stages of 4 k-tiles, 3 stages per loop trip
   const uint32_t* primes = M->basis ? c->dg_primes : c->primes;
+  for (int l = 0; l < m->nlimbs; l++)
+    if (mfma_planes(primes[l]) > 4) {
+      delete m;
+      return fail(c, LAB_ERR_RANGE, "lab_mat8_pack: limb prime %u does not fit four signed byte planes", primes[l]);
+    }
   const int nfull = M->planes32();
   for (int l = 0; l < m->nlimbs; l++) {
     m->planes[l] = mfma_planes(primes[l]);

@@ -587,11 +587,9 @@ hipError_t launch_slot_transpose(uint32_t* out_plane, size_t out_set_stride, siz
 }
 
 // Blocks of 8 waves (two row tiles per B stage) when the limb has 4 planes, at least 2 row tiles and at least 2 column
-// tiles; the caller derives rgroups from gemm_i8_waves().  LAB_GEMM_WAVES=4 in the environment keeps 4-wave blocks.
+// tiles; 6 (3) waves for a 3-plane limb with at least 2 (with 1) row tiles.  The caller derives rgroups from this.
 int gemm_i8_waves(int planes, size_t rt_count, size_t nt) {
-  static const int env = getenv("LAB_GEMM_WAVES") ? atoi(getenv("LAB_GEMM_WAVES")) : 0;
-  if (planes == 3) return rt_count >= 2 && env != 3 ? 6 : 3;
-  if (env == 4) return 4;
+  if (planes == 3) return rt_count >= 2 ? 6 : 3;
   return planes == 4 && rt_count >= 2 && nt >= 2 ? 8 : 4;
 }
 

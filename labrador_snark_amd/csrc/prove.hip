@@ -70,8 +70,12 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if (np == 0) return LAB_OK;
   PtrCacheScope ptr_cache;   // every boundary pointer is classified host/device once per call
   if (!ins || !outs) return fail(c, LAB_ERR_ARG, "lab_prove_core: null argument");
-  for (size_t j = 0; j < np; j++)
+  for (size_t j = 0; j < np; j++) {
     if (!ins[j] || !outs[j]) return fail(c, LAB_ERR_ARG, "lab_prove_core: null argument");
+    if (ins[j]->struct_size != sizeof(lab_prove_input))
+      return fail(c, LAB_ERR_ARG, "lab_prove_core: lab_prove_input.struct_size is %zu, this library's layout has %zu bytes (stale binding?)",
+                  ins[j]->struct_size, sizeof(lab_prove_input));
+  }
   if (np > (size_t)MAX_JOBS) {   // the per-proof kernels serve up to MAX_JOBS proofs per launch
     int first = LAB_OK;
     for (size_t j0 = 0; j0 < np; j0 += MAX_JOBS) {

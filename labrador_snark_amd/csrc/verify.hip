@@ -23,6 +23,9 @@ extern "C" int lab_verify_core(lab_ctx* c, const lab_prove_input* in, const lab_
                                int64_t bconst, double beta_prime, int* failed_line, double* line14_sum) {
   if (!c) return LAB_ERR_ARG;
   if (!in || !pf || !b_poly || !failed_line) return fail(c, LAB_ERR_ARG, "lab_verify_core: null argument");
+  if (in->struct_size != sizeof(lab_prove_input))
+    return fail(c, LAB_ERR_ARG, "lab_verify_core: lab_prove_input.struct_size is %zu, this library's layout has %zu bytes (stale binding?)",
+                in->struct_size, sizeof(lab_prove_input));
   const size_t n = in->n, r = in->r, kappa = in->kappa, k1 = in->kappa1, k2 = in->kappa2;
   const int t1 = in->t1, t2 = in->t2;
   if (n == 0 || r == 0 || kappa == 0 || k1 == 0) return fail(c, LAB_ERR_ARG, "lab_verify_core: empty dimension");

@@ -199,11 +199,50 @@ class CRS:
         return res
 
 
-class State:
-    """The parts of src/structs.rs:269-286 the prover reads: phi_k[0], a_prime_k[0], b_prime_k[0]."""
+def gen_f_b(ctx, witness, phi, a, n, r):
+    """The `b` of State::gen_f (src/structs.rs:316-341): b = sum_{i,j} a_ij <s_i, s_j> + sum_i <phi_i, s_i>, on the
+    Gram / inner-product kernels.  witness, phi: [n][r][64]; a: [r][r][64] (symmetric); returns b as uint64[64].
+    G goes through the coefficient domain before it is multiplied again (product depth 1, like everywhere)."""
+    from .api import gram, polynomial_vec_inner_product
+    hS, hphi, ha = ctx.vec_from(witness), ctx.vec_from(phi), ctx.vec_from(a)
+    G = gram(ctx, hS, hS, n, r)
+    Gc = ctx.vec_from(G.store())
+    t1 = polynomial_vec_inner_product(ctx, ha, Gc).store()[0]           # sum_ij a_ij g_ij
+    t2 = polynomial_vec_inner_product(ctx, hphi, hS).store()[0]         # sum_i <phi_i, s_i>: [n][r] x [n][r] element-wise
+    q = np.uint64(ctx.q)
+    b = (t1 + t2) % q                                                   # residues < 2^40: no overflow in u64
+    for v in (hS, hphi, ha, G, Gc):
+        v.close()
+    return b
 
-    def __init__(self, phi, a, b_prime):
-        self.phi, self.a, self.b_prime = phi, a, int(b_prime)
+
+class State:
+    """The parts of src/structs.rs:269-286 the prover and verifier read: phi_k[0] (= phi_prime_k[0]), a_k[0]
+    (= a_prime_k[0]), b_k[0] and b_prime_k[0] = b_k[0].eval(0)."""
+
+    def __init__(self, phi, a, b_prime, b=None):
+        self.phi, self.a, self.b_prime, self.b = phi, a, int(b_prime), b
+
+    @classmethod
+    def new(cls, ctx, witness, constants, rng):
+        """State::new / gen_f (src/structs.rs:289-387) with a numpy Generator standing in for thread_rng: a_constraints
+        symmetric with a_ij (i <= j in generation order) uniform in [0, q)^64, phi uniform, b computed on the GPU."""
+        k, q = constants, ctx.q
+        a = np.zeros((k.R, k.R, D), dtype=np.uint64)
+        filled = np.zeros((k.R, k.R), dtype=bool)
+        for i in range(k.R):
+            for j in range(k.R):
+                a_ij = rng.integers(0, q, size=D, dtype=np.uint64)      # drawn for every (i, j) like the reference
+                if not filled[i, j]:                                     # `== Rq::new(vec![])`: still unset (src/structs.rs:297)
+                    a[i, j] = a_ij
+                    a[j, i] = a_ij
+                    filled[i, j] = filled[j, i] = True
+        phi = np.empty((k.N, k.R, D), dtype=np.uint64)
+        for i in range(k.R):
+            for j in range(k.N):
+                phi[j, i] = rng.integers(0, q, size=D, dtype=np.uint64)
+        b = gen_f_b(ctx, witness, phi, a, k.N, k.R)
+        return cls(phi, a, int(b[0]), b)
 
 
 class Transcript:
@@ -259,6 +298,7 @@ def _out_shapes(k):
 def _io_template(k, crs):
     """The fields of lab_prove_input that are the same for every proof under one CRS."""
     pin = _lib.lab_prove_input()
+    pin.struct_size = C.sizeof(_lib.lab_prove_input)
     pin.n, pin.r, pin.kappa, pin.kappa1, pin.kappa2 = k.N, k.R, k.KAPPA, k.KAPPA_1, k.KAPPA_2
     pin.b1, pin.b2, pin.t1, pin.t2, pin.beta_bound = k.B_1, k.B_2, k.T_1, k.T_2, k.BETA_BOUND
     pin.A, pin.B, pin.C, pin.Dm = crs.A._h, (crs.B._h if crs.B is not None else None), crs.C._h, crs.Dm._h
@@ -359,6 +399,7 @@ def verify_core(ctx, k, st, b_poly, crs, T, tape=None):
     tape = tape if tape is not None else T.tape
     n, r = k.N, k.R
     pin = _lib.lab_prove_input()
+    pin.struct_size = C.sizeof(_lib.lab_prove_input)
     pin.n, pin.r, pin.kappa, pin.kappa1, pin.kappa2 = n, r, k.KAPPA, k.KAPPA_1, k.KAPPA_2
     pin.b1, pin.b2, pin.t1, pin.t2, pin.beta_bound = k.B_1, k.B_2, k.T_1, k.T_2, k.BETA_BOUND
     keep = []

@@ -244,7 +244,7 @@ def test_sharded_outer_commitment_single_rank(contexts):
     lo, hi = parallel.ik_shard(r, t1, 0, 1)
     assert (lo, hi) == (0, r * t1)
     got = parallel.sharded_outer_commitment(ctx, B, V, hi - lo, kappa1, kappa, q)
-    assert np.array_equal(got.cpu().numpy().view(np.uint64), full)
+    assert np.array_equal(got.cpu().numpy().view(np.uint64)[0], full)
 
 
 @pytest.mark.parametrize("nb", [2, 4, 8])
@@ -431,3 +431,155 @@ def test_mat8_misuse_is_refused(contexts):
         lab.matvec_sum_mfma(ctx, M8, ctx.vec(8), 8)          # V too short for 8 sets
     M8.close()
     big.close()
+
+
+def _signed_digits(x, planes):
+    """signed base-256 digits of x as the packing kernels produce them (mfma_kernels.hip: signed_digits)"""
+    d = []
+    for i in range(planes):
+        if i < planes - 1:
+            lo = ((x & 0xFF) ^ 0x80) - 0x80
+            d.append(lo)
+            x = (x - lo) >> 8
+        else:
+            d.append(x)
+    return d
+
+
+def test_matvec_sum_mfma_prime_between_8355711_and_2p23():
+    # a directly NTT-friendly prime just below 2^23 (the Dilithium prime 8380417 = 2^23 - 2^13 + 1): residues above
+    # 127 * 65793 = 8355711 do not fit three signed bytes, so the packed form must use four planes — full-range residues
+    # (q - 1 in both operands) against the oracle
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    q = 8380417
+    assert _signed_digits(q - 1, 3)[2] > 127          # the three-plane form would wrap its top digit
+    ctx = lab.Context(q, 0)
+    assert ctx.nlimbs == 1 and ctx.primes == [q]
+    rng = np.random.default_rng(23)
+    ns, nmat, rows, cols = 8, 2, 40, 150
+    M = rp(rng, q, nmat, rows, cols)
+    V = rp(rng, q, ns, nmat, cols)
+    M[0, :3] = q - 1
+    M[1, 5] = 8355712
+    V[1] = q - 1
+    V[2, :, :, ::2] = 8355712
+    hM, hV = ctx.vec_from(M), ctx.vec_from(V)
+    M8 = lab.Mat8(ctx, hM, nmat, rows, cols)
+    assert M8.nbytes == 64 * 4 * 2 * 12 * 1024        # 4 planes x 2 row tiles x 12 k-tiles
+    got = lab.matvec_sum_mfma(ctx, M8, hV, ns).store().reshape(ns, rows, D)
+    for b in range(ns):
+        assert np.array_equal(got[b], lab.matvec_sum(ctx, hM, hV, nmat, rows, cols, v_off=b * nmat * cols).store())
+    for b, r_ in ((1, 0), (2, 5), (7, rows - 1)):
+        want = np.zeros(D, np.uint64)
+        for m in range(nmat):
+            want = co.poly_add(q, want, co.inner_product(q, M[m, r_], V[b, m]))
+        assert np.array_equal(got[b, r_], want)
+    M8.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("K", [98304, 131070])
+def test_matvec_sum_mfma_long_sums_three_plane_basis(K):
+    # the reduction lengths the bench runs at (K = r*t1*kappa = 98304: 768 trips of the GEMM's K loop) and the longest the
+    # int32 accumulators allow (2^17 - 2), 64 sets, basis of primes below 2^23.  (a) random data from the shared synthetic
+    # streams: the matrix cores against the oracle on sample (set, row) pairs and against the multiply-add kernel on whole
+    # sets; (b) extreme digit patterns: every matrix and vector residue of every NTT slot has the digits (-128, -128, 127)
+    # resp. (127, 127, 126), so the plane products are K * 16384, K * -16256, K * 16129: the int32 bound |D| <= K * 2^14.
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    q = Q_REF33
+    ctx = lab.Context(q, 0, 1 << 17)
+    bound = 1625
+    primes, _, _ = ctx.enable_digit_basis(1 << 17, bound, mfma=True)
+    assert all(pr < (1 << 23) - 0x8080 for pr in primes)
+    ns, rows = 64, 64
+    nmat, cols = (96, 1024) if K == 98304 else (2, 65535)
+    assert nmat * cols == K
+    hM = ctx.vec(nmat * rows * cols, digit=True).fill_synthetic(71)
+    hV = ctx.vec(ns * K, digit=True).fill_synthetic(72, bound=bound)
+    M8 = lab.Mat8(ctx, hM, nmat, rows, cols)
+    got = lab.matvec_sum_mfma(ctx, M8, hV, ns).store().reshape(ns, rows, D)
+    for b in (0, 37, 63):
+        assert np.array_equal(got[b], lab.matvec_sum(ctx, hM, hV, nmat, rows, cols, v_off=b * K).store()), (b,)
+    for b, r_ in ((0, 0), (63, 63), (21, 40)):
+        v = co.synth_fill(72, b * K * D, K * D, bound).reshape(K, D)
+        want = np.zeros(D, np.uint64)
+        for m in range(nmat):
+            row = co.synth_fill(71, ((m * rows + r_) * cols) * D, cols * D, q).reshape(cols, D)
+            want = co.poly_add(q, want, co.inner_product(q, row, v[m * cols:(m + 1) * cols]))
+        assert np.array_equal(got[b, r_], want), (b, r_)
+    M8.close()
+    hM.close()
+    hV.close()
+    # (b) a constant polynomial x has the residue x in every NTT slot of every limb (x below all three primes)
+    lo, hi = 127 * 65536 - 128 * 256 - 128, 126 * 65536 + 127 * 256 + 127
+    assert _signed_digits(lo, 3) == [-128, -128, 127] and _signed_digits(hi, 3) == [127, 127, 126] and hi < min(primes)
+    rows = 32
+    for xm, xv in ((lo, lo), (hi, hi), (lo, hi)):
+        Mc = np.zeros((rows * K, D), np.uint64)
+        Mc[:, 0] = xm
+        Vc = np.zeros((K, D), np.uint64)
+        Vc[:, 0] = xv
+        hM = ctx.vec(rows * K, digit=True).load(Mc)
+        hV = ctx.vec(ns * K, digit=True)
+        for s in range(ns):
+            hV.load(Vc, s * K)
+        M8 = lab.Mat8(ctx, hM, 1, rows, K)
+        got = lab.matvec_sum_mfma(ctx, M8, hV, ns).store().reshape(ns, rows, D)
+        want = np.zeros(D, np.uint64)
+        want[0] = (K * xm * xv) % q
+        assert np.array_equal(got, np.broadcast_to(want, got.shape)), (xm, xv)
+        assert np.array_equal(got[5, 7], co.inner_product(q, Mc[:K], Vc))
+        M8.close()
+        hM.close()
+        hV.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("K", [98304, 131070])
+def test_matvec_sum_mfma_long_sums_main_basis(K):
+    # the same for the 30-bit limb primes (four planes, k_gemm_i8<NT, 8>): extreme patterns (-128, -128, -128, 63) and
+    # (127, 127, 127, 62) in both operands, full-range residues, 64 sets
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    q = Q_REF33
+    ctx = lab.Context(q, 0, 1 << 17)
+    ns, rows = 64, 32
+    lo = 63 * (1 << 24) - 128 * 65536 - 128 * 256 - 128
+    hi = 62 * (1 << 24) + 127 * 65536 + 127 * 256 + 127
+    assert _signed_digits(lo, 4) == [-128, -128, -128, 63] and _signed_digits(hi, 4) == [127, 127, 127, 62] and hi < min(ctx.primes)
+    for xm, xv in ((lo, lo), (hi, hi), (lo, hi)):
+        Mc = np.zeros((rows * K, D), np.uint64)
+        Mc[:, 0] = xm
+        Vc = np.zeros((K, D), np.uint64)
+        Vc[:, 0] = xv
+        hM = ctx.vec_from(Mc)
+        hV = ctx.vec(ns * K)
+        for s in range(ns):
+            hV.load(Vc, s * K)
+        M8 = lab.Mat8(ctx, hM, 1, rows, K)
+        got = lab.matvec_sum_mfma(ctx, M8, hV, ns).store().reshape(ns, rows, D)
+        want = np.zeros(D, np.uint64)
+        want[0] = (K * xm * xv) % q
+        assert np.array_equal(got, np.broadcast_to(want, got.shape)), (xm, xv)
+        M8.close()
+        hM.close()
+        hV.close()
+    # random full-range residues at the same length: 8 sets against the multiply-add kernel and the oracle
+    nmat, cols = (96, 1024) if K == 98304 else (2, 65535)
+    hM = ctx.vec(nmat * rows * cols).fill_synthetic(81)
+    hV = ctx.vec(8 * K).fill_synthetic(82)
+    M8 = lab.Mat8(ctx, hM, nmat, rows, cols)
+    got = lab.matvec_sum_mfma(ctx, M8, hV, 8).store().reshape(8, rows, D)
+    for b in (0, 7):
+        assert np.array_equal(got[b], lab.matvec_sum(ctx, hM, hV, nmat, rows, cols, v_off=b * K).store()), (b,)
+    b, r_ = 3, 17
+    v = co.synth_fill(82, b * K * D, K * D, q).reshape(K, D)
+    want = np.zeros(D, np.uint64)
+    for m in range(nmat):
+        row = co.synth_fill(81, ((m * rows + r_) * cols) * D, cols * D, q).reshape(cols, D)
+        want = co.poly_add(q, want, co.inner_product(q, row, v[m * cols:(m + 1) * cols]))
+    assert np.array_equal(got[b, r_], want)
+    M8.close()
+    ctx.close()
