@@ -89,7 +89,8 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
     g.M8 = m->d[l]; g.V8 = v8; g.v8_job_stride = v8_stride;
     g.planes = (unsigned)pl; g.rt_count = (unsigned)m->rt_count; g.kt_count = (unsigned)m->kt_count;
     const int waves = gemm_i8_waves(pl, m->rt_count, nt);
-    g.rgroups = (unsigned)((m->rt_count + waves / pl - 1) / (waves / pl)); g.njobs = (unsigned)njobs; g.rows = (unsigned)m->rows;
+    const int tpb = (pl == 3 && waves == 4) ? 4 : waves / pl;       // row tiles per block
+    g.rgroups = (unsigned)((m->rt_count + tpb - 1) / tpb); g.njobs = (unsigned)njobs; g.rows = (unsigned)m->rows;
     g.ns = (unsigned)ns; g.ns_valid = (unsigned)ns_valid; g.nsub = (unsigned)nsub; g.p = primes[l];
     g.tab = (m->basis ? c->dg_tabs : c->d_tabs) + l;
     g.pw[0] = 1 % primes[l];
@@ -113,7 +114,8 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
     if (prof) {
       LAB_HIP(c, hipEventRecord(c->prof_events[c->prof_used++].second, c->stream));
       char kname[48];
-      snprintf(kname, sizeof kname, "k_gemm_i8<%d, %d>", (int)nt, waves);
+      if (pl == 3 && waves == 4) snprintf(kname, sizeof kname, "k_gemm_i8_w3<%d>", (int)nt);
+      else snprintf(kname, sizeof kname, "k_gemm_i8<%d, %d>", (int)nt, waves);
       c->prof_kernel = kname;
       // the matrix digit planes once, the B-operand tiles once per 32-row block (from L2), the residues out
       c->prof_bytes += (double)D * pl * m->rt_count * m->kt_count * 1024 + (double)D * m->kt_count * nt * 1024 +

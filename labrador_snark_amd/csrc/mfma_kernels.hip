@@ -22,6 +22,8 @@ namespace lab {
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 typedef int i32x16_t __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 // signed base-256 digits of x (x < 2^31): digit i in [-128,127] for i < planes-1, the rest in the last plane
 __device__ __forceinline__ void signed_digits(uint32_t x, int planes, int8_t (&d)[4]) {
@@ -559,6 +561,126 @@ k_gemm_i8(const Gemm8Args a) {
   }  // (wave group, half)
 }
 
+// ---- the GEMM for 3-plane limbs, one row tile per wave (the prover's step 1, 3, 4, 9 launches in the matrix-core digit basis).
+// k_gemm_i8 above gives every wave ONE (plane, row tile) A operand and lets it re-read the whole B stage from LDS: one
+// LDS fragment per MFMA, 6 waves on 4 SIMDs (two SIMDs carry two waves, two carry one), a block-wide barrier every 4
+// k-tiles with the B operands staged through VGPRs by the waves that issue the MFMAs — and, as compiled, a drain of the
+// vector-memory queue (s_waitcnt vmcnt(0)) inside every stage: the compiler's wait-count pass does not follow loads that
+// are consumed several loop trips after they were issued, so the HBM stream and the matrix instructions take turns.
+// Here a wave owns all THREE digit planes of one 32-row tile against all NT column tiles: 3*NT accumulator tiles (288
+// registers at 64 sets — one wave per SIMD, 512 registers each), so
+//   * every B fragment read from LDS feeds 3 MFMAs (a third of the LDS traffic per multiply),
+//   * a block is 4 waves = 4 row tiles = one wave per SIMD: the four SIMDs carry equal MFMA load, and one B stage from
+//     L2 serves 128 matrix rows instead of 64,
+//   * B stages arrive by LDS-DMA (global_load_lds_dwordx4) into a 4-slot ring, three stages ahead: no staging registers,
+//     no ds_write, nothing for the MFMA waves to park,
+//   * the barrier at the top of stage st certifies the B operands of stage st+1 (each wave has waited for its own pieces
+//     of that stage), so the first fragments of the next stage are read before the barrier and the MFMA stream does
+//     not drain across it,
+//   * A operands (3 KiB per wave and k-tile, straight from HBM, non-temporal when read once) sit in a 4-slot register
+//     ring, three stages (6 k-tiles, 18 KiB per wave, 72 KiB per CU) in flight,
+//   * the nine int32 tiles a result needs are in the same register of the same lane of ONE wave: the recombination
+//     sum_{i,i'} 256^(i+i') D[i][i'] mod p runs in registers, no LDS parking, no block barrier.
+// The K loop is assembly (gemm_w3_asm.inc, generated by tools/gen_gemm_w3_asm.py): every wait is counted by hand, and the
+// accumulator tiles beyond the 256 accumulation registers sit in vector registers (the compiler assigns one register class
+// to the results of all matrix instructions of a kernel).  Stage = 2 k-tiles; kt_count is a multiple of 12, so the stage
+// count is even and the 4-stage loop body may end after its second stage.
+#include "gemm_w3_asm.inc"
+constexpr int W3_KS = 2;       // k-tiles per stage
+constexpr int W3_RING = 4;     // ring slots (A registers and B LDS slots): 3 stages in flight behind the one being multiplied
+
+template <int NT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_gemm_i8_w3(const Gemm8Args a) {
+  static_assert(NT == 3 || NT == 6, "32 or 64 sets of 3 planes");
+  constexpr int HALVES = NT / 3;                    // 32-set halves: column n = i' * ns + s lies in tile i' * HALVES + s / 32
+  constexpr int PIECES = W3_KS * NT;                // 1 KiB DMA pieces per stage
+  constexpr int PPW = (PIECES + 3) / 4;             // ... per wave (NT = 3: the last wave repeats the third wave's pieces)
+  __shared__ u32x4_t bring[W3_RING * PIECES * 64];  // B ring: slot r at r * PIECES KiB
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const unsigned rt_count = a.rt_count, kt_count = a.kt_count;
+  const unsigned x = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const unsigned per_j = a.rgroups * a.njobs;
+  const unsigned j = x + 8 * (seq / per_j), sub = seq % per_j;
+  const unsigned job = sub % a.njobs, rg = sub / a.njobs;
+  const unsigned rt = rg * 4 + w;
+  const unsigned rtc = min(rt, rt_count - 1);       // a wave past the last row tile multiplies a copy of it and stores nothing
+  const int first_piece = min(w * PPW, PIECES - PPW);
+  uint64_t a0 = (uint64_t)(uintptr_t)a.M8 + (((size_t)j * 3 + 0) * rt_count + rtc) * kt_count * 1024;
+  uint64_t a1 = (uint64_t)(uintptr_t)a.M8 + (((size_t)j * 3 + 1) * rt_count + rtc) * kt_count * 1024;
+  uint64_t a2 = (uint64_t)(uintptr_t)a.M8 + (((size_t)j * 3 + 2) * rt_count + rtc) * kt_count * 1024;
+  uint64_t bg = (uint64_t)(uintptr_t)a.V8 + (size_t)job * a.v8_job_stride + (size_t)j * kt_count * NT * 1024 + first_piece * 1024 + lane * 16;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)bring;
+  const uint32_t voff = lane * 16, vlds = lds0 + lane * 16;
+  const uint32_t m0b = __builtin_amdgcn_readfirstlane(lds0 + first_piece * 1024);
+  const uint32_t nstages = __builtin_amdgcn_readfirstlane(kt_count / W3_KS);
+
+  // accumulator tile (plane i, column tile n) = acc[i * NT + n]; the first 16 in accumulation registers
+  i32x16_t acc[3 * NT];
+#pragma unroll
+  for (int k = 0; k < 3 * NT; k++)
+#pragma unroll
+    for (int g = 0; g < 16; g++) acc[k][g] = 0;
+  if constexpr (NT == 6) {
+#define W3_ACC_OPERANDS                                                                                                          \
+  "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]), "+a"(acc[8]),  \
+      "+a"(acc[9]), "+a"(acc[10]), "+a"(acc[11]), "+a"(acc[12]), "+a"(acc[13]), "+a"(acc[14]), "+a"(acc[15]), "+v"(acc[16]),     \
+      "+v"(acc[17]), "+v"(bg)
+    if (a.njobs > 1)   // the matrix is shared by many jobs (Ajtai): keep it in L2
+      asm volatile(W3_LOOP_ASM_NT6_PLAIN : W3_ACC_OPERANDS : "s"(a0), "s"(a1), "s"(a2), "v"(voff), "v"(vlds), "s"(m0b), "s"(nstages)
+                   : W3_LOOP_CLOBBERS_NT6_PLAIN);
+    else               // read once (outer commitment): non-temporal
+      asm volatile(W3_LOOP_ASM_NT6_NTLOAD : W3_ACC_OPERANDS : "s"(a0), "s"(a1), "s"(a2), "v"(voff), "v"(vlds), "s"(m0b), "s"(nstages)
+                   : W3_LOOP_CLOBBERS_NT6_NTLOAD);
+#undef W3_ACC_OPERANDS
+  } else {
+#define W3_ACC_OPERANDS                                                                                                          \
+  "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]), "+a"(acc[8]),  \
+      "+v"(bg)
+    if (a.njobs > 1)
+      asm volatile(W3_LOOP_ASM_NT3_PLAIN : W3_ACC_OPERANDS : "s"(a0), "s"(a1), "s"(a2), "v"(voff), "v"(vlds), "s"(m0b), "s"(nstages)
+                   : W3_LOOP_CLOBBERS_NT3_PLAIN);
+    else
+      asm volatile(W3_LOOP_ASM_NT3_NTLOAD : W3_ACC_OPERANDS : "s"(a0), "s"(a1), "s"(a2), "v"(voff), "v"(vlds), "s"(m0b), "s"(nstages)
+                   : W3_LOOP_CLOBBERS_NT3_NTLOAD);
+#undef W3_ACC_OPERANDS
+  }
+
+  // ---- recombination in registers: out_s[row] = sum_{i,i'} 256^(i+i') D[i][(i', s)] mod p, every D as the unsigned D + 2^31
+  if (rt >= rt_count) return;
+  const uint32_t p = a.p;
+  const LimbTable* tab = a.tab;
+  const uint32_t p2 = tab->p2, pinv = tab->pinv, r2 = tab->r2;
+  uint32_t pw[5];
+#pragma unroll
+  for (int e = 0; e < 5; e++) pw[e] = a.pw[e];
+  const unsigned ns = a.ns;
+  uint32_t* out = a.out + (size_t)job * a.out_job_stride;
+#pragma unroll
+  for (int h = 0; h < HALVES; h++) {
+    const unsigned s = h * 32 + (lane & 31);
+    const bool s_ok = s % a.nsub < a.ns_valid;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const unsigned row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), grow = rt * 32 + row;
+      uint64_t s64 = 0;                             // 9 products < 2^32 * p: the high word stays below 9p < 2^27
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int iv = 0; iv < 3; iv++) s64 += (uint64_t)((uint32_t)acc[i * NT + iv * HALVES + h][e] ^ 0x80000000u) * pw[i + iv];
+      uint32_t hi = (uint32_t)(s64 >> 32);
+      hi = min(hi, hi - 8 * p); hi = min(hi, hi - 4 * p); hi = min(hi, hi - p2); hi = min(hi, hi - p);
+      const uint32_t v = mont_mul(redc64(((uint64_t)hi << 32) | (uint32_t)s64, p, pinv), r2, p, pinv);
+      const uint32_t res = csub(v + p - a.bias, p);
+      if (s_ok && grow < a.rows) {
+        if (a.stage) a.stage[(((size_t)job * D + j) * (rt_count * 32) + grow) * ns + s] = res;
+        else out[(size_t)s * a.out_set_stride + (size_t)grow * D + j] = res;
+      }
+    }
+  }
+}
+
 // stage[job][j][row][s] -> out[job*out_job_stride + s*out_set_stride + row*64 + j]; block = (row, job)
 __global__ void __launch_bounds__(256)
 k_slot_transpose(uint32_t* __restrict__ out, size_t out_set_stride, size_t out_job_stride, const uint32_t* __restrict__ stage,
@@ -589,6 +711,7 @@ hipError_t launch_slot_transpose(uint32_t* out_plane, size_t out_set_stride, siz
 // Blocks of 8 waves (two row tiles per B stage) when the limb has 4 planes, at least 2 row tiles and at least 2 column
 // tiles; 6 (3) waves for a 3-plane limb with at least 2 (with 1) row tiles.  The caller derives rgroups from this.
 int gemm_i8_waves(int planes, size_t rt_count, size_t nt) {
+  if (planes == 3 && (nt == 6 || nt == 3) && rt_count >= 4) return 4;   // k_gemm_i8_w3: 4 waves = 4 row tiles x 3 planes each
   if (planes == 3) return rt_count >= 2 ? 6 : 3;
   return planes == 4 && rt_count >= 2 && nt >= 2 ? 8 : 4;
 }
@@ -601,6 +724,12 @@ hipError_t launch_gemm_i8(const Gemm8Args& a, size_t nt, int waves, hipStream_t 
 #define LAB_G6(NTV)                                                                                   \
   if (waves == 6) hipLaunchKernelGGL((k_gemm_i8<NTV, 6>), g, dim3(384), 0, s, a);                     \
   else hipLaunchKernelGGL((k_gemm_i8<NTV, 3>), g, dim3(192), 0, s, a)
+  if (a.planes == 3 && waves == 4) {                // 3-plane limbs, one row tile (all three planes) per wave
+    if (nt == 6) hipLaunchKernelGGL((k_gemm_i8_w3<6>), g, dim3(256), 0, s, a);
+    else if (nt == 3) hipLaunchKernelGGL((k_gemm_i8_w3<3>), g, dim3(256), 0, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   if (a.planes == 3) {                              // 3-plane limbs: blocks of 3 or 6 waves
     if (waves != 3 && waves != 6) return hipErrorInvalidValue;
     switch (nt) {

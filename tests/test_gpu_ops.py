@@ -362,10 +362,12 @@ def test_matvec_sum_mfma_digit_basis(ns, nmat, rows, cols, compact):
 
 
 @pytest.mark.parametrize("ns", [8, 16, 32, 64])
-@pytest.mark.parametrize("nmat,rows,cols", [(3, 40, 37), (2, 64, 64), (1, 100, 200), (5, 31, 7)])
+@pytest.mark.parametrize("nmat,rows,cols", [(3, 40, 37), (2, 64, 64), (1, 100, 200), (5, 31, 7), (2, 130, 70), (1, 256, 33), (3, 97, 129)])
 def test_matvec_sum_mfma_three_plane_basis(ns, nmat, rows, cols):
     # the digit basis made for the matrix cores: primes below 2^23, residues as three signed byte planes, GEMM blocks of
-    # 3 (one row tile) or 6 waves, 1/2/3/6 column tiles; bit-identical to lab_matvec_sum and the oracle
+    # 3 (one row tile) or 6 waves, 1/2/3/6 column tiles, and from 4 row tiles on (32 / 64 sets) k_gemm_i8_w3 — one row tile
+    # with its three planes per wave, assembly K loop; ragged last tiles, waves past the last tile (5 tiles = 2 blocks), 6,
+    # 12 and 18 stages; bit-identical to lab_matvec_sum and the oracle
     import labrador_snark_amd as lab
     from oracle import coracle as co
     q = Q_REF33
@@ -493,7 +495,7 @@ def test_matvec_sum_mfma_long_sums_three_plane_basis(K):
     bound = 1625
     primes, _, _ = ctx.enable_digit_basis(1 << 17, bound, mfma=True)
     assert all(pr < (1 << 23) - 0x8080 for pr in primes)
-    ns, rows = 64, 64
+    ns, rows = 64, 128                   # 4 row tiles: k_gemm_i8_w3<6>, the kernel of the bench's step 3
     nmat, cols = (96, 1024) if K == 98304 else (2, 65535)
     assert nmat * cols == K
     hM = ctx.vec(nmat * rows * cols, digit=True).fill_synthetic(71)
@@ -502,7 +504,7 @@ def test_matvec_sum_mfma_long_sums_three_plane_basis(K):
     got = lab.matvec_sum_mfma(ctx, M8, hV, ns).store().reshape(ns, rows, D)
     for b in (0, 37, 63):
         assert np.array_equal(got[b], lab.matvec_sum(ctx, hM, hV, nmat, rows, cols, v_off=b * K).store()), (b,)
-    for b, r_ in ((0, 0), (63, 63), (21, 40)):
+    for b, r_ in ((0, 0), (63, 127), (21, 40)):
         v = co.synth_fill(72, b * K * D, K * D, bound).reshape(K, D)
         want = np.zeros(D, np.uint64)
         for m in range(nmat):
@@ -515,13 +517,15 @@ def test_matvec_sum_mfma_long_sums_three_plane_basis(K):
     # (b) a constant polynomial x has the residue x in every NTT slot of every limb (x below all three primes)
     lo, hi = 127 * 65536 - 128 * 256 - 128, 126 * 65536 + 127 * 256 + 127
     assert _signed_digits(lo, 3) == [-128, -128, 127] and _signed_digits(hi, 3) == [127, 127, 126] and hi < min(primes)
-    rows = 32
-    for xm, xv in ((lo, lo), (hi, hi), (lo, hi)):
-        Mc = np.zeros((rows * K, D), np.uint64)
+    for rows in (128, 32):               # k_gemm_i8_w3<6> and k_gemm_i8<6, 3>
+      for xm, xv in ((lo, lo), (hi, hi), (lo, hi)):
+        Mc = np.zeros((K, D), np.uint64)
         Mc[:, 0] = xm
         Vc = np.zeros((K, D), np.uint64)
         Vc[:, 0] = xv
-        hM = ctx.vec(rows * K, digit=True).load(Mc)
+        hM = ctx.vec(rows * K, digit=True)
+        for r_ in range(rows):
+            hM.load(Mc, r_ * K)
         hV = ctx.vec(ns * K, digit=True)
         for s in range(ns):
             hV.load(Vc, s * K)
@@ -529,8 +533,8 @@ def test_matvec_sum_mfma_long_sums_three_plane_basis(K):
         got = lab.matvec_sum_mfma(ctx, M8, hV, ns).store().reshape(ns, rows, D)
         want = np.zeros(D, np.uint64)
         want[0] = (K * xm * xv) % q
-        assert np.array_equal(got, np.broadcast_to(want, got.shape)), (xm, xv)
-        assert np.array_equal(got[5, 7], co.inner_product(q, Mc[:K], Vc))
+        assert np.array_equal(got, np.broadcast_to(want, got.shape)), (rows, xm, xv)
+        assert np.array_equal(got[5, 7], co.inner_product(q, Mc, Vc))
         M8.close()
         hM.close()
         hV.close()

@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Generates labrador_snark_amd/csrc/gemm_w3_asm.inc: the K loop of k_gemm_i8_w3 (mfma_kernels.hip) as gfx950
+assembly, one inline-asm block per (column tiles NT, non-temporal A loads) variant.
+
+Why assembly: the loop keeps three stages of A operands (registers) and B operands (LDS-DMA) in flight behind the stage
+being multiplied.  hipcc's wait-count pass cannot follow loads that are consumed several loop trips after they were
+issued — it drains the vector-memory queue (s_waitcnt vmcnt(0)) inside every stage, which serialises the HBM stream with
+the matrix instructions (round 1's k_gemm_i8: load time + multiply time instead of their maximum) — and it assigns ONE
+register class to the results of all matrix instructions of a kernel, while 288 accumulators need the 256 accumulation
+registers plus 32 vector registers.  Here every wait is counted by hand.
+
+Register plan of the block (everything else is the compiler's):
+  v[120:215]  A ring: slot r (4), k-tile ks (2), plane i (3) -> 4 registers at 120 + ((r*2 + ks)*3 + i)*4
+  v[216:227]  B fragments in flight from LDS (3 x 4)
+  s[40:51]    loop state: s40 next stage to issue, s41 stage being multiplied, s[42:43] / s44 address increments,
+              s[46:51] the A addresses of the three planes (advanced here)
+Operands: %0 .. %(3*NT-1): accumulator tile (plane i, column tile n) = operand i*NT + n, the first 16 in accumulation
+registers, the rest in vector registers; then
+  BG          (+v, 64-bit)  address of this wave's first DMA piece of the stage to be issued next, + lane*16
+  A0, A1, A2  (s, 64-bit)   address of this wave's A operands of plane i, stage 0
+  VOFF        (v)           lane*16
+  VLDS        (v)           LDS byte address of ring slot 0 + lane*16
+  M0B         (s)           LDS byte address of ring slot 0 + this wave's first piece
+  NST         (s)           number of stages (even, >= 2)
+
+    python tools/gen_gemm_w3_asm.py > labrador_snark_amd/csrc/gemm_w3_asm.inc
+"""
+import sys
+
+KS, RING, PF = 2, 4, 3
+RING0, FR0 = 120, 216
+
+
+def gen(NT, nt_loads):
+    nacc = 3 * NT
+    pieces = KS * NT
+    ppw = (pieces + 3) // 4
+    slot_bytes = pieces * 1024
+    ops = ppw + 3 * KS
+    left = ops + 3 * KS            # may stay in flight at the top of a stage: stage st+2, and the A operands of stage st+1
+    # operand numbers: outputs first (accumulators, then BG), then the inputs
+    o_bg = nacc
+    o_a = [nacc + 1 + i for i in range(3)]
+    o_voff, o_vlds, o_m0b, o_nst = nacc + 4, nacc + 5, nacc + 6, nacc + 7
+    sa = ["s[%d:%d]" % (46 + 2 * i, 47 + 2 * i) for i in range(3)]     # the A addresses, advanced here
+    nt = " nt" if nt_loads else ""
+    L = []
+    emit = L.append
+
+    def ring(r, ks, i):
+        b = RING0 + ((r * KS + ks) * 3 + i) * 4
+        return "v[%d:%d]" % (b, b + 3)
+
+    def fr(k):
+        b = FR0 + 4 * k
+        return "v[%d:%d]" % (b, b + 3)
+
+    # s40: index of the next stage to issue, s41: stage being multiplied, s[42:43]: 64-bit B increment, s44: A increment
+    def vmem_ops(slot):
+        """the instructions that issue one stage, in groups that are spread between the matrix instructions"""
+        grp = [["s_add_u32 m0, %%%d, %d" % (o_m0b, slot * slot_bytes), "s_nop 0", "global_load_lds_dwordx4 %%%d, off" % o_bg]]
+        for q in range(1, ppw):
+            grp.append(["global_load_lds_dwordx4 %%%d, off offset:%d" % (o_bg, q * 1024)])
+        for ks in range(KS):
+            for i in range(3):
+                grp.append(["global_load_dwordx4 %s, %%%d, %s offset:%d%s" % (ring(slot, ks, i), o_voff, sa[i], ks * 1024, nt)])
+        # advance to the next stage unless this was the last one (then the last stage is fetched again, into a slot nobody reads)
+        adv = ["s_add_u32 s40, s40, 1", "s_cmp_lt_u32 s40, %%%d" % o_nst,
+               "s_cselect_b32 s42, %d, 0" % (pieces * 1024), "s_cselect_b32 s44, %d, 0" % (KS * 1024),
+               "v_lshl_add_u64 %%%d, %%%d, 0, s[42:43]" % (o_bg, o_bg)]
+        for i in range(3):
+            adv += ["s_add_u32 s%d, s%d, s44" % (46 + 2 * i, 46 + 2 * i), "s_addc_u32 s%d, s%d, 0" % (47 + 2 * i, 47 + 2 * i)]
+        grp.append(adv)
+        return grp
+
+    def issue_now(slot):
+        for grp in vmem_ops(slot):
+            for ins in grp:
+                emit(ins)
+
+    def stage(k):
+        """multiply ring slot k; issue the loads of three stages ahead into slot (k+3)%4, spread between the matrix instructions"""
+        emit("s_waitcnt vmcnt(%d)" % left)
+        emit("s_barrier")
+        pending = vmem_ops((k + 3) % RING)
+        nm = KS * NT
+        for f in range(nm):
+            ks, n = divmod(f, NT)
+            emit("s_waitcnt lgkmcnt(%d)" % (PF - 1))
+            for i in range(3):
+                emit("v_mfma_i32_32x32x32_i8 %%%d, %s, %s, %%%d" % (i * NT + n, ring(k, ks, i), fr(f % PF), i * NT + n))
+            nxt = f + PF
+            if nxt < nm:
+                emit("ds_read_b128 %s, %%%d offset:%d" % (fr(f % PF), o_vlds, k * slot_bytes + nxt * 1024))
+            else:
+                emit("ds_read_b128 %s, %%%d offset:%d" % (fr(f % PF), o_vlds, ((k + 1) % RING) * slot_bytes + (nxt - nm) * 1024))
+            if pending:
+                for ins in pending.pop(0):
+                    emit(ins)
+        while pending:
+            for ins in pending.pop(0):
+                emit(ins)
+
+    emit("s_waitcnt vmcnt(0) lgkmcnt(0)")     # nothing of the compiler's may be counted with this block's operations
+    for i in range(3):
+        emit("s_mov_b64 %s, %%%d" % (sa[i], o_a[i]))
+    emit("s_mov_b32 s40, 0")
+    emit("s_mov_b32 s41, 0")
+    emit("s_mov_b32 s43, 0")
+    for s in range(3):
+        issue_now(s)
+    emit("s_waitcnt vmcnt(%d)" % (2 * ops))
+    emit("s_barrier")
+    for f in range(PF):
+        emit("ds_read_b128 %s, %%%d offset:%d" % (fr(f), o_vlds, f * 1024))
+    emit("1:")
+    stage(0)
+    stage(1)
+    emit("s_add_u32 s41, s41, 2")
+    emit("s_cmp_ge_u32 s41, %%%d" % o_nst)
+    emit("s_cbranch_scc1 2f")
+    stage(2)
+    stage(3)
+    emit("s_add_u32 s41, s41, 2")
+    emit("s_cmp_lt_u32 s41, %%%d" % o_nst)
+    emit("s_cbranch_scc1 1b")
+    emit("2:")
+    emit("s_waitcnt vmcnt(0) lgkmcnt(0)")   # no DMA may still be writing this block's LDS when it ends
+    emit("s_nop 15")                        # the last matrix instructions are still writing their tiles (16 passes)
+    emit("s_nop 15")
+    emit("s_nop 7")
+    clob = ['"v%d"' % r for r in range(RING0, FR0 + 4 * PF)] + ['"s%d"' % r for r in range(40, 52)] + ['"scc"', '"memory"']
+    return L, clob
+
+
+def main():
+    out = ["// GENERATED by tools/gen_gemm_w3_asm.py — do not edit.  The K loop of k_gemm_i8_w3 (see mfma_kernels.hip).", ""]
+    for NT in (3, 6):
+        for ntl in (0, 1):
+            L, clob = gen(NT, ntl)
+            name = "NT%d_%s" % (NT, "NTLOAD" if ntl else "PLAIN")
+            out.append("#define W3_LOOP_ASM_%s \\" % name)
+            for k, ins in enumerate(L):
+                out.append('    "%s\\n\\t"%s' % (ins, " \\" if k + 1 < len(L) else ""))
+            out.append("")
+            out.append("#define W3_LOOP_CLOBBERS_%s %s" % (name, ", ".join(clob)))
+            out.append("")
+    sys.stdout.write("\n".join(out) + "\n")
+
+
+if __name__ == "__main__":
+    main()
