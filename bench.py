@@ -80,7 +80,7 @@ def challenge_poly(rng, q):
     return np.where((vals > 0) & (signs == 1), q - vals, vals).astype(np.uint64)
 
 
-def make_inputs(k, q, seed, dev=None):
+def make_inputs(k, q, seed, dev=None, packed_pi=False):
     """Seeded synthetic witness / state / challenge tape (same recipe as tests/cases.py, without the oracle):
     witness coefficients uniform in [0, beta/sqrt(n r d)] so the norm bound of generate_witness holds
     (src/proofgen.rs:460-518), phi and a uniform (src/structs.rs:289-314), Pi in {-1,0,1} with weights
@@ -103,11 +103,20 @@ def make_inputs(k, q, seed, dev=None):
         bits = torch.randint(0, 4, (r, 256, n * D), dtype=torch.int8, device=dev, generator=g)
         Pi = (bits == 3).to(torch.int8) - (bits == 0).to(torch.int8)
         del bits
+        if packed_pi:
+            # 2 bits per entry as lab_prove_input.Pi2 wants them: field 2*(col % 4) of byte col/4 = entry + 1
+            f = (Pi + 1).to(torch.uint8).reshape(r, 256, n * D // 4, 4)
+            Pi = (f[..., 0] | (f[..., 1] << 2) | (f[..., 2] << 4) | (f[..., 3] << 6)).contiguous()
+            del f
     else:
         Pi = rng.choice(np.array([-1, 0, 1], dtype=np.int8), size=(r, 256, n * D), p=[0.25, 0.5, 0.25]).astype(np.int8)
-    tape = dict(Pi=Pi, psi=int(rng.integers(0, q)), omega=rng.integers(0, q, size=256, dtype=np.uint64),
+    if packed_pi and dev is None:
+        f = (Pi + 1).astype(np.uint8).reshape(r, 256, n * D // 4, 4)
+        Pi = np.ascontiguousarray(f[..., 0] | (f[..., 1] << 2) | (f[..., 2] << 4) | (f[..., 3] << 6))
+    tape = dict(psi=int(rng.integers(0, q)), omega=rng.integers(0, q, size=256, dtype=np.uint64),
                 alpha=rng.integers(0, q, size=D, dtype=np.uint64), beta=rng.integers(0, q, size=D, dtype=np.uint64),
                 c=np.stack([challenge_poly(rng, q) for _ in range(r)]))
+    tape["Pi2" if packed_pi else "Pi"] = Pi
     return S, phi, a, tape
 
 
@@ -117,7 +126,7 @@ def checksum_u64(t):
     return (t.to(torch.int64).sum() & ((1 << 62) - 1)).reshape(1)
 
 
-def build_workload(lab, ctx, k, q, dev, nbatch, seed0, crs_seed, use_mfma=True, basis23=True, compact=True):
+def build_workload(lab, ctx, k, q, dev, nbatch, seed0, crs_seed, use_mfma=True, basis23=True, compact=True, packed_pi=True):
     """The resident inputs of one bench step: `nbatch` instances (seeds seed0 .. seed0+nbatch-1; witness, state, tape as
     device tensors) and the CRS they share.  tests/test_gpu_bench_config.py builds the same objects and checks the
     transcripts lab_prove_core_batch returns for them against the oracle."""
@@ -129,14 +138,15 @@ def build_workload(lab, ctx, k, q, dev, nbatch, seed0, crs_seed, use_mfma=True, 
 
     dSs, sts, dtapes = [], [], []
     for j in range(nbatch):
-        S, phi, a, tape = make_inputs(k, q, seed=seed0 + j, dev=dev)
+        S, phi, a, tape = make_inputs(k, q, seed=seed0 + j, dev=dev, packed_pi=packed_pi)
         # State::gen_f's b (src/structs.rs:320-341, 373) on the product's own kernels: b' = its constant term
         b_poly = lab.gen_f_b(ctx, S, phi, a, n, r)
         dSs.append(dev64(S))
         sts.append(lab.State(dev64(phi), dev64(a), int(b_poly[0])))
-        dtapes.append(dict(Pi=tape["Pi"] if torch.is_tensor(tape["Pi"]) else torch.from_numpy(tape["Pi"]).to(dev),
-                           psi=tape["psi"], omega=dev64(tape["omega"]),
-                           alpha=dev64(tape["alpha"]), beta=dev64(tape["beta"]), c=dev64(tape["c"])))
+        pikey = "Pi2" if packed_pi else "Pi"
+        dtapes.append({pikey: tape[pikey] if torch.is_tensor(tape[pikey]) else torch.from_numpy(tape[pikey]).to(dev),
+                       "psi": tape["psi"], "omega": dev64(tape["omega"]),
+                       "alpha": dev64(tape["alpha"]), "beta": dev64(tape["beta"]), "c": dev64(tape["c"])})
     # B, C, D are only ever multiplied by decomposition digits: keep them in the digit basis
     crs = lab.ResidentCRS(ctx, k, compact=compact, mfma_basis=basis23).fill_synthetic(crs_seed)
     if use_mfma:
@@ -196,6 +206,8 @@ def main():
                     help="outer commitment sum_ik B_ik t_i^(k): 64-bit multiply-add kernels (B as RNS residues) or exact "
                          "int8 GEMMs on the matrix cores (B packed as signed byte planes, up to 64 proofs per pass over B); "
                          "auto = mfma when --batch > 8")
+    ap.add_argument("--pi", choices=["packed", "int8"], default="packed",
+                    help="projection matrices Pi on the device: 2 bits per entry (lab_prove_input.Pi2) or one int8 per entry")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-compact-crs", action="store_true", help="keep B, C, D in the main RNS basis (12 B/coefficient at the 33-bit q)")
@@ -240,7 +252,7 @@ def main():
     use_mfma = args.step3 == "mfma" or (args.step3 == "auto" and nbatch > 8)
     basis23 = not args.no_compact_crs and (args.digit_basis == "mfma23" or (args.digit_basis == "auto" and use_mfma))
     dSs, sts, dtapes, crs = build_workload(lab, ctx, k, q, dev, nbatch, 50 + rank * nbatch, 1000 + 10 * rank, use_mfma=use_mfma,
-                                           basis23=basis23, compact=not args.no_compact_crs)
+                                           basis23=basis23, compact=not args.no_compact_crs, packed_pi=args.pi == "packed")
 
     def step():
         if nbatch == 1:
@@ -299,8 +311,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": "full Prover::proof_gen n=%d r=%d d=64, kappa=kappa1=kappa2=%d, q=%d (%d RNS limbs), "
-                                   "CRS resident in transform domain, CRS expansion excluded; %d independent proofs per step share the CRS"
-                                   % (n, r, kappa, q, ctx.nlimbs, nbatch),
+                                   "CRS resident in transform domain, CRS expansion excluded; %d independent proofs per step share the CRS; "
+                                   "Pi resident at %s"
+                                   % (n, r, kappa, q, ctx.nlimbs, nbatch, "2 bits per entry" if args.pi == "packed" else "one int8 per entry"),
                        "q": q, "n": n, "r": r, "kappa": kappa, "t1": k.T_1, "t2": k.T_2, "b1": k.B_1, "b2": k.B_2,
                        "nlimbs": ctx.nlimbs, "crs_basis": ("digit basis %s%s" % (getattr(ctx, "digit_primes", None), ", u16 last limb" if ctx.digit_small else
                                                           " (three signed byte planes per residue)"))
@@ -356,6 +369,7 @@ def main():
 
 
 def _time(fn, iters, warm=2):
+    import torch
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -370,6 +384,7 @@ def _time(fn, iters, warm=2):
 
 def side_measurements(lab, ctx, q, dev):
     """BASELINE configs[1] (batched NTT) and configs[3] (Ajtai mat-vec 2^14 x 2^10), reported next to the headline."""
+    import torch
     out = {}
     L = ctx.nlimbs
     for batch in (4096, 1 << 20):

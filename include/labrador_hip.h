@@ -254,6 +254,10 @@ int lab_sigma_inv(lab_ctx *ctx, uint64_t *out, const uint64_t *coeffs, size_t co
  *   proj[m] = sum_{i<r} sum_col Pi[i][m][col] * S[col/64][i][col%64]   over the integers (no reduction)
  * Pi: int8 [r][256][n*64], S: witness coefficients [n][r][64], proj: int64[256] (|proj| < r*n*64*q < 2^63). */
 int lab_jl_project(lab_ctx *ctx, int64_t *proj, const int8_t *Pi, const uint64_t *S, size_t n, size_t r);
+/* sample_jl_projection's matrices (src/verification.rs:553-566) from int8 {-1,0,1} to the 2-bit form of
+ * lab_prove_input.Pi2: `count` entries (a multiple of 16) -> count/4 bytes, entry k in field 2*(k % 4) of byte k/4 as
+ * entry + 1.  Host or device pointers. */
+int lab_pi_pack(lab_ctx *ctx, uint8_t *packed, const int8_t *Pi, size_t count);
 
 /* ---- Prover::proof_gen as one deterministic call (src/proofgen.rs:30-427) ----
  * The verifier's interactive randomness (src/verification.rs:441-513, 553-566) is supplied as a challenge tape and
@@ -293,6 +297,10 @@ typedef struct {
                                * product.  The pass that transforms S also sums its squared norm; a witness above beta_bound
                                * (never produced by generate_witness, src/proofgen.rs:460-518) makes the call redo the batch
                                * in the main basis, so results never depend on this field */
+  const uint8_t *Pi2;      /* optional, instead of Pi (which may then be NULL): the projection matrices at 2 bits per entry
+                            * (lab_pi_pack), [r][256][n*64/4] bytes: entry (i, m, col) is the field 2*(col % 4) of byte
+                            * (i*256 + m) * n*16 + col/4 and holds entry + 1 in {0, 1, 2}.  A quarter of the bytes of the int8
+                            * form on the pass that reads Pi (the reference lifts it to 16-byte Zq, src/proofgen.rs:445-453) */
 } lab_prove_input;
 
 /* The computed fields of `Transcript` (src/structs.rs:192-209); pi_i_all, psi, omega, alpha, beta, c are the tape.

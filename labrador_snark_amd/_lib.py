@@ -56,7 +56,7 @@ class lab_prove_input(C.Structure):
                 ("b_prime", C.c_uint64), ("A", C.c_void_p), ("a_off", C.c_size_t), ("B", C.c_void_p),
                 ("b_off", C.c_size_t), ("C", C.c_void_p), ("c_off", C.c_size_t), ("Dm", C.c_void_p),
                 ("d_off", C.c_size_t), ("Pi", C.c_void_p), ("psi", C.c_uint64), ("omega", C.c_void_p),
-                ("alpha", C.c_void_p), ("beta", C.c_void_p), ("c", C.c_void_p), ("B8", C.c_void_p), ("A8", C.c_void_p), ("C8", C.c_void_p), ("D8", C.c_void_p), ("A8d", C.c_void_p)]
+                ("alpha", C.c_void_p), ("beta", C.c_void_p), ("c", C.c_void_p), ("B8", C.c_void_p), ("A8", C.c_void_p), ("C8", C.c_void_p), ("D8", C.c_void_p), ("A8d", C.c_void_p), ("Pi2", C.c_void_p)]
 
 
 class lab_transcript(C.Structure):
@@ -129,6 +129,7 @@ SIGNATURES = {
     "lab_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64]),
     "lab_sigma_inv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "lab_jl_project": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
+    "lab_pi_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "lab_prove_core": (C.c_int, [C.c_void_p, C.POINTER(lab_prove_input), C.POINTER(lab_transcript)]),
     "lab_prove_core_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.POINTER(lab_prove_input)),
                                        C.POINTER(C.POINTER(lab_transcript)), C.POINTER(C.c_int)]),

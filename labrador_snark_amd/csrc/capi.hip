@@ -1084,6 +1084,23 @@ extern "C" int lab_sigma_inv(lab_ctx* c, uint64_t* out, const uint64_t* coeffs, 
   return coef_unary(c, out, coeffs, count, 0, 3, "lab_sigma_inv");
 }
 
+extern "C" int lab_pi_pack(lab_ctx* c, uint8_t* packed, const int8_t* Pi, size_t count) {
+  if (!c) return LAB_ERR_ARG;
+  if (!packed || !Pi || count % 16) return fail(c, LAB_ERR_ARG, "lab_pi_pack: null pointer or count not a multiple of 16");
+  if (count == 0) return LAB_OK;
+  LAB_HIP(c, hipSetDevice(c->device));
+  PtrCacheScope ptr_cache;
+  int rc = ensure_scratch(c, Staging::need(Pi, count) + Staging::need(packed, count / 4));
+  if (rc) return rc;
+  Carver cv(c->scratch);
+  Staging st(c, &cv);
+  const int8_t* dpi;
+  if ((rc = st.in(Pi, count, &dpi))) return rc;
+  uint8_t* dout = st.out(packed, count / 4);
+  LAB_HIP(c, launch_pi_pack(dout, dpi, count, c->stream));
+  return st.finish();
+}
+
 extern "C" int lab_jl_project(lab_ctx* c, int64_t* proj, const int8_t* Pi, const uint64_t* S, size_t n, size_t r) {
   if (!c) return LAB_ERR_ARG;
   if (!proj || !Pi || !S || n == 0 || r == 0) return fail(c, LAB_ERR_ARG, "lab_jl_project: bad argument");

@@ -573,6 +573,161 @@ k_pi_fused(const JobPtrs projp, const JobPtrs Wp, const JobPtrs Pip, const JobPt
   }
 }
 
+// ---- the same pass over Pi stored at 2 bits per entry (lab_prove_input.Pi2; the reference lifts Pi to 16-byte Zq,
+// src/proofgen.rs:445-453, this path reads a quarter of the int8 form's bytes).  Entry (i, m, col) is the 2-bit field
+// 2*(col % 4) of byte Pi2[(i*256 + m) * cols/4 + col/4], holding e + 1 in {0, 1, 2} — so a thread's 16 columns are one
+// dword per row, and every product is unsigned (v_mad_u32_u24); the surplus sum_col s[col] (rows) resp. sum_m omega[m]
+// (columns) that the +1 adds is taken off once per block / per thread.  8 rows are in flight per thread behind the 8 being
+// consumed.  SMALL: the caller guarantees witness coefficients below 2^24 (a witness inside its norm bound
+// beta < 2^24, checked by the digit-basis step 1 of the same call): one multiply-add per entry for the projection.
+template <bool SMALL>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_pi_fused2(const JobPtrs projp, const JobPtrs Wp, const JobPtrs Pip, const JobPtrs Sp, const JobPtrs omegap, unsigned n,
+            unsigned r, uint64_t q) {
+  unsigned long long* __restrict__ proj = static_cast<unsigned long long*>(projp.p[blockIdx.z]);
+  uint64_t* __restrict__ W = static_cast<uint64_t*>(Wp.p[blockIdx.z]);
+  const uint32_t* __restrict__ Pi = static_cast<const uint32_t*>(Pip.p[blockIdx.z]);
+  const uint64_t* __restrict__ S = static_cast<const uint64_t*>(Sp.p[blockIdx.z]);
+  const uint64_t* __restrict__ omega = static_cast<const uint64_t*>(omegap.p[blockIdx.z]);
+  constexpr int GR = 8;                      // rows per load group
+  __shared__ unsigned om_lo[256], om_hi[256];
+  __shared__ long long rowsum[4][256];
+  __shared__ long long ssum[4], osum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {
+    const uint64_t o = omega[threadIdx.x];
+    om_lo[threadIdx.x] = (unsigned)(o & 0xFFFFF);
+    om_hi[threadIdx.x] = (unsigned)(o >> 20);
+    // sum_m omega[m] (< 2^48): halves summed across the wave (64 x 2^20 and 64 x 2^20: no overflow)
+    const int lo = wave_sum_to_lane63((int)(o & 0xFFFFF)), hi = wave_sum_to_lane63((int)(o >> 20));
+    if (lane == 63) osum[wave] = (long long)lo + ((long long)hi << 20);
+  }
+  const size_t cols = (size_t)n * D;
+  const unsigned i = blockIdx.y;
+  const size_t col0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+  const bool active = col0 < cols;
+  unsigned s_lo[16], s_hi[SMALL ? 1 : 16], wl[16], wh[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) { s_lo[c] = 0; wl[c] = 0; wh[c] = 0; }
+  if (!SMALL) {
+#pragma unroll
+    for (int c = 0; c < 16; c++) s_hi[SMALL ? 0 : c] = 0;
+  }
+  long long my_s = 0;
+  if (active) {
+    const uint64_t* sp = S + ((col0 / D) * r + i) * D + (col0 % D);
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) {
+      const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(sp + c);
+      if (SMALL) {
+        s_lo[c] = (unsigned)v.x & 0xFFFFFF; s_lo[c + 1] = (unsigned)v.y & 0xFFFFFF;
+      } else {
+        s_lo[c] = (unsigned)(v.x & 0xFFFFF); s_hi[SMALL ? 0 : c] = (unsigned)(v.x >> 20);
+        s_lo[c + 1] = (unsigned)(v.y & 0xFFFFF); s_hi[SMALL ? 0 : c + 1] = (unsigned)(v.y >> 20);
+      }
+      my_s += (long long)(SMALL ? (v.x & 0xFFFFFF) : v.x) + (long long)(SMALL ? (v.y & 0xFFFFFF) : v.y);
+    }
+  }
+  {  // this block's sum of witness coefficients (< 4096 * 2^40): 20-bit pieces summed across the wave
+    const int p0 = wave_sum_to_lane63((int)(my_s & 0xFFFFF)), p1 = wave_sum_to_lane63((int)((my_s >> 20) & 0xFFFFF)),
+              p2 = wave_sum_to_lane63((int)(my_s >> 40));
+    if (lane == 63) ssum[wave] = (long long)p0 + ((long long)p1 << 20) + ((long long)p2 << 40);
+  }
+  __syncthreads();
+  // inactive threads (ragged last chunk) read dword 0 of their row: no divergence in the loop, their witness
+  // coefficients are 0 (row sums unaffected) and their column sums are never stored
+  // row m of this matrix = a wave-uniform base (scalar registers, advanced per row) + one 32-bit dword index per lane
+  const size_t row_dwords = cols / 16;
+  const uint32_t* rows = Pi + (size_t)i * 256 * row_dwords;
+  const unsigned voff = active ? (unsigned)(col0 / 16) : 0u;
+  uint32_t cur[GR], nxt[GR];
+#pragma unroll
+  for (int u = 0; u < GR; u++) cur[u] = __builtin_nontemporal_load(rows + (size_t)u * row_dwords + voff);
+#pragma unroll 1
+  for (int m0 = 0; m0 < 256; m0 += GR) {
+    if (m0 + GR < 256) {
+      const uint32_t* nrows = rows + (size_t)(m0 + GR) * row_dwords;
+#pragma unroll
+      for (int u = 0; u < GR; u++) nxt[u] = __builtin_nontemporal_load(nrows + (size_t)u * row_dwords + voff);
+    }
+#pragma unroll
+    for (int u = 0; u < GR; u++) {
+      const int m = m0 + u;
+      const uint32_t w = cur[u];
+      const unsigned ol = om_lo[m], oh = om_hi[m];
+      unsigned a_lo = 0, a_hi = 0;
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        const unsigned g = (w >> (2 * c)) & 3u;          // e + 1
+        a_lo = __umul24(g, s_lo[c]) + a_lo;
+        if (!SMALL) a_hi = __umul24(g, s_hi[SMALL ? 0 : c]) + a_hi;
+        wl[c] = __umul24(g, ol) + wl[c];
+        wh[c] = __umul24(g, oh) + wh[c];
+      }
+      if (SMALL) { a_hi = a_lo >> 20; a_lo &= 0xFFFFF; }   // a < 16 * 2 * 2^24: split so that the wave sums stay below 2^32
+      a_lo = (unsigned)wave_sum_to_lane63((int)a_lo);
+      a_hi = (unsigned)wave_sum_to_lane63((int)a_hi);
+      if (lane == 63) rowsum[wave][m] = (long long)a_lo + ((long long)a_hi << 20);
+    }
+#pragma unroll
+    for (int u = 0; u < GR; u++) cur[u] = nxt[u];
+  }
+  __syncthreads();
+  {
+    const int m = threadIdx.x;
+    const long long t = rowsum[0][m] + rowsum[1][m] + rowsum[2][m] + rowsum[3][m] - (ssum[0] + ssum[1] + ssum[2] + ssum[3]);
+    if (t != 0) atomicAdd(&proj[m], (unsigned long long)t);
+  }
+  if (active) {
+    const size_t x = col0 / D, k0 = col0 % D;
+    const long long om_total = osum[0] + osum[1] + osum[2] + osum[3];
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+      const long long v = (long long)wl[c] + ((long long)wh[c] << 20) - om_total;   // sum_m omega[m]*Pi[m][col], |v| < 2^49
+      const uint64_t mag = (uint64_t)(v < 0 ? -v : v) % q;
+      const uint64_t u = v < 0 ? (mag == 0 ? 0 : q - mag) : mag;
+      const size_t k = k0 + c;
+      W[(x * r + i) * D + (k == 0 ? 0 : D - k)] = k == 0 ? u : (u == 0 ? 0 : q - u);
+    }
+  }
+}
+
+// Pi int8 [count] in {-1, 0, 1} -> 2 bits per entry (e + 1), 16 entries per thread
+__global__ void k_pi_pack(uint32_t* __restrict__ dst, const int8_t* __restrict__ src, size_t ndwords) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= ndwords) return;
+  const uint4 v = *reinterpret_cast<const uint4*>(src + k * 16);
+  const uint32_t ww[4] = {v.x, v.y, v.z, v.w};
+  uint32_t o = 0;
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    const int e = (int)(int8_t)(ww[c >> 2] >> ((c & 3) * 8));
+    o |= (uint32_t)((e + 1) & 3) << (2 * c);
+  }
+  dst[k] = o;
+}
+
+hipError_t launch_pi_pack(uint8_t* dst, const int8_t* src, size_t count, hipStream_t s) {
+  if (count % 16) return hipErrorInvalidValue;
+  const size_t nd = count / 16;
+  if (nd == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_pi_pack, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, reinterpret_cast<uint32_t*>(dst), src, nd);
+  return hipGetLastError();
+}
+
+// packed = true: `Pi` holds the 2-bit form (see k_pi_fused2); small_witness: witness coefficients are known to be below 2^24
+hipError_t launch_pi_fused2_jobs(const JobPtrs& proj /*zeroed*/, const JobPtrs& W, const JobPtrs& Pi2, const JobPtrs& S,
+                                 const JobPtrs& omega, size_t n, size_t r, uint64_t q, size_t njobs, bool small_witness, hipStream_t s) {
+  if (n == 0 || r == 0 || njobs == 0) return hipSuccess;
+  const size_t cols = n * D;
+  const dim3 g((unsigned)((cols + 4095) / 4096), (unsigned)r, (unsigned)njobs);
+  if (small_witness)
+    hipLaunchKernelGGL(k_pi_fused2<true>, g, dim3(256), 0, s, proj, W, Pi2, S, omega, (unsigned)n, (unsigned)r, q);
+  else
+    hipLaunchKernelGGL(k_pi_fused2<false>, g, dim3(256), 0, s, proj, W, Pi2, S, omega, (unsigned)n, (unsigned)r, q);
+  return hipGetLastError();
+}
+
 hipError_t launch_pi_fused_jobs(const JobPtrs& proj /*zeroed*/, const JobPtrs& W, const JobPtrs& Pi, const JobPtrs& S,
                                 const JobPtrs& omega, size_t n, size_t r, uint64_t q, size_t njobs, hipStream_t s) {
   if (n == 0 || r == 0 || njobs == 0) return hipSuccess;

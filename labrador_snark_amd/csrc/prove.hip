@@ -57,6 +57,7 @@ struct Job {  // device pointers of one proof of the batch
   uint64_t* dproj;
   const uint64_t *dS, *dphi, *da, *domega, *dalpha, *dbeta, *dc;
   const int8_t* dPi;
+  const uint8_t* dPi2;
 };
 
 }  // namespace
@@ -96,8 +97,10 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if (r > 4096 || n > (1u << 22) || kappa > (1u << 24) || k1 > (1u << 24)) return fail(c, LAB_ERR_ARG, "lab_prove_core: dimension too large");
   for (size_t j = 0; j < np; j++) {
     const lab_prove_input* x = ins[j];
-    if (!x->S || !x->phi || !x->a || !x->Pi || !x->omega || !x->alpha || !x->beta || !x->c)
+    if (!x->S || !x->phi || !x->a || (!x->Pi && !x->Pi2) || !x->omega || !x->alpha || !x->beta || !x->c)
       return fail(c, LAB_ERR_ARG, "lab_prove_core: null input array");
+    if ((x->Pi2 != nullptr) != (in->Pi2 != nullptr))
+      return fail(c, LAB_ERR_ARG, "lab_prove_core_batch: either every proof of a batch hands over Pi2 (2 bits per entry) or none");
     if (x->n != n || x->r != r || x->kappa != kappa || x->kappa1 != k1 || x->kappa2 != k2 || x->t1 != t1 || x->t2 != t2 ||
         x->b1 != in->b1 || x->b2 != in->b2 || x->beta_bound != in->beta_bound || x->A != in->A || x->B != in->B || x->B8 != in->B8 || x->A8 != in->A8 || x->C8 != in->C8 || x->D8 != in->D8 || x->A8d != in->A8d ||
         x->C != in->C || x->Dm != in->Dm || x->a_off != in->a_off || x->b_off != in->b_off || x->c_off != in->c_off ||
@@ -198,7 +201,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   for (size_t j = 0; j < np; j++) {
     const lab_prove_input* x = ins[j];
     bytes += Staging::need(x->S, nr * D * 8) + Staging::need(x->phi, nr * D * 8) + Staging::need(x->a, rr * D * 8) +
-             Staging::need(x->Pi, r * 256 * n * D) + Staging::need(x->omega, 256 * 8) + Staging::need(x->alpha, D * 8) +
+             (x->Pi2 ? Staging::need(x->Pi2, r * 256 * n * (D / 4)) : Staging::need(x->Pi, r * 256 * n * D)) + Staging::need(x->omega, 256 * 8) + Staging::need(x->alpha, D * 8) +
              Staging::need(x->beta, D * 8) + Staging::need(x->c, r * D * 8);
   }
   // int8-MFMA step 3: padded set count of the largest group and its scratch (B-operand tiles + int32 results)
@@ -244,7 +247,9 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     if ((rc = st.in(x->S, nr * D, &J.dS))) return rc;
     if ((rc = st.in(x->phi, nr * D, &J.dphi))) return rc;
     if ((rc = st.in(x->a, rr * D, &J.da))) return rc;
-    if ((rc = st.in(x->Pi, r * 256 * n * D, &J.dPi))) return rc;
+    J.dPi = nullptr; J.dPi2 = nullptr;
+    if (x->Pi2) { if ((rc = st.in(x->Pi2, r * 256 * n * (D / 4), &J.dPi2))) return rc; }
+    else if ((rc = st.in(x->Pi, r * 256 * n * D, &J.dPi))) return rc;
     if ((rc = st.in(x->omega, (size_t)256, &J.domega))) return rc;
     if ((rc = st.in(x->alpha, (size_t)D, &J.dalpha))) return rc;
     if ((rc = st.in(x->beta, (size_t)D, &J.dbeta))) return rc;
@@ -430,7 +435,11 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   // ================= step 5 (:161-186, 429-456): JL projection over the integers
   // (one pass over Pi also produces W, the Pi part of phi'' used in step 6)
   LAB_HIP(c, hipMemsetAsync(proj_all, 0, np * 256 * 8, s));
-  LAB_HIP(c, launch_pi_fused_jobs(JP(&Job::dproj_int), JP(&Job::cW), JP(&Job::dPi), JP(&Job::dS), JP(&Job::domega), n, r, q, np, s));
+  if (in->Pi2)   // 2 bits per entry; with the digit-basis step 1 the witness is inside its norm bound (coefficients < 2^24) or the batch is redone
+    LAB_HIP(c, launch_pi_fused2_jobs(JP(&Job::dproj_int), JP(&Job::cW), JP(&Job::dPi2), JP(&Job::dS), JP(&Job::domega), n, r, q, np,
+                                     a8d != nullptr, s));
+  else
+    LAB_HIP(c, launch_pi_fused_jobs(JP(&Job::dproj_int), JP(&Job::cW), JP(&Job::dPi), JP(&Job::dS), JP(&Job::domega), n, r, q, np, s));
   LAB_HIP(c, launch_lift_i64_jobs(JP(&Job::dproj), JP(&Job::dproj_int), 256, q, np, s));
 
   // ================= steps 6-8 (:205-289, :301-314, :320-358).  phi''_i = psi phi'_i + W_i and phi_i = alpha phi'_i + beta phi''_i

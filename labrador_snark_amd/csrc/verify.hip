@@ -32,7 +32,7 @@ extern "C" int lab_verify_core(lab_ctx* c, const lab_prove_input* in, const lab_
   if (k1 != k2) return fail(c, LAB_ERR_LEN_MISMATCH, "lab_verify_core: kappa1 != kappa2");
   if (t1 < 1 || t2 < 1 || t1 > 64 || t2 > 64 || in->b1 < 2 || in->b2 < 2 || bconst < 2)
     return fail(c, LAB_ERR_DECOMPOSE, "lab_verify_core: bad decomposition parameters");
-  if (!in->phi || !in->a || !in->Pi || !in->omega || !in->alpha || !in->beta || !in->c)
+  if (!in->phi || !in->a || (!in->Pi && !in->Pi2) || !in->omega || !in->alpha || !in->beta || !in->c)
     return fail(c, LAB_ERR_ARG, "lab_verify_core: null input array");
   if (!pf->u_1 || !pf->b_prime_prime || !pf->u_2 || !pf->z || !pf->t_i_all || !pf->g_mat || !pf->h_mat)
     return fail(c, LAB_ERR_ARG, "lab_verify_core: null transcript field");
@@ -99,7 +99,8 @@ extern "C" int lab_verify_core(lab_ctx* c, const lab_prove_input* in, const lab_
   size_t bytes = Carver::padded((size_t)L * hat_words * 4) + Carver::padded((size_t)Ld * hatd_words * 4) +
                  Carver::padded((size_t)L * tmp_elems * D * 4) +
                  coef_elems * D * 8 + 2 * Carver::padded(npoly_norm * 8) + 64 * 256 + (1 << 16);
-  bytes += Staging::need(in->phi, nr * D * 8) + Staging::need(in->a, rr * D * 8) + Staging::need(in->Pi, r * 256 * n * D) +
+  bytes += Staging::need(in->phi, nr * D * 8) + Staging::need(in->a, rr * D * 8) +
+           (in->Pi2 ? Staging::need(in->Pi2, r * 256 * n * (D / 4)) + Carver::padded(nr * D * 8) + 4096 : Staging::need(in->Pi, r * 256 * n * D)) +
            Staging::need(in->omega, 256 * 8) + Staging::need(in->alpha, D * 8) + Staging::need(in->beta, D * 8) +
            Staging::need(in->c, r * D * 8) + Staging::need(pf->u_1, k1 * D * 8) + Staging::need(pf->u_2, k2 * D * 8) +
            Staging::need(pf->z, n * D * 8) + Staging::need(pf->t_i_all, rk * D * 8) + Staging::need(pf->g_mat, rr * D * 8) +
@@ -124,7 +125,10 @@ extern "C" int lab_verify_core(lab_ctx* c, const lab_prove_input* in, const lab_
   const int8_t* dPi;
   if ((rc = st.in(in->phi, nr * D, &dphi))) return rc;
   if ((rc = st.in(in->a, rr * D, &da))) return rc;
-  if ((rc = st.in(in->Pi, r * 256 * n * D, &dPi))) return rc;
+  const uint8_t* dPi2 = nullptr;
+  dPi = nullptr;
+  if (in->Pi2) { if ((rc = st.in(in->Pi2, r * 256 * n * (D / 4), &dPi2))) return rc; }
+  else if ((rc = st.in(in->Pi, r * 256 * n * D, &dPi))) return rc;
   if ((rc = st.in(in->omega, (size_t)256, &domega))) return rc;
   if ((rc = st.in(in->alpha, (size_t)D, &dalpha))) return rc;
   if ((rc = st.in(in->beta, (size_t)D, &dbeta))) return rc;
@@ -155,7 +159,17 @@ extern "C" int lab_verify_core(lab_ctx* c, const lab_prove_input* in, const lab_
   // lines 3-4 (src/verification.rs:38-89): a'' = psi a', phi''_i
   const uint64_t psi = in->psi % q;
   LAB_HIP(c, launch_coef_elementwise(capp, da, nullptr, rr, q, psi, 0, s));
-  LAB_HIP(c, launch_phi_pi_part(cW, dPi, domega, n, r, q, s));
+  if (dPi2) {   // 2-bit Pi: the prover's fused pass with an all-zero witness (its projection output is not used here)
+    uint64_t* zeroS = cv.take<uint64_t>(nr * D);
+    uint64_t* dummy_proj = cv.take<uint64_t>(256);
+    LAB_HIP(c, hipMemsetAsync(zeroS, 0, nr * D * 8, s));
+    LAB_HIP(c, hipMemsetAsync(dummy_proj, 0, 256 * 8, s));
+    JobPtrs pj, wj, pij, sj, oj;
+    pj.p[0] = dummy_proj; wj.p[0] = cW; pij.p[0] = const_cast<uint8_t*>(dPi2); sj.p[0] = zeroS; oj.p[0] = const_cast<uint64_t*>(domega);
+    LAB_HIP(c, launch_pi_fused2_jobs(pj, wj, pij, sj, oj, n, r, q, 1, false, s));
+  } else {
+    LAB_HIP(c, launch_phi_pi_part(cW, dPi, domega, n, r, q, s));
+  }
   LAB_HIP(c, launch_coef_elementwise(cphipp, dphi, cW, nr, q, psi, 1, s));
   if ((rc = to_hat(c, capp, HV(happ), rr))) return rc;
   if ((rc = to_hat(c, cphipp, HV(hphipp), nr))) return rc;

@@ -309,6 +309,38 @@ def _io_template(k, crs):
     return pin
 
 
+def pack_pi(ctx, Pi):
+    """sample_jl_projection's matrices from int8 {-1,0,1} to 2 bits per entry (lab_pi_pack; lab_prove_input.Pi2):
+    same shape with the last axis a quarter as long, uint8; numpy in -> numpy out, cuda tensor in -> cuda tensor out."""
+    if isinstance(Pi, np.ndarray):
+        Pi = np.ascontiguousarray(Pi, dtype=np.int8)
+        out = np.empty(Pi.shape[:-1] + (Pi.shape[-1] // 4,), dtype=np.uint8)
+        count = Pi.size
+    else:
+        import torch
+        Pi = Pi.contiguous()
+        out = torch.empty(tuple(Pi.shape[:-1]) + (Pi.shape[-1] // 4,), dtype=torch.uint8, device=Pi.device)
+        count = Pi.numel()
+    ctx._check(ctx._lib.lab_pi_pack(ctx._h, _ptr(out), _ptr(Pi), count))
+    return out
+
+
+def _set_pi(pin, tape, keep):
+    """tape["Pi2"] (2 bits per entry, pack_pi) takes precedence over tape["Pi"] (int8)."""
+    if tape.get("Pi2") is not None:
+        Pi2 = tape["Pi2"]
+        if isinstance(Pi2, np.ndarray):
+            Pi2 = np.ascontiguousarray(Pi2, dtype=np.uint8)
+        keep.append(Pi2)
+        pin.Pi2, pin.Pi = _ptr(Pi2), None
+        return
+    Pi = tape["Pi"]
+    if isinstance(Pi, np.ndarray):
+        Pi = np.ascontiguousarray(Pi, dtype=np.int8)
+    keep.append(Pi)
+    pin.Pi, pin.Pi2 = _ptr(Pi), None
+
+
 def _prove_io(ctx, k, witness, st, crs, tape, device_outputs, out_views=None, template=None):
     """ctypes input/output structs for one proof; returns (lab_prove_input, lab_transcript, Transcript, keep-alive list).
     out_views: preallocated device tensors for the nine outputs (prove_core_batch slices them out of one allocation
@@ -327,11 +359,7 @@ def _prove_io(ctx, k, witness, st, crs, tape, device_outputs, out_views=None, te
 
     pin.S, pin.phi, pin.a = p64(witness), p64(st.phi), p64(st.a)
     pin.b_prime = st.b_prime
-    Pi = tape["Pi"]
-    if isinstance(Pi, np.ndarray):
-        Pi = np.ascontiguousarray(Pi, dtype=np.int8)
-    keep.append(Pi)
-    pin.Pi = _ptr(Pi)
+    _set_pi(pin, tape, keep)
     pin.psi = int(tape["psi"])
     pin.omega, pin.alpha, pin.beta, pin.c = p64(tape["omega"]), p64(tape["alpha"]), p64(tape["beta"]), p64(tape["c"])
 
@@ -419,11 +447,7 @@ def verify_core(ctx, k, st, b_poly, crs, T, tape=None):
     pin.D8 = crs.D8._h if getattr(crs, "D8", None) is not None else None
     pin.A8d = crs.A8d._h if getattr(crs, "A8d", None) is not None else None
     pin.a_off = pin.b_off = pin.c_off = pin.d_off = 0
-    Pi = tape["Pi"]
-    if isinstance(Pi, np.ndarray):
-        Pi = np.ascontiguousarray(Pi, dtype=np.int8)
-    keep.append(Pi)
-    pin.Pi = _ptr(Pi)
+    _set_pi(pin, tape, keep)
     pin.psi = int(tape["psi"])
     pin.omega, pin.alpha, pin.beta, pin.c = p64(tape["omega"]), p64(tape["alpha"]), p64(tape["beta"]), p64(tape["c"])
     tr = _lib.lab_transcript()

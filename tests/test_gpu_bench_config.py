@@ -65,7 +65,10 @@ def test_bench_transcript_spot_rows_against_the_oracle(bench_run, j):
     phi = _host(R["sts"][j].phi).reshape(n, r, D)
     a = _host(R["sts"][j].a).reshape(r, r, D)
     tape = R["dtapes"][j]
-    Pi = tape["Pi"].cpu().numpy()
+    packed = tape["Pi2"].cpu().numpy()                      # bench.py's default: Pi at 2 bits per entry (field = entry + 1)
+    Pi = np.empty(packed.shape[:-1] + (packed.shape[-1] * 4,), np.int8)
+    for f in range(4):
+        Pi[..., f::4] = ((packed >> (2 * f)) & 3).astype(np.int8) - 1
     omega, alpha, beta, c = (_host(tape[x]) for x in ("omega", "alpha", "beta", "c"))
     psi = int(tape["psi"])
     F = _fields(T)

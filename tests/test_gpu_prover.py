@@ -1,6 +1,8 @@
 """GPU parity of the fused prover core (lab_prove_core) vs the oracle's restatement of
 Prover::proof_gen (src/proofgen.rs:30-427): every transcript field bit-exact, then the oracle's restated
 Verifier::verify accepts the GPU transcript (the reference's CI invariant, src/main.rs:106-107)."""
+import copy
+
 import numpy as np
 import pytest
 
@@ -354,5 +356,87 @@ def test_prove_core_batch_matrix_cores_r32(nb, mfma_basis):
         for f in ("t_i_all", "g_mat", "h_mat", "u_1", "u_2", "z", "b_prime_prime", "projection_int"):
             assert np.array_equal(getattr(got[j], f), getattr(ref[j], f)), (j, f)
     assert np.array_equal(got[-1].t_i_all, want_last["t"]) and np.array_equal(got[-1].u_1, want_last["u1"])
+    crs.close()
+    ctx.close()
+
+
+def _pack_pi_numpy(Pi):
+    f = (Pi.astype(np.int16) + 1).astype(np.uint8).reshape(Pi.shape[:-1] + (Pi.shape[-1] // 4, 4))
+    return np.ascontiguousarray(f[..., 0] | (f[..., 1] << 2) | (f[..., 2] << 4) | (f[..., 3] << 6))
+
+
+@pytest.mark.parametrize("q", ALL_Q)
+@pytest.mark.parametrize("n,r", [(4, 3), (65, 2), (128, 1)])
+def test_packed_pi_gives_the_same_transcript(q, n, r):
+    # Pi at 2 bits per entry (lab_prove_input.Pi2, lab_pi_pack) against the int8 form: every transcript field, for a
+    # norm-bounded witness and for a full-range one (raw residues up to q - 1: the projection is then rejected, its
+    # integer value is still produced); 256, 4160 (one full + one ragged 4096-column chunk) and 8192 columns
+    import labrador_snark_amd as lab
+    kappa, kappa1 = 8, 5
+    ctx = lab.Context(q, 0)
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
+    crs = lab.ResidentCRS(ctx, k).fill_synthetic(1000)
+    S, phi, a, tape = cases.make_inputs(p, seed=4242 + n)
+    packed = lab.pack_pi(ctx, tape["Pi"])
+    assert packed.dtype == np.uint8 and np.array_equal(packed, _pack_pi_numpy(tape["Pi"]))
+    tape2 = dict(tape)
+    del tape2["Pi"]
+    tape2["Pi2"] = packed
+    rng = np.random.default_rng(7)
+    S_full = rng.integers(0, q, size=S.shape, dtype=np.uint64)
+    S_full[0, 0, :4] = q - 1
+    for W in (S, S_full):
+        st = lab.State(phi, a, int(lab.gen_f_b(ctx, W, phi, a, n, r)[0]))
+        (T1,), c1 = lab.prove_core_batch(ctx, k, [W], [st], crs, [tape], raise_on_reject=False)
+        (T2,), c2 = lab.prove_core_batch(ctx, k, [W], [st], crs, [tape2], raise_on_reject=False)
+        assert c1 == c2
+        for f in ("projection_int", "projection", "b_prime_prime", "h_mat", "u_2", "u_1", "z", "t_i_all", "g_mat"):
+            assert np.array_equal(getattr(T1, f), getattr(T2, f)), f
+    # the verifier takes the packed form too
+    st = lab.State(phi, a, int(lab.gen_f_b(ctx, S, phi, a, n, r)[0]))
+    b_poly = lab.gen_f_b(ctx, S, phi, a, n, r)
+    T = lab.prove_core(ctx, k, S, st, crs, tape2)
+    kinf = copy.copy(k)
+    kinf.BETA_PRIME = float("inf")
+    assert lab.verify_core(ctx, kinf, st, b_poly, crs, T, tape=tape2)[0] == lab.verify_core(ctx, kinf, st, b_poly, crs, T, tape=tape)[0] == 0
+    crs.close()
+    ctx.close()
+
+
+def test_packed_pi_on_the_norm_bounded_fast_path_and_its_fallback():
+    # with step 1 in the digit basis (A8d) the witness is inside its norm bound or the batch is redone, so the packed-Pi pass
+    # uses one multiply-add per entry for the projection (coefficients < 2^24); a witness above the bound takes the general
+    # pass in the redone batch — both equal the int8 form
+    import labrador_snark_amd as lab
+    q, n, r, kappa, kappa1 = Q_REF33, 4, 8, 64, 20
+    ctx = lab.Context(q, 0)
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
+    crs = lab.ResidentCRS(ctx, k, mfma_basis=True).fill_synthetic(1000)
+    crs.pack_mfma()
+    ws, sts, tapes, tapes2 = [], [], [], []
+    for j in range(3):
+        case, (S, phi, a, tape) = cases.oracle_case(p, seed=900 + j)
+        S = S.copy()
+        S[0, 0, 0] = min(k.BETA_BOUND // 2, (1 << 24) - 1)        # a coefficient that needs all 24 bits of the fast path
+        st = lab.State(phi, a, int(lab.gen_f_b(ctx, S, phi, a, n, r)[0]))
+        ws.append(S); sts.append(st); tapes.append(tape)
+        t2 = {kk: v for kk, v in tape.items() if kk != "Pi"}
+        t2["Pi2"] = lab.pack_pi(ctx, tape["Pi"])
+        tapes2.append(t2)
+    ref, c_ref = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes, raise_on_reject=False)
+    assert ctx.prove_flags() == 1
+    got, c_got = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes2, raise_on_reject=False)
+    assert ctx.prove_flags() == 1 and c_ref == c_got
+    big = [w.copy() for w in ws]
+    big[1][2, 3, 5] = q - 1
+    ref2, c_ref2 = lab.prove_core_batch(ctx, k, big, sts, crs, tapes, raise_on_reject=False)
+    got2, c_got2 = lab.prove_core_batch(ctx, k, big, sts, crs, tapes2, raise_on_reject=False)
+    assert ctx.prove_flags() == 2 and c_ref2 == c_got2
+    for A, B in ((ref, got), (ref2, got2)):
+        for j in range(3):
+            for f in ("projection_int", "projection", "b_prime_prime", "h_mat", "u_2", "u_1", "z", "t_i_all", "g_mat"):
+                assert np.array_equal(getattr(A[j], f), getattr(B[j], f)), (j, f)
     crs.close()
     ctx.close()

@@ -11,6 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 4 --warmup 1 > $O/trace_bench.json 2> $O/trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 > $O/pmc_fetch_bench.json 2> $O/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 > $O/pmc_write_bench.json 2> $O/pmc_write.err
+rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_clk -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 > $O/pmc_clk_bench.json 2> $O/pmc_clk.err
 # keep what travels back small: the per-dispatch CSVs are large
 find $O -name '*_agent_info.csv' -delete
 ls -la $O $O/*/* | head -40

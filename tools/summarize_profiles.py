@@ -9,7 +9,7 @@ import json
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 P = "gpurun_out/prof/"
 # the dominant kernel is the one bench.py's profiling hook reports ("lab::<name> — ...")
 DOM = sys.argv[2] if len(sys.argv) > 2 else json.load(open(P + "bench_n1.json"))["roofline"]["kernel"].split(" — ")[0].replace("lab::", "")
@@ -50,6 +50,21 @@ out = {"kernel": "lab::" + DOM + " (step-3 launch of bench.py: nmat=96, rows=102
        "kernel_ns_under_pmc": fs[1],
        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --no-cpu-baseline "
                   "--no-extras --steps 2 --warmup 1  (tools/run_profiles.sh)"}
+# clock the chip holds under the dominant launch: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / duration (MI355X_MICROARCH.md 'DVFS give-back')
+try:
+    f = newest(P + "pmc_clk/*/*_counter_collection.csv")
+    clk = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            if dur > 200000:      # the quotient reads high on short dispatches
+                clk[r["Kernel_Name"].split("(")[0]].append((float(r["Counter_Value"]) / 8.0 / dur, dur))
+    out["clock_GHz_by_kernel"] = {k: {"launches": len(v), "avg_ms": sum(d for _, d in v) / len(v) / 1e6,
+                                      "GHz_min": min(c for c, _ in v), "GHz_avg": sum(c for c, _ in v) / len(v), "GHz_max": max(c for c, _ in v)}
+                                  for k, v in sorted(clk.items(), key=lambda kv: -sum(d for _, d in kv[1]))}
+    out["clock_method"] = "rocprofv3 --pmc GRBM_GUI_ACTIVE (own pass): counter / 8 XCDs / dispatch duration, dispatches longer than 0.2 ms"
+except Exception as e:      # pass not run
+    out["clock_GHz_by_kernel"] = None
 json.dump(out, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
 
 tr = list(csv.DictReader(open(newest(P + "trace/*/*_kernel_trace.csv"))))
