@@ -38,19 +38,18 @@ def ring_products_per_proof(n, r, kappa, kappa1, kappa2, t1, t2):
             "8_H": 2 * r * r * n, "9_u2": pairs * t1 * kappa2, "10_z": r * n}
 
 
-def cpu_baseline(q, products_per_proof, seconds=12.0):
-    """Reference-faithful CPU port (oracle orc_polymul_faithful: i128 `%` after every coefficient op, like
+def cpu_baseline_b0(q, products_per_proof, seconds=6.0):
+    """B0, reference-faithful CPU port (oracle orc_polymul_faithful: i128 `%` after every coefficient op, like
     src/algebraic.rs:30-38,95-134) timed on this host on a bounded sample of ring products, all threads
     busy; proofs/s is extrapolated from the measured products/s and the per-proof product count."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import coracle as co
     lib = co.lib()
-    cores = max(1, min(16, os.cpu_count() or 1))
+    cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     rng = np.random.default_rng(123)
     length = 64
     data = [(rng.integers(0, q, size=(length, D), dtype=np.uint64), rng.integers(0, q, size=(length, D), dtype=np.uint64))
             for _ in range(cores)]
-    # calibrate
     t0 = time.perf_counter()
     lib.orc_bench_inner_product_faithful(q, data[0][0], data[0][1], length, 1)
     per_call = max(time.perf_counter() - t0, 1e-6)
@@ -65,11 +64,72 @@ def cpu_baseline(q, products_per_proof, seconds=12.0):
     dt = time.perf_counter() - t0
     products = cores * reps * length
     rate = products / dt
-    return {"value": rate / products_per_proof, "unit": "constraints/s", "cores": cores, "kind": "port",
-            "products_per_s": rate, "extrapolated": True,
+    return {"value": rate / products_per_proof, "unit": "constraints/s", "cores": cores, "kind": "port", "products_per_s": rate,
+            "extrapolated": True,
             "sample": "%d reference-faithful ring products (schoolbook 64x64, i128 %% per op + X^64+1 fold + accumulate) "
-                      "on %d threads in %.1f s; proofs/s = products/s / %d products per proof"
-                      % (products, cores, dt, products_per_proof)}
+                      "on %d threads in %.1f s; proofs/s = products/s / %d products per proof" % (products, cores, dt, products_per_proof)}
+
+
+def cpu_baseline_b1(k, q, proofs=3):
+    """B1, the honest-fast CPU prover (oracle/fastcpu.c: RNS/NTT residues, transform-domain accumulation, phi never
+    formed, OpenMP over output rows, CRS resident in the transform domain like on the GPU), measured DIRECTLY at the
+    bench's sizes: `proofs` full proof_gen calls after one warm-up, all host threads.  The 6.4e9-coefficient B is filled
+    with uniform residues directly in the transform domain (a uniform matrix is uniform in either domain; transforming
+    1e8 polynomials on the host would take longer than the measurement); A, C, D come from the shared synthetic streams."""
+    from oracle import coracle as co
+    from oracle import fastcpu as fc
+    n, r, kappa = k.N, k.R, k.KAPPA
+    pairs = r * (r + 1) // 2
+    f = fc.FastCpu(q, max(65536, n * r + r * r), 0)
+    t0 = time.perf_counter()
+    A = f.synthetic_hat(1000, kappa * n)
+    B = f.random_hat(1001, r * k.T_1 * k.KAPPA_1 * kappa)
+    Cm = f.synthetic_hat(1002, pairs * k.T_2 * k.KAPPA_2)
+    Dm = f.synthetic_hat(1003, pairs * k.T_1 * k.KAPPA_2)
+    t_fill = time.perf_counter() - t0
+    S, phi, a, tape = make_inputs(k, q, seed=50)
+    dummy = np.zeros((1, D), np.uint64)
+    case = co.ProverCase(q, n, r, kappa, k.KAPPA_1, k.KAPPA_2, k.B_1, k.T_1, k.B_2, k.T_2, k.BETA_BOUND, S, phi, a, dummy, dummy, dummy,
+                         dummy, tape["Pi"], tape["psi"], tape["omega"], tape["alpha"], tape["beta"], tape["c"])
+    f.prove(case, A, B, Cm, Dm)          # warm-up (first touch of the scratch allocations)
+    t0 = time.perf_counter()
+    for _ in range(proofs):
+        out = f.prove(case, A, B, Cm, Dm)
+    dt = time.perf_counter() - t0
+    ok = bool(out["bpp_ok"])
+    threads, limbs = f.threads, f.L
+    f.close()
+    del A, B, Cm, Dm
+    return {"value": proofs / dt, "unit": "constraints/s", "cores": threads, "kind": "port", "extrapolated": False,
+            "s_per_proof": dt / proofs, "rns_limbs": limbs, "crs_fill_s": t_fill, "bpp_check_ok": ok,
+            "sample": "%d full proof_gen calls (n=%d r=%d kappa=kappa1=kappa2=%d, q=%d) of the honest-fast CPU prover "
+                      "(oracle/fastcpu.c: %d-limb RNS/NTT, transform-domain accumulation, OpenMP) on %d threads in %.1f s, "
+                      "CRS resident in the transform domain" % (proofs, n, r, kappa, q, limbs, threads, dt)}
+
+
+def cpu_config1(samples=1000):
+    """BASELINE configs[0] (benches/ntt_speed.rs:51-81 restated): one pair of uniform polynomials, a single ring product
+    timed `samples` times per arm, median ns — classic (i128 `%` per op, schoolbook + fold) vs through the NTT — at the
+    reference's default Q, its commented-out "32-bit" Q and the largest NTT-friendly prime below 2^32."""
+    from oracle import fastcpu as fc
+    out = {}
+    for name, qq in (("Q8191", 8191), ("Q2p32p15", (1 << 32) + 15), ("Q4294966657_ntt_friendly", 4294966657)):
+        out[name] = {"q": qq, "classic_median_ns": fc.bench_polymul(qq, "classic", samples), "ntt_median_ns": fc.bench_polymul(qq, "ntt", samples),
+                     "samples": samples}
+    return out
+
+
+def cpu_baseline(k, q, products_per_proof):
+    """The `cpu_baseline` object of the bench line: `value` is B1 (measured directly, the honest comparison); B0 (the
+    reference-faithful port, extrapolated) and config 1's single-product medians ride along."""
+    b1 = cpu_baseline_b1(k, q)
+    b0 = cpu_baseline_b0(q, products_per_proof)
+    res = dict(b1)
+    res["host_cpus"] = os.cpu_count()
+    res["b1_honest_fast"] = {kk: b1[kk] for kk in ("value", "s_per_proof", "cores", "rns_limbs", "crs_fill_s", "extrapolated")}
+    res["b0_reference_faithful"] = b0
+    res["config1_single_product"] = cpu_config1()
+    return res
 
 
 def challenge_poly(rng, q):
@@ -109,7 +169,9 @@ def make_inputs(k, q, seed, dev=None, packed_pi=False):
             Pi = (f[..., 0] | (f[..., 1] << 2) | (f[..., 2] << 4) | (f[..., 3] << 6)).contiguous()
             del f
     else:
-        Pi = rng.choice(np.array([-1, 0, 1], dtype=np.int8), size=(r, 256, n * D), p=[0.25, 0.5, 0.25]).astype(np.int8)
+        bits = rng.integers(0, 4, size=(r, 256, n * D), dtype=np.int8)       # two fair bits per entry, as on the device
+        Pi = (bits == 3).astype(np.int8) - (bits == 0).astype(np.int8)
+        del bits
     if packed_pi and dev is None:
         f = (Pi + 1).astype(np.uint8).reshape(r, 256, n * D // 4, 4)
         Pi = np.ascontiguousarray(f[..., 0] | (f[..., 1] << 2) | (f[..., 2] << 4) | (f[..., 3] << 6))
@@ -357,7 +419,7 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             counts = ring_products_per_proof(n, r, kappa, kappa, kappa, k.T_1, k.T_2)
-            result["cpu_baseline"] = cpu_baseline(q, sum(counts.values()))
+            result["cpu_baseline"] = cpu_baseline(k, q, sum(counts.values()))
         else:
             result["cpu_baseline"] = None
         if extras:

@@ -22,11 +22,12 @@ i8p = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
 def build(force=False):
     """(Re)build the shared object when it is missing or older than its sources.  Safe under concurrent callers
     (pytest-xdist workers, torchrun ranks): compile to a private temporary file, then rename atomically."""
-    src = [os.path.join(_HERE, f) for f in ("labrador_oracle.c", "labrador_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("labrador_oracle.c", "fastcpu.c", "labrador_oracle.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
         tmp = "%s.%d.tmp" % (_SO, os.getpid())
-        subprocess.check_call([os.environ.get("CC", "gcc"), "-O2", "-fPIC", "-Wall", "-Wextra", "-std=c11", "-shared", "-o", tmp,
-                               src[0], "-lm"])
+        # same flags as oracle/Makefile (no -march=native: the library travels to the GPU box)
+        subprocess.check_call([os.environ.get("CC", "gcc"), "-O3", "-fPIC", "-Wall", "-Wextra", "-std=gnu11", "-fopenmp", "-shared",
+                               "-o", tmp, src[0], src[1], "-lm"])
         os.replace(tmp, _SO)
     return _SO
 
