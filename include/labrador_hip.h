@@ -167,6 +167,16 @@ int lab_crs_expand(lab_ctx *ctx, lab_vec *dst, size_t dst_off, size_t count, con
 int lab_crs_expand_u64(lab_ctx *ctx, uint64_t *coeffs, size_t count, const uint8_t base_seed[32],
                        uint64_t offset_lo, uint64_t offset_hi);
 
+/* The outer commitment  out_s[rho] = sum_{m<nmat} < M_m[rho, :], V_s[m] >  (src/proofgen.rs:101-132) with the matrices M_m
+ * streamed from the seed instead of resident: M_m[rho][c] is the polynomial fetch_next_n returns for the 64 seeds
+ * base_seed + off_m + (rho*cols + c)*64 .. (src/structs.rs:147-171), off_m = mat_offsets[2m] + 2^64 * mat_offsets[2m+1]
+ * (coefficient units; for B_ik: CRS::fetch_B_ik_row's offset of row 0, src/structs.rs:78-82).  Slabs of 128 rows are
+ * expanded, transformed, packed and multiplied on the matrix cores (ns in {8,16,32,64} vector sets laid out as for
+ * lab_matvec_sum_mfma) and discarded: only a fixed working set exists in device memory.  Bit-identical to
+ * lab_crs_expand + lab_mat8_pack + lab_matvec_sum_mfma.  SURVEY §8(f) row f1. */
+int lab_crs_matvec_mfma(lab_ctx *ctx, lab_vec *out, size_t out_off, const uint8_t base_seed[32], const uint64_t *mat_offsets,
+                        size_t nmat, size_t rows, size_t cols, const lab_vec *V, size_t v_off, int ns);
+
 /* ---- src/util.rs vector helpers on hat vectors ---------------------------- */
 
 /* polynomial_vec_inner_product (src/util.rs:496-509): out[out_off] = sum_i v1[off1+i]*v2[off2+i] */
@@ -301,6 +311,12 @@ typedef struct {
                             * (lab_pi_pack), [r][256][n*64/4] bytes: entry (i, m, col) is the field 2*(col % 4) of byte
                             * (i*256 + m) * n*16 + col/4 and holds entry + 1 in {0, 1, 2}.  A quarter of the bytes of the int8
                             * form on the pass that reads Pi (the reference lifts it to 16-byte Zq, src/proofgen.rs:445-453) */
+  const uint8_t *crs_seed; /* optional, 32 bytes: CRS::base_seed (src/structs.rs:29, 173-189).  With B == NULL and B8 == NULL the
+                            * B_ik matrices are STREAMED from this seed (the rows fetch_B_ik_row regenerates on every fetch,
+                            * src/structs.rs:74-88): step 3 expands a slab of rows on the device, multiplies it with every proof
+                            * of the batch on the matrix cores and discards it (lab_crs_matvec_mfma) — B is never resident, so
+                            * the reference's own ranks kappa1 = kappa = n*64 (1 TiB per B_ik) are reachable.  A, C, D stay
+                            * resident vectors (expand them with lab_crs_expand).  lab_verify_core does not take this mode */
 } lab_prove_input;
 
 /* The computed fields of `Transcript` (src/structs.rs:192-209); pi_i_all, psi, omega, alpha, beta, c are the tape.

@@ -56,7 +56,7 @@ class lab_prove_input(C.Structure):
                 ("b_prime", C.c_uint64), ("A", C.c_void_p), ("a_off", C.c_size_t), ("B", C.c_void_p),
                 ("b_off", C.c_size_t), ("C", C.c_void_p), ("c_off", C.c_size_t), ("Dm", C.c_void_p),
                 ("d_off", C.c_size_t), ("Pi", C.c_void_p), ("psi", C.c_uint64), ("omega", C.c_void_p),
-                ("alpha", C.c_void_p), ("beta", C.c_void_p), ("c", C.c_void_p), ("B8", C.c_void_p), ("A8", C.c_void_p), ("C8", C.c_void_p), ("D8", C.c_void_p), ("A8d", C.c_void_p), ("Pi2", C.c_void_p)]
+                ("alpha", C.c_void_p), ("beta", C.c_void_p), ("c", C.c_void_p), ("B8", C.c_void_p), ("A8", C.c_void_p), ("C8", C.c_void_p), ("D8", C.c_void_p), ("A8d", C.c_void_p), ("Pi2", C.c_void_p), ("crs_seed", C.c_char_p)]
 
 
 class lab_transcript(C.Structure):
@@ -100,6 +100,8 @@ SIGNATURES = {
                                          C.c_uint64]),
     "lab_crs_expand": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_char_p, C.c_uint64, C.c_uint64]),
     "lab_crs_expand_u64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_uint64, C.c_uint64]),
+    "lab_crs_matvec_mfma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
+                                      C.c_void_p, C.c_size_t, C.c_int]),
     "lab_inner_product": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                     C.c_size_t, C.c_size_t]),
     "lab_matvec_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,

@@ -266,6 +266,19 @@ def matvec_sum_mfma(ctx, M8, V, ns, v_off=0, out=None, out_off=0):
     return out
 
 
+def crs_matvec_mfma(ctx, base_seed, mat_offsets, rows, cols, V, ns, v_off=0, out=None, out_off=0):
+    """lab_crs_matvec_mfma: out_s[rho] = sum_m <M_m[rho,:], V_s[m]> with the matrices regenerated from the CRS seed slab by
+    slab (never resident).  mat_offsets: the seed offset (coefficient units, python ints) of row 0 of every matrix."""
+    nmat = len(mat_offsets)
+    offs = np.empty(2 * nmat, dtype=np.uint64)
+    for m, o in enumerate(mat_offsets):
+        offs[2 * m], offs[2 * m + 1] = o & ((1 << 64) - 1), o >> 64
+    if out is None:
+        out = HatVec(ctx, ns * rows, digit=V.digit)
+    ctx._check(ctx._lib.lab_crs_matvec_mfma(ctx._h, out._h, out_off, bytes(base_seed), _ptr(offs), nmat, rows, cols, V._h, v_off, ns))
+    return out
+
+
 def ajtai_commit(ctx, A, S, rows, inner, ncols, a_off=0, s_off=0, out=None, out_off=0):
     """t_i_all[i][rho] = <A[rho,:], s_i> for every witness column (src/proofgen.rs:41-49). out: [ncols][rows]."""
     if out is None:

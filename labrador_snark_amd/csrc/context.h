@@ -158,6 +158,14 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
 size_t mfma_prepacked_bytes(const lab_mat8* m, int ns);
 int digits_to_v8_impl(lab_ctx* c, const lab_mat8* m, const JobPtrs& src16, int ns, int ns_valid, int8_t* dst);
 uint32_t mat8_min_prime(const lab_ctx* c, const lab_mat8* m);
+// the outer commitment with the matrices streamed from the CRS seed (crs_stream.hip)
+struct CrsStream;
+size_t crs_stream_scratch_bytes(lab_ctx* c, int basis, size_t nmat, size_t rows, size_t cols, int ns);
+int crs_stream_create(lab_ctx* c, int basis, size_t nmat, size_t rows, size_t cols, int ns, CrsStream** out);
+void crs_stream_destroy(CrsStream* st);
+int crs_stream_run(CrsStream* st, const uint8_t seed[32], const uint64_t* mat_offsets, size_t nmat, HatView out, size_t out_set_stride,
+                   const ConstHatView* V, size_t v_set_stride, const JobPtrs* dig, int ns, int ns_valid, void* scratch);
+uint32_t basis_min_prime(const lab_ctx* c, int basis);
 bool mat8_matches(const lab_mat8* m, int basis, size_t nmat, size_t rows, size_t cols);
 int mat8_basis(const lab_mat8* m);
 // launch_matvec_partial wrapped in the profiling events when the hook is active

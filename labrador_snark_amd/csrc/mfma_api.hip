@@ -12,6 +12,7 @@ struct lab_mat8 {
   int basis = 0;
   int nlimbs = 0;
   size_t nmat = 0, rows = 0, cols = 0;
+  size_t rows_alloc = 0;                  // mat8_alloc: rows of the buffer layout (`rows` = those the current contents fill)
   size_t rt_count = 0, kt_count = 0;      // 32-row tiles, 32-k tiles (kt padded to a multiple of 12)
   int planes[MAX_LIMBS] = {0, 0, 0, 0};   // signed base-256 digit planes per limb
   int8_t* d[MAX_LIMBS] = {nullptr, nullptr, nullptr, nullptr};
@@ -151,6 +152,12 @@ int digits_to_v8_impl(lab_ctx* c, const lab_mat8* m, const JobPtrs& src16, int n
                                  m->basis ? c->dg_tabs : c->d_tabs, m->planes, nt, c->stream));
   return LAB_OK;
 }
+uint32_t basis_min_prime(const lab_ctx* c, int basis) {
+  const uint32_t* primes = basis ? c->dg_primes : c->primes;
+  uint32_t mn = primes[0];
+  for (int l = 1; l < basis_nlimbs(c, basis); l++) mn = primes[l] < mn ? primes[l] : mn;
+  return mn;
+}
 uint32_t mat8_min_prime(const lab_ctx* c, const lab_mat8* m) {
   const uint32_t* primes = m->basis ? c->dg_primes : c->primes;
   uint32_t mn = primes[0];
@@ -204,6 +211,43 @@ extern "C" int lab_mat8_pack(lab_ctx* c, const lab_vec* M, size_t m_off, size_t 
   *out = m;
   return LAB_OK;
 }
+
+namespace lab {
+// an empty packed matrix of up to nmat_max x rows x cols elements whose contents mat8_repack() replaces (the slab of the
+// streamed outer commitment, crs_stream.hip)
+int mat8_alloc(lab_ctx* c, int basis, size_t nmat_max, size_t rows, size_t cols, lab_mat8** out) {
+  if (nmat_max * cols >= (1u << 17) - 1) return fail(c, LAB_ERR_RANGE, "mat8_alloc: %zu products per sum exceed the int32 exactness bound", nmat_max * cols);
+  lab_mat8* m = new lab_mat8();
+  m->ctx = c; m->basis = basis; m->nlimbs = basis_nlimbs(c, basis);
+  m->nmat = nmat_max; m->rows = rows; m->rows_alloc = rows; m->cols = cols;
+  m->rt_count = (rows + 31) / 32;
+  m->kt_count = ((nmat_max * cols + 31) / 32 + 11) / 12 * 12;
+  const uint32_t* primes = basis ? c->dg_primes : c->primes;
+  for (int l = 0; l < m->nlimbs; l++) {
+    m->planes[l] = mfma_planes(primes[l]);
+    const size_t bytes = (size_t)D * m->planes[l] * m->rt_count * m->kt_count * 1024;
+    if (m->planes[l] > 4 || hipMalloc(reinterpret_cast<void**>(&m->d[l]), bytes) != hipSuccess) {
+      lab_mat8_destroy(m);
+      return fail(c, LAB_ERR_HIP, "mat8_alloc: cannot allocate %zu bytes", bytes);
+    }
+    m->bytes += bytes;
+  }
+  *out = m;
+  return LAB_OK;
+}
+// repack from transform-domain planes [limb][nmat][rows][cols][64] (plane stride in words); nmat <= the allocated count
+// (source layout [nmat][rows_alloc][cols]); only the first rows_valid rows of every matrix are meaningful: the GEMM stores no others
+int mat8_repack(lab_ctx* c, lab_mat8* m, const uint32_t* hat_planes, size_t plane_stride, size_t nmat, size_t rows_valid) {
+  if (nmat == 0 || ((nmat * m->cols + 31) / 32) > m->kt_count || rows_valid == 0 || rows_valid > m->rows_alloc)
+    return fail(c, LAB_ERR_ARG, "mat8_repack: shape exceeds the allocation");
+  m->nmat = nmat;
+  m->rows = rows_valid;
+  for (int l = 0; l < m->nlimbs; l++)
+    LAB_HIP(c, launch_pack_matrix_i8(m->d[l], hat_planes + (size_t)l * plane_stride, false, nmat, m->rows_alloc, m->cols, m->rt_count,
+                                     m->kt_count, m->planes[l], c->stream));
+  return LAB_OK;
+}
+}  // namespace lab
 
 extern "C" int lab_mat8_destroy(lab_mat8* m) {
   if (!m) return LAB_OK;

@@ -102,7 +102,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     if ((x->Pi2 != nullptr) != (in->Pi2 != nullptr))
       return fail(c, LAB_ERR_ARG, "lab_prove_core_batch: either every proof of a batch hands over Pi2 (2 bits per entry) or none");
     if (x->n != n || x->r != r || x->kappa != kappa || x->kappa1 != k1 || x->kappa2 != k2 || x->t1 != t1 || x->t2 != t2 ||
-        x->b1 != in->b1 || x->b2 != in->b2 || x->beta_bound != in->beta_bound || x->A != in->A || x->B != in->B || x->B8 != in->B8 || x->A8 != in->A8 || x->C8 != in->C8 || x->D8 != in->D8 || x->A8d != in->A8d ||
+        x->b1 != in->b1 || x->b2 != in->b2 || x->beta_bound != in->beta_bound || x->A != in->A || x->B != in->B || x->crs_seed != in->crs_seed || x->B8 != in->B8 || x->A8 != in->A8 || x->C8 != in->C8 || x->D8 != in->D8 || x->A8d != in->A8d ||
         x->C != in->C || x->Dm != in->Dm || x->a_off != in->a_off || x->b_off != in->b_off || x->c_off != in->c_off ||
         x->d_off != in->d_off)
       return fail(c, LAB_ERR_ARG, "lab_prove_core_batch: all proofs of a batch must share dimensions, constants and the CRS");
@@ -113,7 +113,9 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if ((rc = check_range(c, in->A, in->a_off, kappa * n, "lab_prove_core(A)"))) return rc;
   // step 3 runs on the matrix cores when the B matrices were packed for them (lab_mat8_pack); B itself may then be absent
   const lab_mat8* b8 = in->B8;
-  if (!b8 && !in->B) return fail(c, LAB_ERR_ARG, "lab_prove_core: neither B nor B8 given");
+  // ... or streamed from the CRS seed, slab by slab (crs_stream.hip): B is then never resident
+  const bool stream_b = !b8 && !in->B && in->crs_seed;
+  if (!b8 && !in->B && !stream_b) return fail(c, LAB_ERR_ARG, "lab_prove_core: neither B, B8 nor crs_seed given");
   if (in->B && (rc = check_range(c, in->B, in->b_off, r * (size_t)t1 * k1 * kappa, "lab_prove_core(B)"))) return rc;
   if ((rc = check_range(c, in->C, in->c_off, pairs * (size_t)t2 * k2, "lab_prove_core(C)"))) return rc;
   if ((rc = check_range(c, in->Dm, in->d_off, pairs * (size_t)t1 * k2, "lab_prove_core(D)"))) return rc;
@@ -209,8 +211,12 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   size_t mf_bytes = b8 ? mfma_scratch_bytes(b8, mf_ns, 1) + 4096 : 0;
   // the digits of t go straight into B-operand tiles of every limb (transform + packing fused) when they are 16-bit words
   // below every prime of B's basis
-  const bool fuse_t = b8 && in->b1 <= 65536 && in->b2 <= 65536 && (uint64_t)in->b1 <= mat8_min_prime(c, b8);
-  if (fuse_t && mfma_prepacked_bytes(b8, mf_ns) + 4096 > mf_bytes) mf_bytes = mfma_prepacked_bytes(b8, mf_ns) + 4096;
+  const bool fuse_t = (b8 || stream_b) && in->b1 <= 65536 && in->b2 <= 65536 &&
+                      (uint64_t)in->b1 <= (b8 ? mat8_min_prime(c, b8) : basis_min_prime(c, bdig));
+  if (stream_b && !fuse_t) return fail(c, LAB_ERR_ARG, "lab_prove_core: the streamed outer commitment needs decomposition bases up to 65536 below the limb primes");
+  if (stream_b && crs_stream_scratch_bytes(c, bdig, r * (size_t)t1, k1, kappa, mf_ns) + 4096 > mf_bytes)
+    mf_bytes = crs_stream_scratch_bytes(c, bdig, r * (size_t)t1, k1, kappa, mf_ns) + 4096;
+  if (fuse_t && b8 && mfma_prepacked_bytes(b8, mf_ns) + 4096 > mf_bytes) mf_bytes = mfma_prepacked_bytes(b8, mf_ns) + 4096;
   const int a8_ns = r <= 8 ? 8 : r <= 16 ? 16 : 32;       // witness columns per Ajtai GEMM pass
   if (a8 && mfma_scratch_bytes(a8, a8_ns, np) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(a8, a8_ns, np) + 4096;
   if (a8d && mfma_scratch_bytes(a8d, a8_ns, np) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(a8d, a8_ns, np) + 4096;
@@ -380,7 +386,29 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
                                fuse_t ? reinterpret_cast<const int8_t*>(mf_scratch) : nullptr))) return rc;
     j0 += valid;
   }
-  for (size_t j0 = 0; !b8 && j0 < np;) {
+  if (stream_b) {   // B streamed from the seed: up to 64 proofs per pass over the regenerated rows
+    const size_t nmat = r * (size_t)t1;
+    // CRS::fetch_B_ik_row (src/structs.rs:78-82): offset of row 0 of B_ik = kappa*n*d + (i*T_1 + k) * kappa_1*kappa, copied literally
+    std::vector<uint64_t> offs(2 * nmat);
+    for (size_t m = 0; m < nmat; m++) {
+      const u128 off = (u128)kappa * n * D + (u128)m * k1 * kappa;
+      offs[2 * m] = (uint64_t)off; offs[2 * m + 1] = (uint64_t)(off >> 64);
+    }
+    for (size_t j0 = 0; j0 < np;) {
+      const size_t left = np - j0;
+      const int ns = left > 32 ? 64 : left > 16 ? 32 : left > 8 ? 16 : 8, valid = (int)(left < (size_t)ns ? left : (size_t)ns);
+      CrsStream* cs = nullptr;
+      if ((rc = crs_stream_create(c, bdig, nmat, k1, kappa, ns, &cs))) return rc;
+      JobPtrs dig;
+      for (int i = 0; i < MAX_JOBS; i++) dig.p[i] = i < valid ? jobs[j0 + i].cTdec : nullptr;
+      rc = crs_stream_run(cs, in->crs_seed, offs.data(), nmat, HD(j0, hlhs), perd * D, nullptr, 0, &dig, ns, valid, mf_scratch);
+      if (rc == LAB_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(c, LAB_ERR_HIP, "lab_prove_core: streamed outer commitment failed");
+      crs_stream_destroy(cs);
+      if (rc) return rc;
+      j0 += valid;
+    }
+  }
+  for (size_t j0 = 0; !b8 && !stream_b && j0 < np;) {
     int g = 1;
     while (g < 8 && j0 + 2 * (size_t)g <= np) g *= 2;
     if (g == 1) {

@@ -49,7 +49,7 @@ class RuntimeConstants:
 class ResidentCRS:
     """A, B_ik, C_ijk, D_ijk as transform-domain device matrices (stand-in for CRS::fetch_*, src/structs.rs:55-144)."""
 
-    def __init__(self, ctx, constants, compact=False, mfma_basis=False):
+    def __init__(self, ctx, constants, compact=False, mfma_basis=False, with_B=True):
         """compact=True keeps B, C, D in the context's digit basis with the small limb as u16 (they are only ever
         multiplied by decomposition digits < B_1, B_2): fewer bytes per coefficient on the HBM-bound kernel.
         Falls back to the main basis when no smaller basis exists (q its own NTT prime).
@@ -72,14 +72,15 @@ class ResidentCRS:
             self.compact = bool(getattr(ctx, "digit_primes", None))
         dg = dict(digit=self.compact, compact=self.compact and ctx.digit_small)
         self.A = HatVec(ctx, k.KAPPA * k.N)
-        self.B = HatVec(ctx, k.R * k.T_1 * k.KAPPA_1 * k.KAPPA, **dg)
+        self.B = HatVec(ctx, k.R * k.T_1 * k.KAPPA_1 * k.KAPPA, **dg) if with_B else None    # with_B=False: B is streamed from crs_seed
         self.C = HatVec(ctx, pairs * k.T_2 * k.KAPPA_2, **dg)
         self.Dm = HatVec(ctx, pairs * k.T_1 * k.KAPPA_2, **dg)
 
     def fill_synthetic(self, seed):
         """Uniform residues in [0,q) from the shared splitmix64 streams seed..seed+3 (oracle: orc_synth_fill)."""
         self.A.fill_synthetic(seed)
-        self.B.fill_synthetic(seed + 1)
+        if self.B is not None:
+            self.B.fill_synthetic(seed + 1)
         self.C.fill_synthetic(seed + 2)
         self.Dm.fill_synthetic(seed + 3)
         return self
@@ -94,7 +95,7 @@ class ResidentCRS:
         single-proof VALU path need it; a prover-only service does not)."""
         from .api import Mat8
         k = self.constants
-        self.B8 = Mat8(self.ctx, self.B, k.R * k.T_1, k.KAPPA_1, k.KAPPA)
+        self.B8 = Mat8(self.ctx, self.B, k.R * k.T_1, k.KAPPA_1, k.KAPPA) if self.B is not None else None
         self.A8 = Mat8(self.ctx, self.A, 1, k.KAPPA, k.N)
         pairs = k.R * (k.R + 1) // 2
         self.C8 = Mat8(self.ctx, self.C, pairs * k.T_2, k.KAPPA_2, 1)      # element (rho, m) = C[m][rho]
@@ -110,7 +111,7 @@ class ResidentCRS:
             self.A8d = Mat8(self.ctx, Ad, 1, k.KAPPA, k.N)
             self.ctx.synchronize()
             Ad.close()
-        if drop_B:
+        if drop_B and self.B is not None:
             self.ctx.synchronize()
             self.B.close()
             self.B = None
@@ -181,13 +182,19 @@ class CRS:
         self.ctx._check(self.ctx._lib.lab_crs_expand(self.ctx._h, vec._h, dst_off, count, self.base_seed,
                                                      offset & ((1 << 64) - 1), offset >> 64))
 
-    def materialize(self, compact=False):
-        """Resident transform-domain A, B, C, D with exactly the rows the reference's fetch_* would return."""
+    def materialize(self, compact=False, mfma_basis=False, stream_B=False):
+        """Resident transform-domain A, B, C, D with exactly the rows the reference's fetch_* would return.
+        stream_B=True: A, C, D resident, B NOT materialised — lab_prove_core[_batch] regenerates its rows from the seed
+        slab by slab inside step 3 (lab_prove_input.crs_seed), like the reference does on every fetch_B_ik_row."""
         k = self.constants
-        res = ResidentCRS(self.ctx, k, compact=compact)
+        res = ResidentCRS(self.ctx, k, compact=compact, mfma_basis=mfma_basis, with_B=not stream_B)
+        if stream_B:
+            res.crs_seed = self.base_seed
         self._expand_into(res.A, 0, k.KAPPA * k.N, self.offset_A(0))       # rows of A are consecutive in seed space
         for i in range(k.R):
             for kk in range(k.T_1):                                           # rows of one B_ik are consecutive too
+                if stream_B:
+                    break
                 self._expand_into(res.B, (i * k.T_1 + kk) * k.KAPPA_1 * k.KAPPA, k.KAPPA_1 * k.KAPPA, self.offset_B(i, kk, 0))
         for i in range(k.R):
             for j in range(i, k.R):
@@ -305,6 +312,7 @@ def _io_template(k, crs):
     for name in ("B8", "A8", "C8", "D8", "A8d"):
         m = getattr(crs, name, None)
         setattr(pin, name, m._h if m is not None else None)
+    pin.crs_seed = getattr(crs, "crs_seed", None)          # B streamed from the seed when crs.B and crs.B8 are absent
     pin.a_off = pin.b_off = pin.c_off = pin.d_off = 0
     return pin
 

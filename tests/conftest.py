@@ -12,7 +12,10 @@ if ROOT not in sys.path:
 Q_DEFAULT = 8191
 Q_REF33 = (1 << 32) + 15
 Q_DIRECT = 1073738753
-ALL_Q = [Q_DEFAULT, Q_REF33, Q_DIRECT]
+# the largest prime below 2^32 with q == 1 (mod 128): SURVEY §7's "NTT-friendly 32-bit q" (path (b)); on the GPU it runs
+# through the exact 3-limb RNS path (a single-limb strict-32 policy is not built), in oracle/fastcpu.c as one limb
+Q_NTT32 = 4294966657
+ALL_Q = [Q_DEFAULT, Q_REF33, Q_DIRECT, Q_NTT32]
 
 
 def pytest_configure(config):

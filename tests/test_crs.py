@@ -153,3 +153,88 @@ def test_gpu_prove_on_seed_addressed_crs_matches_oracle(contexts):
     assert np.array_equal(T.u_1, want["u1"]) and np.array_equal(T.u_2, want["u2"])
     assert np.array_equal(T.t_i_all, want["t"]) and np.array_equal(T.z, want["z"])
     assert np.array_equal(T.h_mat, want["H"]) and np.array_equal(T.g_mat, want["G"])
+
+
+# ------------------------------------------------------------------ streamed mode (row f1 as written)
+@pytest.mark.gpu
+@pytest.mark.parametrize("mfma_basis", [True, False])
+@pytest.mark.parametrize("nmat,rows,cols,ns", [(3, 40, 37, 8), (2, 300, 64, 32), (5, 130, 70, 64)])
+def test_streamed_crs_matvec_equals_materialise_then_multiply(mfma_basis, nmat, rows, cols, ns):
+    # lab_crs_matvec_mfma: slabs of 128 rows expanded from the seed, transformed, packed, multiplied on the matrix cores
+    # and discarded == lab_crs_expand of whole matrices + lab_mat8_pack + lab_matvec_sum_mfma, bit for bit; and the oracle's
+    # CRS restatement + schoolbook products on sample rows.  300 and 130 rows: three resp. two slabs, the last one ragged.
+    import labrador_snark_amd as lab
+    q = Q_REF33
+    ctx = lab.Context(q, 0)
+    ctx.enable_digit_basis(nmat * cols, 1625, mfma=mfma_basis)
+    base = bytes((i * 29 + 5) % 256 for i in range(32))
+    # matrix m starts at an arbitrary offset (one beyond 64 bits); its rows are consecutive in seed space
+    offs = [1000 + m * (rows * cols * D + 77) + ((1 << 66) if m == 1 else 0) for m in range(nmat)]
+    rng = np.random.default_rng(ns + rows)
+    V = rng.integers(0, 1625, size=(ns, nmat, cols, D), dtype=np.uint64)
+    hV = ctx.vec(ns * nmat * cols, digit=True).load(V)
+    got = lab.crs_matvec_mfma(ctx, base, offs, rows, cols, hV, ns).store().reshape(ns, rows, D)
+    M = ctx.vec(nmat * rows * cols, digit=True)
+    for m in range(nmat):
+        ctx._check(ctx._lib.lab_crs_expand(ctx._h, M._h, m * rows * cols, rows * cols, base, offs[m] & ((1 << 64) - 1), offs[m] >> 64))
+    M8 = lab.Mat8(ctx, M, nmat, rows, cols)
+    want = lab.matvec_sum_mfma(ctx, M8, hV, ns).store().reshape(ns, rows, D)
+    assert np.array_equal(got, want)
+    for s, rho in ((0, 0), (ns - 1, rows - 1), (3, 129 % rows)):
+        acc = np.zeros(D, np.uint64)
+        for m in range(nmat):
+            row = co.crs_fill(base, offs[m] + rho * cols * D, cols * D, q).reshape(cols, D)
+            acc = co.poly_add(q, acc, co.inner_product(q, row, V[s, m]))
+        assert np.array_equal(got[s, rho], acc), (s, rho)
+    M8.close(); M.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproofs", [1, 3])
+def test_prover_with_B_streamed_from_the_seed(nproofs):
+    # lab_prove_input.crs_seed with B == B8 == NULL: step 3 regenerates the B_ik rows from the seed inside the call
+    # (fetch_B_ik_row's literal offsets) — same transcripts as with the materialised CRS, and as the oracle on its own
+    # CRS restatement
+    import labrador_snark_amd as lab
+    import cases
+    q, n, r, kappa, kappa1 = Q_REF33, 2, 2, 5, 4
+    ctx = lab.Context(q, 0)
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, kappa1)
+    base = bytes((i * 37 + 11) % 256 for i in range(32))
+    crs = lab.CRS(ctx, k, base)
+    full = crs.materialize(mfma_basis=True)
+    streamed = crs.materialize(mfma_basis=True, stream_B=True)
+    assert streamed.B is None and streamed.crs_seed == base
+    ws, sts, tapes = [], [], []
+    for j in range(nproofs):
+        S, phi, a, tape = cases.make_inputs(p, seed=41 + j)
+        ws.append(S); tapes.append(tape)
+        sts.append(lab.State(phi, a, int(lab.gen_f_b(ctx, S, phi, a, n, r)[0])))
+    want, c1 = lab.prove_core_batch(ctx, k, ws, sts, full, tapes, raise_on_reject=False)
+    got, c2 = lab.prove_core_batch(ctx, k, ws, sts, streamed, tapes, raise_on_reject=False)
+    assert c1 == c2
+    for j in range(nproofs):
+        for f in ("u_1", "u_2", "t_i_all", "g_mat", "h_mat", "z", "b_prime_prime", "projection_int"):
+            assert np.array_equal(getattr(got[j], f), getattr(want[j], f)), (j, f)
+    # oracle: u_1 of proof 0 from the oracle's own expansion of B, C at the reference's offsets
+    off = lambda which, **kw: co.crs_offset(which, n, r, kappa, kappa1, kappa1, p.t1, **kw)
+    T = got[0]
+    acc = [np.zeros(D, np.uint64) for _ in range(kappa1)]
+    for i in range(r):
+        dec = co.decompose_vec(q, T.t_i_all[i], k.B_1, k.T_1)
+        for kk in range(k.T_1):
+            for rho in range(kappa1):
+                b_row = co.crs_fill(base, off("B", i=i, k=kk, row=rho), kappa * D, q).reshape(kappa, D)
+                acc[rho] = co.poly_add(q, acc[rho], co.inner_product(q, b_row, dec[kk]))
+    pairs = [(i, j) for i in range(r) for j in range(i, r)]
+    for (i, j) in pairs:
+        gdec = co.decompose(q, T.g_mat[i, j], k.B_2, k.T_2)
+        for kk in range(k.T_2):
+            c_vec = co.crs_fill(base, off("C", i=i, j=j, k=kk), kappa1 * D, q).reshape(kappa1, D)
+            for rho in range(kappa1):
+                acc[rho] = co.poly_add(q, acc[rho], co.polymul(q, gdec[kk], c_vec[rho]))
+    assert np.array_equal(T.u_1, np.stack(acc))
+    full.close(); streamed.close()
+    ctx.close()

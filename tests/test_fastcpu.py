@@ -6,15 +6,14 @@ the classic product (the reference's test_NTT_preserves_result, tests/proptest.r
 import numpy as np
 import pytest
 
-from conftest import ALL_Q
+from conftest import ALL_Q, Q_NTT32
 
 import cases
 
 D = 64
-Q_NTT32 = 4294966657          # largest prime below 2^32 with q == 1 (mod 128): single-modulus transform
 
 
-@pytest.mark.parametrize("q", ALL_Q + [Q_NTT32])
+@pytest.mark.parametrize("q", ALL_Q)
 def test_fast_product_equals_classic(q):
     from oracle import coracle as co
     from oracle import fastcpu as fc
@@ -32,7 +31,7 @@ def test_fast_product_equals_classic(q):
     f.close()
 
 
-@pytest.mark.parametrize("q", ALL_Q + [Q_NTT32])
+@pytest.mark.parametrize("q", ALL_Q)
 @pytest.mark.parametrize("n,r,kappa,kappa1", [(2, 2, 8, 6), (5, 3, 7, 4)])
 def test_fast_prover_equals_the_oracle_prover(q, n, r, kappa, kappa1):
     from oracle import fastcpu as fc

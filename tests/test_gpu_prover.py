@@ -6,7 +6,7 @@ import copy
 import numpy as np
 import pytest
 
-from conftest import ALL_Q, Q_DEFAULT, Q_REF33, Q_DIRECT
+from conftest import ALL_Q, Q_DEFAULT, Q_REF33, Q_DIRECT, Q_NTT32
 
 import cases
 
@@ -33,6 +33,9 @@ def run_gpu(ctx, p, S, phi, a, tape, b_prime, crs_seed=1000):
     (Q_DIRECT, 3, 2, 7, 4),
     (Q_REF33, 16, 8, 24, 16),
     (Q_DEFAULT, 16, 16, 16, 8),
+    (Q_NTT32, 2, 2, 5, 4),         # the NTT-friendly 32-bit modulus (SURVEY §8(d) "q: report both")
+    (Q_NTT32, 4, 3, 6, 5),
+    (Q_NTT32, 16, 8, 24, 16),
 ])
 def test_prove_core_matches_oracle(contexts, q, n, r, kappa, kappa1):
     ctx = contexts(q)
