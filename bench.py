@@ -188,7 +188,8 @@ def checksum_u64(t):
     return (t.to(torch.int64).sum() & ((1 << 62) - 1)).reshape(1)
 
 
-def build_workload(lab, ctx, k, q, dev, nbatch, seed0, crs_seed, use_mfma=True, basis23=True, compact=True, packed_pi=True):
+def build_workload(lab, ctx, k, q, dev, nbatch, seed0, crs_seed, use_mfma=True, basis23=True, compact=True, packed_pi=True,
+                   stream_b=False):
     """The resident inputs of one bench step: `nbatch` instances (seeds seed0 .. seed0+nbatch-1; witness, state, tape as
     device tensors) and the CRS they share.  tests/test_gpu_bench_config.py builds the same objects and checks the
     transcripts lab_prove_core_batch returns for them against the oracle."""
@@ -209,6 +210,14 @@ def build_workload(lab, ctx, k, q, dev, nbatch, seed0, crs_seed, use_mfma=True, 
         dtapes.append({pikey: tape[pikey] if torch.is_tensor(tape[pikey]) else torch.from_numpy(tape[pikey]).to(dev),
                        "psi": tape["psi"], "omega": dev64(tape["omega"]),
                        "alpha": dev64(tape["alpha"]), "beta": dev64(tape["beta"]), "c": dev64(tape["c"])})
+    if stream_b:
+        # the reference's own CRS: A, C, D expanded from the 32-byte seed once (resident), the B_ik rows regenerated from it
+        # inside every step (lab_prove_input.crs_seed) — B is never materialised, so its expansion IS in the timed region
+        seed = bytes((crs_seed * 7 + 13 * i) % 256 for i in range(32))
+        crs = lab.CRS(ctx, k, seed).materialize(mfma_basis=True, stream_B=True)
+        crs.pack_mfma()
+        torch.cuda.synchronize()
+        return dSs, sts, dtapes, crs
     # B, C, D are only ever multiplied by decomposition digits: keep them in the digit basis
     crs = lab.ResidentCRS(ctx, k, compact=compact, mfma_basis=basis23).fill_synthetic(crs_seed)
     if use_mfma:
@@ -268,6 +277,10 @@ def main():
                     help="outer commitment sum_ik B_ik t_i^(k): 64-bit multiply-add kernels (B as RNS residues) or exact "
                          "int8 GEMMs on the matrix cores (B packed as signed byte planes, up to 64 proofs per pass over B); "
                          "auto = mfma when --batch > 8")
+    ap.add_argument("--crs", choices=["resident", "streamed"], default="resident",
+                    help="resident: A, B, C, D in HBM in the transform domain (expansion outside the timed region); streamed: B "
+                         "regenerated from the ChaCha20 seed inside every step (SURVEY §8(f) row f1: the only way to the reference's "
+                         "ranks, e.g. --kappa 16384), expansion INSIDE the timed region")
     ap.add_argument("--pi", choices=["packed", "int8"], default="packed",
                     help="projection matrices Pi on the device: 2 bits per entry (lab_prove_input.Pi2) or one int8 per entry")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -314,7 +327,8 @@ def main():
     use_mfma = args.step3 == "mfma" or (args.step3 == "auto" and nbatch > 8)
     basis23 = not args.no_compact_crs and (args.digit_basis == "mfma23" or (args.digit_basis == "auto" and use_mfma))
     dSs, sts, dtapes, crs = build_workload(lab, ctx, k, q, dev, nbatch, 50 + rank * nbatch, 1000 + 10 * rank, use_mfma=use_mfma,
-                                           basis23=basis23, compact=not args.no_compact_crs, packed_pi=args.pi == "packed")
+                                           basis23=basis23, compact=not args.no_compact_crs, packed_pi=args.pi == "packed",
+                                           stream_b=args.crs == "streamed")
 
     def step():
         if nbatch == 1:
@@ -355,17 +369,21 @@ def main():
         achieved = (alg_bytes / max(launches, 1)) / per_launch_s / 1e9 if launches else 0.0
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE, gfx950 corrections applied) — only when they were taken on this very workload
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc):
+        # (PMC counters cannot be read from inside the run: `traffic` is the value of the committed rocprofv3 --pmc passes of
+        # this command, and `traffic_source` says so; null when no committed pass matches this workload and kernel)
+        traffic, traffic_source = None, None
+        for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+            if not name.endswith("_pmc_traffic.json"):
+                continue
             try:
-                rec = json.load(open(pmc))
+                rec = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if rec.get("workload_key") == [q, n, r, kappa, ctx.nlimbs, bool(crs.compact), nbatch] and \
                         rec.get("digit_primes") == getattr(ctx, "digit_primes", None) and \
-                        rec.get("step3", "valu") == ("mfma" if use_mfma else "valu"):
-                    traffic = rec.get("hbm_bytes_per_launch")
+                        rec.get("step3", "valu") == ("mfma" if use_mfma else "valu") and step3_kernel in rec.get("kernel", ""):
+                    traffic, traffic_source = rec.get("hbm_bytes_per_launch"), "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run)" % name
+                    break
             except Exception:
-                traffic = None
+                pass
         counts = ring_products_per_proof(n, r, kappa, kappa, kappa, k.T_1, k.T_2)
         result = {
             "metric": "prover constraints/sec", "value": value, "unit": "constraints/s", "n_gpus": world,
@@ -373,9 +391,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": "full Prover::proof_gen n=%d r=%d d=64, kappa=kappa1=kappa2=%d, q=%d (%d RNS limbs), "
-                                   "CRS resident in transform domain, CRS expansion excluded; %d independent proofs per step share the CRS; "
-                                   "Pi resident at %s"
-                                   % (n, r, kappa, q, ctx.nlimbs, nbatch, "2 bits per entry" if args.pi == "packed" else "one int8 per entry"),
+                                   "%s; %d independent proofs per step share the CRS; Pi resident at %s"
+                                   % (n, r, kappa, q, ctx.nlimbs,
+                                      "B STREAMED from the ChaCha20 seed inside the timed region (A, C, D resident)" if args.crs == "streamed"
+                                      else "CRS resident in transform domain, CRS expansion excluded",
+                                      nbatch, "2 bits per entry" if args.pi == "packed" else "one int8 per entry"),
                        "q": q, "n": n, "r": r, "kappa": kappa, "t1": k.T_1, "t2": k.T_2, "b1": k.B_1, "b2": k.B_2,
                        "nlimbs": ctx.nlimbs, "crs_basis": ("digit basis %s%s" % (getattr(ctx, "digit_primes", None), ", u16 last limb" if ctx.digit_small else
                                                           " (three signed byte planes per residue)"))
@@ -397,7 +417,7 @@ def main():
                                                     "(src/proofgen.rs:101-132) for the %d proofs of a step; the u16 limb runs as a "
                                                     "second launch of the same kernel template") % (step3_kernel, nbatch),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "launches": launches, "avg_launch_ms": per_launch_s * 1e3,
+                         "traffic": traffic, "traffic_source": traffic_source, "launches": launches, "avg_launch_ms": per_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1),
                          "kernel_share_of_step": (kernel_ms / 1e3) / elapsed if elapsed > 0 else None},
         }
@@ -407,9 +427,22 @@ def main():
             ns_pad = 64 if nbatch > 32 else 32 if nbatch > 16 else 16 if nbatch > 8 else 8
             pl = 3 if basis23 else 4
             ops = 2.0 * D * pl * kappa * (r * k.T_1 * kappa) * (ns_pad * pl)
+            mfma_frac = ops / per_launch_s / 1e12 / 5000.0
             result["roofline"].update({"mfma_int8_ops_per_launch": ops, "mfma_achieved_TOPs": ops / per_launch_s / 1e12,
-                                       "mfma_peak_TOPs": 5000.0, "mfma_frac": ops / per_launch_s / 1e12 / 5000.0})
+                                       "mfma_peak_TOPs": 5000.0, "mfma_frac": mfma_frac})
+            # the roofline this launch sits closer to (both fractions are printed either way)
+            if mfma_frac > result["roofline"]["frac"]:
+                result["roofline"].update({"bound": "mfma", "achieved": ops / per_launch_s / 1e12, "peak": 5000.0, "unit": "TOP/s",
+                                           "frac": mfma_frac, "hbm_achieved_GBps": achieved, "hbm_frac": achieved / HBM_PEAK_GBS})
+            else:
+                result["roofline"]["bound_note"] = ("HBM: %.2f of the 8 TB/s spec (%.2f of the ~6.3 TB/s a streaming kernel reaches); "
+                                                    "matrix cores at %.2f of the dense int8 peak" % (achieved / HBM_PEAK_GBS, achieved / 6300.0, mfma_frac))
 
+    if rank == 0 and args.crs == "streamed":
+        coefs = r * k.T_1 * kappa * kappa * D
+        result["crs_expansion"] = {"B_coefficients_regenerated_per_step": coefs, "coefficients_per_s": coefs / (elapsed / args.steps),
+                                   "note": "every coefficient = one ChaCha20 key set-up + block + gen_range on i128 (src/structs.rs:167-171): "
+                                           "the step is bound by that VALU work (k_crs_expand), not by HBM or the matrix cores"}
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:
         # release the big CRS before the side measurements
@@ -470,6 +503,19 @@ def side_measurements(lab, ctx, q, dev):
         out["ajtai_2p14x2p10_rhs%d" % ncols] = {"ms": t * 1e3, "algorithmic_GBps": byt / t / 1e9,
                                                 "modmuladds_per_s": L * rows * cols * ncols * 64 / t}
         S.close(); o.close()
+    # the same 32 right-hand sides on the matrix cores (the path the prover's step 1 takes for a batch): A packed once as
+    # signed byte planes, the 32 columns as 32 vector sets, exact int8 GEMMs
+    try:
+        A8 = lab.Mat8(ctx, A, 1, rows, cols)
+        Vs = ctx.vec(32 * cols).fill_synthetic(5)
+        o = ctx.vec(32 * rows)
+        t = _time(lambda: lab.matvec_sum_mfma(ctx, A8, Vs, 32, out=o), 5)
+        out["ajtai_2p14x2p10_rhs32_matrix_cores"] = {"ms": t * 1e3, "packed_matrix_GBps": A8.nbytes / t / 1e9,
+                                                     "modmuladds_per_s": L * rows * cols * 32 * 64 / t,
+                                                     "int8_TOPs": 2.0 * 16 * L * rows * cols * 32 * 64 / t / 1e12}
+        A8.close(); Vs.close(); o.close()
+    except Exception as e:
+        out["ajtai_2p14x2p10_rhs32_matrix_cores"] = {"error": str(e)}
     A.close()
     # the same mat-vec shape as the prover's step 3 when q is its own NTT prime (single limb, 4 B per coefficient):
     # the data point for an NTT-friendly modulus (q = 1073738753, 30 bits); 24 GiB streamed per call

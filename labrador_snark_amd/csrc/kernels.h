@@ -129,6 +129,7 @@ struct Gemm8Args {
   const int8_t* V8;          // + job*v8_job_stride (bytes)
   size_t v8_job_stride;
   unsigned planes, rt_count, kt_count, rgroups /* row groups per slot */, njobs, rows, ns, ns_valid;
+  unsigned kt_real;         // k-tiles that hold terms (the rest of kt_count is zero padding): k_gemm_i8_w3 stops after them
   unsigned nsub;            // sets per source job (= ns unless several source jobs are multiplied as one job); ns_valid counts within it
   unsigned tile_r, tile_j;   // block-order super-tile (set by launch_gemm_i8)
   uint32_t p;

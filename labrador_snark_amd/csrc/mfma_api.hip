@@ -89,6 +89,7 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
     g.out = out.base + (size_t)l * out.plane_stride; g.out_set_stride = out_set_stride; g.out_job_stride = out_job_stride;
     g.M8 = m->d[l]; g.V8 = v8; g.v8_job_stride = v8_stride;
     g.planes = (unsigned)pl; g.rt_count = (unsigned)m->rt_count; g.kt_count = (unsigned)m->kt_count;
+    g.kt_real = (unsigned)((ktotal + 31) / 32);
     const int waves = gemm_i8_waves(pl, m->rt_count, nt);
     const int tpb = (pl == 3 && waves == 4) ? 4 : waves / pl;       // row tiles per block
     g.rgroups = (unsigned)((m->rt_count + tpb - 1) / tpb); g.njobs = (unsigned)njobs; g.rows = (unsigned)m->rows;

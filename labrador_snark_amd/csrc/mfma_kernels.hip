@@ -614,7 +614,9 @@ k_gemm_i8_w3(const Gemm8Args a) {
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)bring;
   const uint32_t voff = lane * 16, vlds = lds0 + lane * 16;
   const uint32_t m0b = __builtin_amdgcn_readfirstlane(lds0 + first_piece * 1024);
-  const uint32_t nstages = __builtin_amdgcn_readfirstlane(kt_count / W3_KS);
+  // stages that hold terms, rounded up to an even count (the loop body is two stages; kt_count is a multiple of 4, so
+  // the extra stage is zero padding inside the allocation)
+  const uint32_t nstages = __builtin_amdgcn_readfirstlane(min(kt_count / W3_KS, 2 * ((a.kt_real + 2 * W3_KS - 1) / (2 * W3_KS))));
 
   // accumulator tile (plane i, column tile n) = acc[i * NT + n]; the first 16 in accumulation registers
   i32x16_t acc[3 * NT];

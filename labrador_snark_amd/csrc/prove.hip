@@ -165,6 +165,10 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if ((u128)r * n * D * qm1 >= ((u128)1 << 63)) return fail(c, LAB_ERR_RANGE, "lab_prove_core: JL projection does not fit 64 bits");
   LAB_HIP(c, hipSetDevice(c->device));
 
+  // the digits of t go straight into B-operand tiles of every limb (transform + packing fused) when they are 16-bit words
+  // below every prime of B's basis: their transform-domain copy then never exists
+  const bool fuse_t = (b8 || stream_b) && in->b1 <= 65536 && in->b2 <= 65536 &&
+                      (uint64_t)in->b1 <= (b8 ? mat8_min_prime(c, b8) : basis_min_prime(c, bdig));
   // ---------------- workspace plan: one arena per basis, proof j owns elements [j*per, (j+1)*per) of every plane
   const int L = c->nlimbs;
   HatArena ha;
@@ -176,11 +180,12 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   const size_t hpart = ha.take(part_elems);
   // second arena, in the basis of B/C/D, for the digit-operand reductions (steps 3, 4, 9)
   HatArena hd;
-  const size_t hTdec = hd.take(rk * t1), hGdec = hd.take(pairs * t2), hlhs = hd.take(k1), hrhs = hd.take(k1),
+  const size_t hTdec = hd.take(fuse_t ? 1 : rk * t1), hGdec = hd.take(pairs * t2), hlhs = hd.take(k1), hrhs = hd.take(k1),
                hHdec = hd.take(pairs * t1), hu2 = hd.take(k2);
-  size_t partd_elems = r * (size_t)t1 * k1;
-  if (axpy_partial_elems(pairs * t2, k2) > partd_elems) partd_elems = axpy_partial_elems(pairs * t2, k2);
-  if (axpy_partial_elems(pairs * t1, k2) > partd_elems) partd_elems = axpy_partial_elems(pairs * t1, k2);
+  // partial sums of the multiply-add kernels (not needed for the steps that run on the matrix cores)
+  size_t partd_elems = (b8 || stream_b) ? 1 : r * (size_t)t1 * k1;
+  if (!in->C8 && axpy_partial_elems(pairs * t2, k2) > partd_elems) partd_elems = axpy_partial_elems(pairs * t2, k2);
+  if (!in->D8 && axpy_partial_elems(pairs * t1, k2) > partd_elems) partd_elems = axpy_partial_elems(pairs * t1, k2);
   const size_t hpartd = hd.take(partd_elems);
   const size_t hSd = a8d ? hd.take(nr) : 0, hTd = a8d ? hd.take(rk) : 0;   // witness and t = A s in the digit basis
   const size_t hGd = a8d ? hd.take(rr) : 0;                                 // G = S^T S from the same packed operands
@@ -209,10 +214,6 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   // int8-MFMA step 3: padded set count of the largest group and its scratch (B-operand tiles + int32 results)
   const int mf_ns = np > 32 ? 64 : np > 16 ? 32 : np > 8 ? 16 : 8;
   size_t mf_bytes = b8 ? mfma_scratch_bytes(b8, mf_ns, 1) + 4096 : 0;
-  // the digits of t go straight into B-operand tiles of every limb (transform + packing fused) when they are 16-bit words
-  // below every prime of B's basis
-  const bool fuse_t = (b8 || stream_b) && in->b1 <= 65536 && in->b2 <= 65536 &&
-                      (uint64_t)in->b1 <= (b8 ? mat8_min_prime(c, b8) : basis_min_prime(c, bdig));
   if (stream_b && !fuse_t) return fail(c, LAB_ERR_ARG, "lab_prove_core: the streamed outer commitment needs decomposition bases up to 65536 below the limb primes");
   if (stream_b && crs_stream_scratch_bytes(c, bdig, r * (size_t)t1, k1, kappa, mf_ns) + 4096 > mf_bytes)
     mf_bytes = crs_stream_scratch_bytes(c, bdig, r * (size_t)t1, k1, kappa, mf_ns) + 4096;

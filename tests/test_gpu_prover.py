@@ -443,3 +443,52 @@ def test_packed_pi_on_the_norm_bounded_fast_path_and_its_fallback():
                 assert np.array_equal(getattr(A[j], f), getattr(B[j], f)), (j, f)
     crs.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("q", [Q_DEFAULT, Q_REF33])
+def test_state_gen_f_and_transcript_bytes_from_a_gpu_proof(q):
+    # State::new / gen_f (src/structs.rs:289-387) on the Gram / inner-product kernels: b equals the oracle's orc_state_b for
+    # the same (phi, a); then the proof made from that state serialises (bincode layout of src/structs.rs:192-220) to bytes
+    # an independent reader decodes back to the device results, trimmed polynomials included
+    import struct
+    import labrador_snark_amd as lab
+    from labrador_snark_amd import transcript as tr
+    from oracle import coracle as co
+    from test_transcript import Reader
+    n, r, kappa, kappa1 = 4, 3, 6, 5
+    ctx = lab.Context(q, 0)
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
+    S, _, _, tape = cases.make_inputs(p, seed=5)
+    st = lab.State.new(ctx, S, k, np.random.default_rng(9))
+    assert np.array_equal(st.a, st.a.transpose(1, 0, 2))                        # a_constraints symmetric (src/structs.rs:297-300)
+    want_b = np.empty(D, np.uint64)
+    co.lib().orc_state_b(q, n, r, np.ascontiguousarray(S), np.ascontiguousarray(st.phi), np.ascontiguousarray(st.a), want_b)
+    assert np.array_equal(st.b, want_b) and st.b_prime == int(want_b[0])
+    crs = lab.ResidentCRS(ctx, k).fill_synthetic(1000)
+    (T,), (code,) = lab.prove_core_batch(ctx, k, [S], [st], crs, [tape], raise_on_reject=False)
+    assert code in (0, -6)                                                       # b'' check passes with gen_f's b'
+    data = tr.serialize_transcript(T, q, tape)
+    rd = Reader(data)
+    assert np.array_equal(np.array(rd.vec_rq(), dtype=np.uint64), T.u_1)
+    assert rd.u64() == r
+    for i in range(r):
+        assert rd.u8() == 1 and (rd.u64(), rd.u64()) == (256, n * D)
+        rd.o += 8 + 16 * 256 * n * D                                             # the lifted Pi_i block
+    assert rd.vec_zq() == [int(x) for x in T.projection]
+    assert rd.u64() == 1 and rd.vec_zq() == [int(tape["psi"]) % q]
+    assert rd.u64() == 1 and rd.vec_zq() == [int(x) for x in tape["omega"]]
+    assert np.array_equal(np.array(rd.vec_rq(), dtype=np.uint64)[0], T.b_prime_prime)
+    rd.vec_rq(); rd.vec_rq()                                                     # alpha, beta
+    assert np.array_equal(np.array(rd.vec_rq(), dtype=np.uint64), T.u_2)
+    rd.vec_rq()                                                                  # c
+    assert np.array_equal(np.array(rd.vec_rq(), dtype=np.uint64), T.z)
+    assert rd.u64() == r
+    for i in range(r):
+        assert np.array_equal(np.array(rd.vec_rq(), dtype=np.uint64), T.t_i_all[i])
+    for M in (T.g_mat, T.h_mat):
+        assert rd.u8() == 1 and (rd.u64(), rd.u64()) == (r, r)
+        assert np.array_equal(np.array(rd.vec_rq(), dtype=np.uint64).reshape(r, r, D), M)
+    assert rd.o == len(data)
+    crs.close()
+    ctx.close()

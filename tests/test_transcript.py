@@ -83,3 +83,52 @@ def test_bincode_layout_round_trip():
     # the zero polynomial is an empty Vec (8-byte length only), a 40-coefficient one carries 40 Zq
     assert data[8:16] == struct.pack("<Q", 40)
     assert tr.gzip_size_estimate(data) < len(data)
+
+
+def test_bincode_layout_hand_built_bytes():
+    """A transcript small enough to write its bytes out by hand from the published formats (bincode 1.x: little-endian
+    fixed-width integers, u64 length prefixes, struct fields in declaration order; ndarray 0.15 serde: u8 version 1, the
+    dimension tuple, then the elements as a sequence; Zq = one i128; Rq = Vec<Zq> of the trimmed coefficients,
+    src/algebraic.rs:422-429).  This pins the serialiser to those formats — the reference holds no transcript bytes to
+    pin it to the Rust binary (parity unpinned, as the module says)."""
+    q = 8191
+    zq = lambda v: struct.pack("<QQ", v, 0)
+    u64 = lambda v: struct.pack("<Q", v)
+    rq = lambda cs: u64(len(cs)) + b"".join(zq(c) for c in cs)
+    t = T()
+    poly = lambda cs: np.array(list(cs) + [0] * (D - len(cs)), dtype=np.uint64)
+    t.u_1 = np.stack([poly([5, 0, 7]), poly([])])                 # kappa1 = 2
+    t.projection = np.arange(256, dtype=np.uint64)
+    t.b_prime_prime = poly([9])
+    t.u_2 = np.stack([poly([1]), poly([0, 2])])
+    t.z = np.stack([poly([3, 4])])                                # n = 1
+    t.t_i_all = np.stack([np.stack([poly([6])])])                 # r = 1, kappa = 1
+    t.g_mat = np.stack([np.stack([poly([8, 8])])])
+    t.h_mat = np.stack([np.stack([poly([])])])
+    Pi = np.zeros((1, 256, D), dtype=np.int8)
+    Pi[0, 0, 0], Pi[0, 255, 63] = -1, 1
+    omega = np.full(256, 2, dtype=np.uint64)
+    tape = dict(Pi=Pi, psi=77, omega=omega, alpha=poly([1, 1]), beta=poly([0, 0, 3]), c=np.stack([poly([q - 1])]))
+    lifted = [0] * (256 * D)
+    lifted[0], lifted[-1] = q - 1, 1                              # Zq::lift(-1) = q - 1 (src/proofgen.rs:445-451)
+    want = b"".join([
+        u64(2) + rq([5, 0, 7]) + rq([]),                                              # u_1: Vec<Rq>
+        u64(1) + b"\x01" + u64(256) + u64(D) + u64(256 * D) + b"".join(zq(v) for v in lifted),   # pi_i_all: Vec<Array2<Zq>>
+        u64(256) + b"".join(zq(v) for v in range(256)),                                # projection: Vec<Zq>
+        u64(1) + u64(1) + zq(77),                                                      # psi: Vec<Vec<Zq>>
+        u64(1) + u64(256) + zq(2) * 256,                                               # omega
+        u64(1) + rq([9]),                                                              # b_prime_prime: Vec<Rq>
+        u64(1) + rq([1, 1]), u64(1) + rq([0, 0, 3]),                                   # alpha, beta
+        u64(2) + rq([1]) + rq([0, 2]),                                                 # u_2
+        u64(1) + rq([q - 1]),                                                          # c
+        u64(1) + rq([3, 4]),                                                           # z
+        u64(1) + u64(1) + rq([6]),                                                     # t_i_all: Vec<Vec<Rq>>
+        b"\x01" + u64(1) + u64(1) + u64(1) + rq([8, 8]),                               # g_mat: Array2<Rq>
+        b"\x01" + u64(1) + u64(1) + u64(1) + rq([]),                                   # h_mat
+    ])
+    assert tr.serialize_transcript(t, q, tape) == want
+    # the 2-bit tape (lab_prove_input.Pi2) serialises to the same bytes
+    f = (Pi + 1).astype(np.uint8).reshape(1, 256, D // 4, 4)
+    tape2 = {k: v for k, v in tape.items() if k != "Pi"}
+    tape2["Pi2"] = f[..., 0] | (f[..., 1] << 2) | (f[..., 2] << 4) | (f[..., 3] << 6)
+    assert tr.serialize_transcript(t, q, tape2) == want
