@@ -38,6 +38,19 @@ def ring_products_per_proof(n, r, kappa, kappa1, kappa2, t1, t2):
             "8_H": 2 * r * r * n, "9_u2": pairs * t1 * kappa2, "10_z": r * n}
 
 
+def cpu_share():
+    """Threads this process may keep busy: the affinity mask, cut to the cgroup CPU quota when there is one and to 16 — the
+    CPU share of a one-GPU box on this pool (its 256 logical CPUs are shared with the jobs of the other 7 GPUs)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("LAB_CPU_THREADS", "16"))))
+
+
 def cpu_baseline_b0(q, products_per_proof, seconds=6.0):
     """B0, reference-faithful CPU port (oracle orc_polymul_faithful: i128 `%` after every coefficient op, like
     src/algebraic.rs:30-38,95-134) timed on this host on a bounded sample of ring products, all threads
@@ -45,14 +58,15 @@ def cpu_baseline_b0(q, products_per_proof, seconds=6.0):
     from concurrent.futures import ThreadPoolExecutor
     from oracle import coracle as co
     lib = co.lib()
-    cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    cores = cpu_share()
     rng = np.random.default_rng(123)
     length = 64
     data = [(rng.integers(0, q, size=(length, D), dtype=np.uint64), rng.integers(0, q, size=(length, D), dtype=np.uint64))
             for _ in range(cores)]
-    t0 = time.perf_counter()
-    lib.orc_bench_inner_product_faithful(q, data[0][0], data[0][1], length, 1)
-    per_call = max(time.perf_counter() - t0, 1e-6)
+    with ThreadPoolExecutor(cores) as ex:      # calibrate with every thread busy (one call each)
+        t0 = time.perf_counter()
+        list(ex.map(lambda i: lib.orc_bench_inner_product_faithful(q, data[i][0], data[i][1], length, 1), range(cores)))
+        per_call = max(time.perf_counter() - t0, 1e-6)
     reps = max(1, int(seconds / per_call))
 
     def work(i):
@@ -80,7 +94,7 @@ def cpu_baseline_b1(k, q, proofs=3):
     from oracle import fastcpu as fc
     n, r, kappa = k.N, k.R, k.KAPPA
     pairs = r * (r + 1) // 2
-    f = fc.FastCpu(q, max(65536, n * r + r * r), 0)
+    f = fc.FastCpu(q, max(65536, n * r + r * r), cpu_share())
     t0 = time.perf_counter()
     A = f.synthetic_hat(1000, kappa * n)
     B = f.random_hat(1001, r * k.T_1 * k.KAPPA_1 * kappa)
