@@ -178,17 +178,18 @@ def make_inputs(k, q, seed, dev=None, packed_pi=False):
         Pi = (bits == 3).to(torch.int8) - (bits == 0).to(torch.int8)
         del bits
         if packed_pi:
-            # 2 bits per entry as lab_prove_input.Pi2 wants them: field 2*(col % 4) of byte col/4 = entry + 1
-            f = (Pi + 1).to(torch.uint8).reshape(r, 256, n * D // 4, 4)
-            Pi = (f[..., 0] | (f[..., 1] << 2) | (f[..., 2] << 4) | (f[..., 3] << 6)).contiguous()
-            del f
+            # 2 bits per entry in the tiled order lab_prove_input.Pi2 wants (the same arithmetic as lab.pack_pi_host, on the device)
+            f = (Pi + 1).to(torch.uint8).reshape(r, 4, 4, 4, 4, n * D // 16, 16)                 # [i, s, kq, j, k, ct, cc]
+            b = f[:, :, :, 0] | (f[:, :, :, 1] << 2) | (f[:, :, :, 2] << 4) | (f[:, :, :, 3] << 6)
+            Pi = b.permute(0, 1, 4, 2, 5, 3).contiguous().reshape(r, 256 * n * D // 4)
+            del f, b
     else:
         bits = rng.integers(0, 4, size=(r, 256, n * D), dtype=np.int8)       # two fair bits per entry, as on the device
         Pi = (bits == 3).astype(np.int8) - (bits == 0).astype(np.int8)
         del bits
     if packed_pi and dev is None:
-        f = (Pi + 1).astype(np.uint8).reshape(r, 256, n * D // 4, 4)
-        Pi = np.ascontiguousarray(f[..., 0] | (f[..., 1] << 2) | (f[..., 2] << 4) | (f[..., 3] << 6))
+        from labrador_snark_amd import pack_pi_host
+        Pi = pack_pi_host(Pi)
     tape = dict(psi=int(rng.integers(0, q)), omega=rng.integers(0, q, size=256, dtype=np.uint64),
                 alpha=rng.integers(0, q, size=D, dtype=np.uint64), beta=rng.integers(0, q, size=D, dtype=np.uint64),
                 c=np.stack([challenge_poly(rng, q) for _ in range(r)]))

@@ -264,10 +264,10 @@ int lab_sigma_inv(lab_ctx *ctx, uint64_t *out, const uint64_t *coeffs, size_t co
  *   proj[m] = sum_{i<r} sum_col Pi[i][m][col] * S[col/64][i][col%64]   over the integers (no reduction)
  * Pi: int8 [r][256][n*64], S: witness coefficients [n][r][64], proj: int64[256] (|proj| < r*n*64*q < 2^63). */
 int lab_jl_project(lab_ctx *ctx, int64_t *proj, const int8_t *Pi, const uint64_t *S, size_t n, size_t r);
-/* sample_jl_projection's matrices (src/verification.rs:553-566) from int8 {-1,0,1} to the 2-bit form of
- * lab_prove_input.Pi2: `count` entries (a multiple of 16) -> count/4 bytes, entry k in field 2*(k % 4) of byte k/4 as
- * entry + 1.  Host or device pointers. */
-int lab_pi_pack(lab_ctx *ctx, uint8_t *packed, const int8_t *Pi, size_t count);
+/* sample_jl_projection's matrices (src/verification.rs:553-566) from int8 {-1,0,1}, `mats` row-major matrices of 256 x cols
+ * (cols a multiple of 16), to the tiled 2-bit form of lab_prove_input.Pi2 (mats * 256 * cols / 4 bytes).  Host or device
+ * pointers. */
+int lab_pi_pack(lab_ctx *ctx, uint8_t *packed, const int8_t *Pi, size_t mats, size_t cols);
 
 /* ---- Prover::proof_gen as one deterministic call (src/proofgen.rs:30-427) ----
  * The verifier's interactive randomness (src/verification.rs:441-513, 553-566) is supplied as a challenge tape and
@@ -307,10 +307,12 @@ typedef struct {
                                * product.  The pass that transforms S also sums its squared norm; a witness above beta_bound
                                * (never produced by generate_witness, src/proofgen.rs:460-518) makes the call redo the batch
                                * in the main basis, so results never depend on this field */
-  const uint8_t *Pi2;      /* optional, instead of Pi (which may then be NULL): the projection matrices at 2 bits per entry
-                            * (lab_pi_pack), [r][256][n*64/4] bytes: entry (i, m, col) is the field 2*(col % 4) of byte
-                            * (i*256 + m) * n*16 + col/4 and holds entry + 1 in {0, 1, 2}.  A quarter of the bytes of the int8
-                            * form on the pass that reads Pi (the reference lifts it to 16-byte Zq, src/proofgen.rs:445-453) */
+  const uint8_t *Pi2;      /* optional, instead of Pi (which may then be NULL): the projection matrices at 2 bits per entry in the
+                            * tiled order lab_pi_pack produces (r * 256 * n*16 bytes): dword ((i*4 + s) * (n*4) + ct) * 64 + lane
+                            * holds rows 64s + 16*(lane >> 4) + 0..15 of column 16ct + (lane & 15) of Pi_i, row 4j + k in the
+                            * field at bit 8k + 2j, as entry + 1 in {0, 1, 2} — one dword per lane is one matrix-core operand.
+                            * A quarter of the bytes of the int8 form (the reference lifts Pi to 16-byte Zq,
+                            * src/proofgen.rs:445-453) and W = sum_m omega_m sigma_inv(pi^(m)) on the matrix cores */
   const uint8_t *crs_seed; /* optional, 32 bytes: CRS::base_seed (src/structs.rs:29, 173-189).  With B == NULL and B8 == NULL the
                             * B_ik matrices are STREAMED from this seed (the rows fetch_B_ik_row regenerates on every fetch,
                             * src/structs.rs:74-88): step 3 expands a slab of rows on the device, multiplies it with every proof

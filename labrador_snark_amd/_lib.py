@@ -131,7 +131,7 @@ SIGNATURES = {
     "lab_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64]),
     "lab_sigma_inv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "lab_jl_project": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
-    "lab_pi_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "lab_pi_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     "lab_prove_core": (C.c_int, [C.c_void_p, C.POINTER(lab_prove_input), C.POINTER(lab_transcript)]),
     "lab_prove_core_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.POINTER(lab_prove_input)),
                                        C.POINTER(C.POINTER(lab_transcript)), C.POINTER(C.c_int)]),

@@ -1084,9 +1084,10 @@ extern "C" int lab_sigma_inv(lab_ctx* c, uint64_t* out, const uint64_t* coeffs, 
   return coef_unary(c, out, coeffs, count, 0, 3, "lab_sigma_inv");
 }
 
-extern "C" int lab_pi_pack(lab_ctx* c, uint8_t* packed, const int8_t* Pi, size_t count) {
+extern "C" int lab_pi_pack(lab_ctx* c, uint8_t* packed, const int8_t* Pi, size_t mats, size_t cols) {
   if (!c) return LAB_ERR_ARG;
-  if (!packed || !Pi || count % 16) return fail(c, LAB_ERR_ARG, "lab_pi_pack: null pointer or count not a multiple of 16");
+  if (!packed || !Pi || cols % 16) return fail(c, LAB_ERR_ARG, "lab_pi_pack: null pointer or a column count that is not a multiple of 16");
+  const size_t count = mats * 256 * cols;
   if (count == 0) return LAB_OK;
   LAB_HIP(c, hipSetDevice(c->device));
   PtrCacheScope ptr_cache;
@@ -1097,7 +1098,7 @@ extern "C" int lab_pi_pack(lab_ctx* c, uint8_t* packed, const int8_t* Pi, size_t
   const int8_t* dpi;
   if ((rc = st.in(Pi, count, &dpi))) return rc;
   uint8_t* dout = st.out(packed, count / 4);
-  LAB_HIP(c, launch_pi_pack(dout, dpi, count, c->stream));
+  LAB_HIP(c, launch_pi_pack(dout, dpi, mats, cols, c->stream));
   return st.finish();
 }
 

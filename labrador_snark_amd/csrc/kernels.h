@@ -180,10 +180,11 @@ hipError_t launch_symmetrize_half_jobs(const JobPtrs& H, const JobPtrs& X, size_
                                        hipStream_t s);
 hipError_t launch_pi_fused_jobs(const JobPtrs& proj, const JobPtrs& W, const JobPtrs& Pi, const JobPtrs& S, const JobPtrs& omega,
                                 size_t n, size_t r, uint64_t q, size_t njobs, hipStream_t s);
-// the same pass over Pi at 2 bits per entry (field = entry + 1; see k_pi_fused2); launch_pi_pack converts the int8 form
+// the same pass over Pi at 2 bits per entry in MFMA-operand tiles (field = entry + 1; see k_pi_mfma); launch_pi_pack converts
+// `mats` int8 matrices of 256 x cols
 hipError_t launch_pi_fused2_jobs(const JobPtrs& proj, const JobPtrs& W, const JobPtrs& Pi2, const JobPtrs& S, const JobPtrs& omega,
                                  size_t n, size_t r, uint64_t q, size_t njobs, bool small_witness, hipStream_t s);
-hipError_t launch_pi_pack(uint8_t* dst, const int8_t* src, size_t count, hipStream_t s);
+hipError_t launch_pi_pack(uint8_t* dst, const int8_t* src, size_t mats, size_t cols, hipStream_t s);
 hipError_t launch_lift_i64(uint64_t* out, const int64_t* in, size_t n, uint64_t q, hipStream_t s);
 hipError_t launch_norm_sq(uint64_t* lo, uint64_t* hi, const uint64_t* in, size_t count, hipStream_t s);
 // mode 0: s1*a ; 1: s1*a + b ; 2: a + b ; 3: sigma_inv(a)

@@ -574,157 +574,233 @@ k_pi_fused(const JobPtrs projp, const JobPtrs Wp, const JobPtrs Pip, const JobPt
 }
 
 // ---- the same pass over Pi stored at 2 bits per entry (lab_prove_input.Pi2; the reference lifts Pi to 16-byte Zq,
-// src/proofgen.rs:445-453, this path reads a quarter of the int8 form's bytes).  Entry (i, m, col) is the 2-bit field
-// 2*(col % 4) of byte Pi2[(i*256 + m) * cols/4 + col/4], holding e + 1 in {0, 1, 2} — so a thread's 16 columns are one
-// dword per row, and every product is unsigned (v_mad_u32_u24); the surplus sum_col s[col] (rows) resp. sum_m omega[m]
-// (columns) that the +1 adds is taken off once per block / per thread.  8 rows are in flight per thread behind the 8 being
-// consumed.  SMALL: the caller guarantees witness coefficients below 2^24 (a witness inside its norm bound
-// beta < 2^24, checked by the digit-basis step 1 of the same call): one multiply-add per entry for the projection.
-template <bool SMALL>
+// src/proofgen.rs:445-453, this path reads a quarter of the int8 form's bytes).
+// In the int8 kernel above every entry costs a byte extract and four 24-bit multiply-adds (two for the projection, two
+// for W) plus its share of a wave reduction per row: 5 VALU instructions per entry, 34e9 entries per 64-proof batch —
+// the pass is bound by VALU issue, not by its stream, and a denser storage alone buys nothing.  Here
+//   * W[col] = sum_m omega[m] Pi[m][col] runs on the matrix cores: omega in 7-bit limbs is the A operand (row = limb),
+//     a 64-row x 16-column tile of Pi expanded to int8 the B operand (v_mfma_i32_16x16x64_i8: D[limb][col], exact in
+//     int32: 256 rows x 127), 4 k-steps per 16 columns, 4 accumulator registers per column tile;
+//   * the storage is TILED so that one dword per lane is that B operand: lane (kq = l >> 4, cc = l & 15) of tile
+//     (i, s, ct) holds rows 64s + 16kq + 0..15 of column 16ct + cc, row 4j + k in the 2-bit field at bit 8k + 2j, value
+//     entry + 1 in {0, 1, 2}: four (shift, and) pairs give four selector dwords and v_perm_b32 with the byte table
+//     {0xFF, 0x00, 0x01} turns each into four int8 rows — 11 instructions for 16 entries;
+//   * the projection keeps the VALU (one extract and one unsigned 24-bit multiply-add per entry when the witness is
+//     inside its norm bound, SMALL; two otherwise), but a lane now owns 16 ROWS of one column, so its 16 row sums
+//     accumulate over the wave's CT column tiles in registers and are reduced across the 16 lanes of a DPP row once per
+//     64 x 16CT block of entries instead of once per row.
+// ~3 (4) instead of 5.3 instructions per entry.  The surplus sum_col s[col] that the +1 of the fields adds to the row
+// sums is taken off once per block.
+// Word address: ((i*4 + s) * (cols/16) + ct) * 64 + lane.  Block = 4 waves x CT column tiles of witness column i.
+constexpr int PI_LIMBS = 6;                        // 7-bit limbs of omega (< 2^42)
+
+template <bool SMALL, int CT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_pi_fused2(const JobPtrs projp, const JobPtrs Wp, const JobPtrs Pip, const JobPtrs Sp, const JobPtrs omegap, unsigned n,
-            unsigned r, uint64_t q) {
+k_pi_mfma(const JobPtrs projp, const JobPtrs Wp, const JobPtrs Pip, const JobPtrs Sp, const JobPtrs omegap, unsigned n, unsigned r,
+          unsigned ib, uint64_t q) {
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  typedef int i32x4_t __attribute__((ext_vector_type(4)));
   unsigned long long* __restrict__ proj = static_cast<unsigned long long*>(projp.p[blockIdx.z]);
   uint64_t* __restrict__ W = static_cast<uint64_t*>(Wp.p[blockIdx.z]);
   const uint32_t* __restrict__ Pi = static_cast<const uint32_t*>(Pip.p[blockIdx.z]);
   const uint64_t* __restrict__ S = static_cast<const uint64_t*>(Sp.p[blockIdx.z]);
   const uint64_t* __restrict__ omega = static_cast<const uint64_t*>(omegap.p[blockIdx.z]);
-  constexpr int GR = 8;                      // rows per load group
-  __shared__ unsigned om_lo[256], om_hi[256];
-  __shared__ long long rowsum[4][256];
-  __shared__ long long ssum[4], osum[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ u32x4_t om_op[4][64];                 // A operand of k-step s: lane (limb = l & 15, kq = l >> 4): limb of omega[64s + 16kq + 0..15]
+  // row sums.  SMALL: every lane parks its 16 partial sums of a k-step (< 2^29 each) at [wave][s][lane][16 rows]; they are
+  // added up across the 16 lanes of a row group and the 4 waves once, at the end (LDS atomics into one shared area, and
+  // several witness columns per block to share it, were both slower).  Otherwise: per-wave totals from DPP reductions.
+  __shared__ u32x4_t parked[SMALL ? 4 * 4 * 64 * 4 : 1];
+  __shared__ long long rowsum[SMALL ? 1 : 4][SMALL ? 1 : 256];
+  __shared__ long long wstage_own[SMALL ? 1 : 4 * CT * 32];   // W halves of a wave's columns on their way to the lanes that finish them
+  static_assert(!SMALL || sizeof(long long) * 4 * CT * 32 <= sizeof(u32x4_t) * 4 * 4 * 64 * 4, "W staging fits the parking area");
+  __shared__ long long ssum[4];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int cc = lane & 15, kq = lane >> 4;
   {
-    const uint64_t o = omega[threadIdx.x];
-    om_lo[threadIdx.x] = (unsigned)(o & 0xFFFFF);
-    om_hi[threadIdx.x] = (unsigned)(o >> 20);
-    // sum_m omega[m] (< 2^48): halves summed across the wave (64 x 2^20 and 64 x 2^20: no overflow)
-    const int lo = wave_sum_to_lane63((int)(o & 0xFFFFF)), hi = wave_sum_to_lane63((int)(o >> 20));
-    if (lane == 63) osum[wave] = (long long)lo + ((long long)hi << 20);
-  }
-  const size_t cols = (size_t)n * D;
-  const unsigned i = blockIdx.y;
-  const size_t col0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
-  const bool active = col0 < cols;
-  unsigned s_lo[16], s_hi[SMALL ? 1 : 16], wl[16], wh[16];
+    const int s = t >> 6, l = t & 63, limb = l & 15, g = l >> 4;
+    u32x4_t v = {0, 0, 0, 0};
+    if (limb < PI_LIMBS) {
 #pragma unroll
-  for (int c = 0; c < 16; c++) { s_lo[c] = 0; wl[c] = 0; wh[c] = 0; }
-  if (!SMALL) {
-#pragma unroll
-    for (int c = 0; c < 16; c++) s_hi[SMALL ? 0 : c] = 0;
+      for (int b = 0; b < 16; b++) {
+        const uint32_t d = (uint32_t)(omega[64 * s + 16 * g + b] >> (7 * limb)) & 127u;
+        v[b >> 2] |= d << (8 * (b & 3));
+      }
+    }
+    om_op[s][l] = v;
   }
+  __syncthreads();
+  const size_t cols = (size_t)n * D, ctiles = cols / 16;
+  const size_t ct0 = ((size_t)blockIdx.x * 4 + wave) * CT;             // this wave's first column tile
   long long my_s = 0;
-  if (active) {
-    const uint64_t* sp = S + ((col0 / D) * r + i) * D + (col0 % D);
-#pragma unroll
-    for (int c = 0; c < 16; c += 2) {
-      const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(sp + c);
-      if (SMALL) {
-        s_lo[c] = (unsigned)v.x & 0xFFFFFF; s_lo[c + 1] = (unsigned)v.y & 0xFFFFFF;
-      } else {
-        s_lo[c] = (unsigned)(v.x & 0xFFFFF); s_hi[SMALL ? 0 : c] = (unsigned)(v.x >> 20);
-        s_lo[c + 1] = (unsigned)(v.y & 0xFFFFF); s_hi[SMALL ? 0 : c + 1] = (unsigned)(v.y >> 20);
-      }
-      my_s += (long long)(SMALL ? (v.x & 0xFFFFFF) : v.x) + (long long)(SMALL ? (v.y & 0xFFFFFF) : v.y);
-    }
-  }
-  {  // this block's sum of witness coefficients (< 4096 * 2^40): 20-bit pieces summed across the wave
-    const int p0 = wave_sum_to_lane63((int)(my_s & 0xFFFFF)), p1 = wave_sum_to_lane63((int)((my_s >> 20) & 0xFFFFF)),
-              p2 = wave_sum_to_lane63((int)(my_s >> 40));
-    if (lane == 63) ssum[wave] = (long long)p0 + ((long long)p1 << 20) + ((long long)p2 << 40);
-  }
-  __syncthreads();
-  // inactive threads (ragged last chunk) read dword 0 of their row: no divergence in the loop, their witness
-  // coefficients are 0 (row sums unaffected) and their column sums are never stored
-  // row m of this matrix = a wave-uniform base (scalar registers, advanced per row) + one 32-bit dword index per lane
-  const size_t row_dwords = cols / 16;
-  const uint32_t* rows = Pi + (size_t)i * 256 * row_dwords;
-  const unsigned voff = active ? (unsigned)(col0 / 16) : 0u;
-  uint32_t cur[GR], nxt[GR];
-#pragma unroll
-  for (int u = 0; u < GR; u++) cur[u] = __builtin_nontemporal_load(rows + (size_t)u * row_dwords + voff);
-#pragma unroll 1
-  for (int m0 = 0; m0 < 256; m0 += GR) {
-    if (m0 + GR < 256) {
-      const uint32_t* nrows = rows + (size_t)(m0 + GR) * row_dwords;
-#pragma unroll
-      for (int u = 0; u < GR; u++) nxt[u] = __builtin_nontemporal_load(nrows + (size_t)u * row_dwords + voff);
-    }
-#pragma unroll
-    for (int u = 0; u < GR; u++) {
-      const int m = m0 + u;
-      const uint32_t w = cur[u];
-      const unsigned ol = om_lo[m], oh = om_hi[m];
-      unsigned a_lo = 0, a_hi = 0;
-#pragma unroll
-      for (int c = 0; c < 16; c++) {
-        const unsigned g = (w >> (2 * c)) & 3u;          // e + 1
-        a_lo = __umul24(g, s_lo[c]) + a_lo;
-        if (!SMALL) a_hi = __umul24(g, s_hi[SMALL ? 0 : c]) + a_hi;
-        wl[c] = __umul24(g, ol) + wl[c];
-        wh[c] = __umul24(g, oh) + wh[c];
-      }
-      if (SMALL) { a_hi = a_lo >> 20; a_lo &= 0xFFFFF; }   // a < 16 * 2 * 2^24: split so that the wave sums stay below 2^32
-      a_lo = (unsigned)wave_sum_to_lane63((int)a_lo);
-      a_hi = (unsigned)wave_sum_to_lane63((int)a_hi);
-      if (lane == 63) rowsum[wave][m] = (long long)a_lo + ((long long)a_hi << 20);
-    }
-#pragma unroll
-    for (int u = 0; u < GR; u++) cur[u] = nxt[u];
-  }
-  __syncthreads();
+  const unsigned i = blockIdx.y;
+  (void)ib;
   {
-    const int m = threadIdx.x;
-    const long long t = rowsum[0][m] + rowsum[1][m] + rowsum[2][m] + rowsum[3][m] - (ssum[0] + ssum[1] + ssum[2] + ssum[3]);
-    if (t != 0) atomicAdd(&proj[m], (unsigned long long)t);
-  }
-  if (active) {
-    const size_t x = col0 / D, k0 = col0 % D;
-    const long long om_total = osum[0] + osum[1] + osum[2] + osum[3];
+    // witness coefficients of this lane's column in each of its tiles (tiles past the end: 0, nothing stored)
+    unsigned s_lo[CT], s_hi[SMALL ? 1 : CT];
 #pragma unroll
-    for (int c = 0; c < 16; c++) {
-      const long long v = (long long)wl[c] + ((long long)wh[c] << 20) - om_total;   // sum_m omega[m]*Pi[m][col], |v| < 2^49
-      const uint64_t mag = (uint64_t)(v < 0 ? -v : v) % q;
-      const uint64_t u = v < 0 ? (mag == 0 ? 0 : q - mag) : mag;
-      const size_t k = k0 + c;
-      W[(x * r + i) * D + (k == 0 ? 0 : D - k)] = k == 0 ? u : (u == 0 ? 0 : q - u);
+    for (int c = 0; c < CT; c++) {
+      const size_t col = (ct0 + c) * 16 + cc;
+      uint64_t v = 0;
+      if (ct0 + c < ctiles) v = S[((col / D) * r + i) * D + (col % D)];
+      if (SMALL) { v &= 0xFFFFFF; s_lo[c] = (unsigned)v; }
+      else { s_lo[c] = (unsigned)(v & 0xFFFFF); s_hi[SMALL ? 0 : c] = (unsigned)(v >> 20); }
+      if (kq == 0) my_s += (long long)v;            // each column once per wave
+    }
+    i32x4_t acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; c++) acc[c] = i32x4_t{0, 0, 0, 0};
+    // tiles of k-step s: consecutive column tiles are consecutive 256-byte blocks; past the end the last tile is read again
+    const uint32_t* base = Pi + (size_t)i * 4 * ctiles * 64;
+    auto tile_ptr = [&](int s, int c) { return base + ((size_t)s * ctiles + min(ct0 + c, ctiles - 1)) * 64 + lane; };
+    // the CT tiles of the next k-step are requested while this one is consumed (after the last k-step: a harmless re-read)
+    uint32_t cur[CT], nxt[CT];
+#pragma unroll
+    for (int c = 0; c < CT; c++) cur[c] = __builtin_nontemporal_load(tile_ptr(0, c));
+#pragma unroll 1
+    for (int s = 0; s < 4; s++) {
+      const int sn = s + (s < 3 ? 1 : 0);
+#pragma unroll
+      for (int c = 0; c < CT; c++) nxt[c] = __builtin_nontemporal_load(tile_ptr(sn, c));
+      const u32x4_t ao = om_op[s][lane];
+      const i32x4_t af = {(int)ao.x, (int)ao.y, (int)ao.z, (int)ao.w};
+      unsigned p_lo[16], p_hi[SMALL ? 1 : 16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) p_lo[k] = 0;
+      if (!SMALL) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) p_hi[SMALL ? 0 : k] = 0;
+      }
+#pragma unroll
+      for (int c = 0; c < CT; c++) {
+        const uint32_t w = cur[c];
+        // 2-bit fields -> int8 rows: selector dword j = fields j of the four bytes, table {0: -1, 1: 0, 2: +1}
+        i32x4_t bf;
+#pragma unroll
+        for (int j = 0; j < 4; j++) bf[j] = (int)__builtin_amdgcn_perm(0u, 0x020100FFu, (w >> (2 * j)) & 0x03030303u);
+        acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, acc[c], 0, 0, 0);
+        const unsigned sl = s_lo[c], sh = SMALL ? 0u : s_hi[SMALL ? 0 : c];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {             // row 4j + kk of this lane's block sits at bit 8kk + 2j
+          const unsigned g = (w >> (8 * (k & 3) + 2 * (k >> 2))) & 3u;
+          p_lo[k] = __umul24(g, sl) + p_lo[k];
+          if (!SMALL) p_hi[SMALL ? 0 : k] = __umul24(g, sh) + p_hi[SMALL ? 0 : k];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CT; c++) cur[c] = nxt[c];
+      if constexpr (SMALL) {
+        u32x4_t* dst = parked + (((size_t)wave * 4 + s) * 64 + lane) * 4;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; k4++) dst[k4] = u32x4_t{p_lo[4 * k4], p_lo[4 * k4 + 1], p_lo[4 * k4 + 2], p_lo[4 * k4 + 3]};
+      } else {
+        // row sums of this k-step across the 16 lanes of each DPP row (row_shr 1, 2, 4, 8): the totals of rows
+        // 64s + 16kq + k are valid in lane 15 of row kq
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          unsigned a = p_lo[k], b = p_hi[SMALL ? 0 : k];
+#pragma unroll
+          for (int st = 0; st < 2; st++) {
+            unsigned x = st ? b : a;
+            x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
+            x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
+            x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);
+            x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);
+            if (st) b = x; else a = x;
+          }
+          if (cc == 15) rowsum[wave][64 * s + 16 * kq + k] = (long long)a + ((long long)b << 20);
+        }
+      }
+    }
+    // (acc is finished after the row sums of the block, below: its staging area aliases the parking area)
+    {  // this wave's sum of witness coefficients (< 256 * 2^40): 20-bit pieces summed across the wave
+      const int p0 = wave_sum_to_lane63((int)(my_s & 0xFFFFF)), p1 = wave_sum_to_lane63((int)((my_s >> 20) & 0xFFFFF)),
+                p2 = wave_sum_to_lane63((int)((my_s >> 40) & 0xFFFFF));
+      if (lane == 63) ssum[wave] = (long long)p0 + ((long long)p1 << 20) + ((long long)p2 << 40);
+    }
+    __syncthreads();
+    {
+      const int m = threadIdx.x;
+      long long tot = 0;
+      if constexpr (SMALL) {   // row m = 64s + 16kq + k: the k-th dword of lanes 16kq .. 16kq+15 of k-step s, every wave
+        const int sm = m >> 6, kqm = (m >> 4) & 3, km = m & 15;
+        const uint32_t* pw = reinterpret_cast<const uint32_t*>(parked);
+        for (int wv = 0; wv < 4; wv++)
+          for (int l16 = 0; l16 < 16; l16++) tot += pw[((((size_t)wv * 4 + sm) * 64 + 16 * kqm + l16) * 4) * 4 + km];
+      } else {
+        tot = rowsum[0][m] + rowsum[1][m] + rowsum[2][m] + rowsum[3][m];
+      }
+      tot -= ssum[0] + ssum[1] + ssum[2] + ssum[3];
+      if (tot != 0) atomicAdd(&proj[m], (unsigned long long)tot);
+    }
+    __syncthreads();                                 // the parking area is free again
+    // W: D[limb][col] of tile c sits in register limb & 3 of lane (limb >> 2) * 16 + col: limbs 0..3 in lanes 0..15,
+    // limbs 4, 5 in lanes 16..31 (the matrix-core operand holds the entries themselves, -1/0/+1: no surplus here).  The
+    // two halves of every column go through LDS so that all 64 lanes share the reductions mod q and the stores: lane j
+    // finishes columns j, j + 64, ... of the wave's 16 CT.  
+    long long* wpart = (SMALL ? reinterpret_cast<long long*>(parked) : wstage_own) + (size_t)wave * CT * 32;
+    if (kq < 2) {
+#pragma unroll
+      for (int c = 0; c < CT; c++) {
+        const long long part = kq == 0 ? (long long)acc[c][0] + (long long)acc[c][1] * 128 + (long long)acc[c][2] * 16384 + (long long)acc[c][3] * 2097152
+                                       : (long long)acc[c][0] * 268435456LL + (long long)acc[c][1] * 34359738368LL;
+        wpart[(c * 2 + kq) * 16 + cc] = part;
+      }
+    }
+    __syncthreads();
+    const double inv_q = 1.0 / (double)q;
+#pragma unroll 1
+    for (int jj = 0; jj < CT / 4; jj++) {
+      const int cw = lane + 64 * jj, c = cw >> 4, c16 = cw & 15;
+      if (ct0 + c < ctiles) {
+        const long long v = wpart[(c * 2) * 16 + c16] + wpart[(c * 2 + 1) * 16 + c16];     // sum_m omega[m] * Pi[m][col], |v| < 2^49
+        const uint64_t mag = mod_u64_near((uint64_t)(v < 0 ? -v : v), q, inv_q);
+        const uint64_t u = v < 0 ? (mag == 0 ? 0 : q - mag) : mag;
+        const size_t col = (ct0 + c) * 16 + c16, x = col / D, k = col % D;
+        W[(x * r + i) * D + (k == 0 ? 0 : D - k)] = k == 0 ? u : (u == 0 ? 0 : q - u);
+      }
     }
   }
 }
 
-// Pi int8 [count] in {-1, 0, 1} -> 2 bits per entry (e + 1), 16 entries per thread
-__global__ void k_pi_pack(uint32_t* __restrict__ dst, const int8_t* __restrict__ src, size_t ndwords) {
+// Pi int8 [mats][256][cols] in {-1, 0, 1} -> the tiled 2-bit form of k_pi_mfma; one thread per output dword
+__global__ void k_pi_pack(uint32_t* __restrict__ dst, const int8_t* __restrict__ src, size_t mats, size_t cols) {
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= ndwords) return;
-  const uint4 v = *reinterpret_cast<const uint4*>(src + k * 16);
-  const uint32_t ww[4] = {v.x, v.y, v.z, v.w};
+  const size_t ctiles = cols / 16, per_mat = 4 * ctiles * 64;
+  if (k >= mats * per_mat) return;
+  const size_t i = k / per_mat, w = k % per_mat;
+  const size_t s = w / (ctiles * 64), ct = (w / 64) % ctiles, lane = w % 64;
+  const size_t row0 = 64 * s + 16 * (lane >> 4), col = 16 * ct + (lane & 15);
   uint32_t o = 0;
 #pragma unroll
-  for (int c = 0; c < 16; c++) {
-    const int e = (int)(int8_t)(ww[c >> 2] >> ((c & 3) * 8));
-    o |= (uint32_t)((e + 1) & 3) << (2 * c);
+  for (int t = 0; t < 16; t++) {
+    const int e = src[(i * 256 + row0 + t) * cols + col];
+    o |= (uint32_t)((e + 1) & 3) << (8 * (t & 3) + 2 * (t >> 2));
   }
   dst[k] = o;
 }
 
-hipError_t launch_pi_pack(uint8_t* dst, const int8_t* src, size_t count, hipStream_t s) {
-  if (count % 16) return hipErrorInvalidValue;
-  const size_t nd = count / 16;
+hipError_t launch_pi_pack(uint8_t* dst, const int8_t* src, size_t mats, size_t cols, hipStream_t s) {
+  if (cols % 16) return hipErrorInvalidValue;
+  const size_t nd = mats * 256 * cols / 16;
   if (nd == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_pi_pack, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, reinterpret_cast<uint32_t*>(dst), src, nd);
+  hipLaunchKernelGGL(k_pi_pack, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, reinterpret_cast<uint32_t*>(dst), src, mats, cols);
   return hipGetLastError();
 }
 
-// packed = true: `Pi` holds the 2-bit form (see k_pi_fused2); small_witness: witness coefficients are known to be below 2^24
+// small_witness: witness coefficients are known to be below 2^24
 hipError_t launch_pi_fused2_jobs(const JobPtrs& proj /*zeroed*/, const JobPtrs& W, const JobPtrs& Pi2, const JobPtrs& S,
                                  const JobPtrs& omega, size_t n, size_t r, uint64_t q, size_t njobs, bool small_witness, hipStream_t s) {
   if (n == 0 || r == 0 || njobs == 0) return hipSuccess;
-  const size_t cols = n * D;
-  const dim3 g((unsigned)((cols + 4095) / 4096), (unsigned)r, (unsigned)njobs);
+  constexpr int CT = 16;
+  const size_t cols = n * D, ctiles = cols / 16;
+  const size_t xblocks = (ctiles + 4 * CT - 1) / (4 * CT);
+  const unsigned ib = 1;     // witness columns per block (more than one would need the row sums accumulated: slower, see the kernel)
+  const dim3 g((unsigned)xblocks, (unsigned)((r + ib - 1) / ib), (unsigned)njobs);
   if (small_witness)
-    hipLaunchKernelGGL(k_pi_fused2<true>, g, dim3(256), 0, s, proj, W, Pi2, S, omega, (unsigned)n, (unsigned)r, q);
+    hipLaunchKernelGGL((k_pi_mfma<true, CT>), g, dim3(256), 0, s, proj, W, Pi2, S, omega, (unsigned)n, (unsigned)r, ib, q);
   else
-    hipLaunchKernelGGL(k_pi_fused2<false>, g, dim3(256), 0, s, proj, W, Pi2, S, omega, (unsigned)n, (unsigned)r, q);
+    hipLaunchKernelGGL((k_pi_mfma<false, CT>), g, dim3(256), 0, s, proj, W, Pi2, S, omega, (unsigned)n, (unsigned)r, ib, q);
   return hipGetLastError();
 }
 

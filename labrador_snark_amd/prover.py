@@ -318,19 +318,42 @@ def _io_template(k, crs):
 
 
 def pack_pi(ctx, Pi):
-    """sample_jl_projection's matrices from int8 {-1,0,1} to 2 bits per entry (lab_pi_pack; lab_prove_input.Pi2):
-    same shape with the last axis a quarter as long, uint8; numpy in -> numpy out, cuda tensor in -> cuda tensor out."""
+    """sample_jl_projection's matrices, int8 {-1,0,1} of shape (..., 256, cols), to the tiled 2-bit form of
+    lab_prove_input.Pi2 (lab_pi_pack): uint8 of shape (..., 256*cols/4); numpy in -> numpy out, cuda tensor in -> cuda
+    tensor out."""
+    cols = Pi.shape[-1]
     if isinstance(Pi, np.ndarray):
         Pi = np.ascontiguousarray(Pi, dtype=np.int8)
-        out = np.empty(Pi.shape[:-1] + (Pi.shape[-1] // 4,), dtype=np.uint8)
+        out = np.empty(Pi.shape[:-2] + (256 * cols // 4,), dtype=np.uint8)
         count = Pi.size
     else:
         import torch
         Pi = Pi.contiguous()
-        out = torch.empty(tuple(Pi.shape[:-1]) + (Pi.shape[-1] // 4,), dtype=torch.uint8, device=Pi.device)
+        out = torch.empty(tuple(Pi.shape[:-2]) + (256 * cols // 4,), dtype=torch.uint8, device=Pi.device)
         count = Pi.numel()
-    ctx._check(ctx._lib.lab_pi_pack(ctx._h, _ptr(out), _ptr(Pi), count))
+    if Pi.shape[-2] != 256:
+        raise ValueError("projection matrices have 256 rows")
+    ctx._check(ctx._lib.lab_pi_pack(ctx._h, _ptr(out), _ptr(Pi), count // (256 * cols), cols))
     return out
+
+
+def pack_pi_host(Pi):
+    """The same packing in numpy (reference for tests; bench.py's host path): field = entry + 1 in {0, 1, 2}; dword
+    ((i*4 + s)*(cols/16) + ct)*64 + 16*kq + cc = rows 64s + 16kq + 0..15 of column 16ct + cc, row 4j + k at bit 8k + 2j."""
+    Pi = np.asarray(Pi, dtype=np.int8)
+    lead, cols = Pi.shape[:-2], Pi.shape[-1]
+    f = (Pi.astype(np.int16) + 1).astype(np.uint8).reshape((-1, 4, 4, 4, 4, cols // 16, 16))      # [mat, s, kq, j, k, ct, cc]
+    b = f[:, :, :, 0] | (f[:, :, :, 1] << 2) | (f[:, :, :, 2] << 4) | (f[:, :, :, 3] << 6)          # [mat, s, kq, k, ct, cc]
+    return np.ascontiguousarray(b.transpose(0, 1, 4, 2, 5, 3)).reshape(lead + (256 * cols // 4,))   # [mat, s, ct, kq, cc, k]
+
+
+def unpack_pi_host(packed, cols):
+    """Inverse of pack_pi_host / lab_pi_pack: uint8 (..., 256*cols/4) -> int8 (..., 256, cols)."""
+    packed = np.asarray(packed, dtype=np.uint8)
+    lead = packed.shape[:-1]
+    b = packed.reshape((-1, 4, cols // 16, 4, 16, 4)).transpose(0, 1, 3, 5, 2, 4)                 # [mat, s, kq, k, ct, cc]
+    f = np.stack([(b >> (2 * j)) & 3 for j in range(4)], axis=3)                                    # [mat, s, kq, j, k, ct, cc]
+    return (f.astype(np.int8) - 1).reshape(lead + (256, cols))
 
 
 def _set_pi(pin, tape, keep):

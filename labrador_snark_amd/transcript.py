@@ -64,12 +64,11 @@ def serialize_transcript(T, q, tape=None):
     if tape.get("Pi") is not None:
         Pi = tape["Pi"]
         Pi = Pi.cpu().numpy() if hasattr(Pi, "cpu") else np.asarray(Pi)
-    else:                                              # the 2-bit form (lab_prove_input.Pi2): field = entry + 1; expanded here only
+    else:                                              # the tiled 2-bit form (lab_prove_input.Pi2): expanded here only
+        from .prover import unpack_pi_host
         P2 = tape["Pi2"]
         P2 = P2.cpu().numpy() if hasattr(P2, "cpu") else np.asarray(P2)
-        Pi = np.empty(P2.shape[:-1] + (P2.shape[-1] * 4,), dtype=np.int8)
-        for f in range(4):
-            Pi[..., f::4] = ((P2 >> (2 * f)) & 3).astype(np.int8) - 1
+        Pi = unpack_pi_host(P2, P2.shape[-1] * 4 // 256)
     parts.append(_u64(Pi.shape[0]))
     for i in range(Pi.shape[0]):                       # Zq::lift: -1 -> q-1 (src/proofgen.rs:445-451)
         lifted = np.where(Pi[i] < 0, np.uint64(q - 1), Pi[i].astype(np.uint64)).astype(np.uint64)

@@ -65,10 +65,8 @@ def test_bench_transcript_spot_rows_against_the_oracle(bench_run, j):
     phi = _host(R["sts"][j].phi).reshape(n, r, D)
     a = _host(R["sts"][j].a).reshape(r, r, D)
     tape = R["dtapes"][j]
-    packed = tape["Pi2"].cpu().numpy()                      # bench.py's default: Pi at 2 bits per entry (field = entry + 1)
-    Pi = np.empty(packed.shape[:-1] + (packed.shape[-1] * 4,), np.int8)
-    for f in range(4):
-        Pi[..., f::4] = ((packed >> (2 * f)) & 3).astype(np.int8) - 1
+    import labrador_snark_amd as lab
+    Pi = lab.unpack_pi_host(tape["Pi2"].cpu().numpy(), n * D)   # bench.py's default: Pi at 2 bits per entry, tiled (lab_prove_input.Pi2)
     omega, alpha, beta, c = (_host(tape[x]) for x in ("omega", "alpha", "beta", "c"))
     psi = int(tape["psi"])
     F = _fields(T)

@@ -364,8 +364,17 @@ def test_prove_core_batch_matrix_cores_r32(nb, mfma_basis):
 
 
 def _pack_pi_numpy(Pi):
-    f = (Pi.astype(np.int16) + 1).astype(np.uint8).reshape(Pi.shape[:-1] + (Pi.shape[-1] // 4, 4))
-    return np.ascontiguousarray(f[..., 0] | (f[..., 1] << 2) | (f[..., 2] << 4) | (f[..., 3] << 6))
+    """independent restatement of the tiled 2-bit layout (include/labrador_hip.h, lab_prove_input.Pi2), entry by entry"""
+    mats, rows, cols = Pi.shape
+    out = np.zeros((mats, 4 * (cols // 16) * 64), dtype=np.uint32)
+    for i in range(mats):
+        for m in range(256):
+            s, kq, t = m // 64, (m % 64) // 16, m % 16
+            shift = 8 * (t % 4) + 2 * (t // 4)
+            for col in range(cols):
+                ct, cc = col // 16, col % 16
+                out[i, (s * (cols // 16) + ct) * 64 + 16 * kq + cc] |= np.uint32((int(Pi[i, m, col]) + 1) << shift)
+    return out.view(np.uint8).reshape(mats, 256 * cols // 4)
 
 
 @pytest.mark.parametrize("q", ALL_Q)
@@ -382,7 +391,10 @@ def test_packed_pi_gives_the_same_transcript(q, n, r):
     crs = lab.ResidentCRS(ctx, k).fill_synthetic(1000)
     S, phi, a, tape = cases.make_inputs(p, seed=4242 + n)
     packed = lab.pack_pi(ctx, tape["Pi"])
-    assert packed.dtype == np.uint8 and np.array_equal(packed, _pack_pi_numpy(tape["Pi"]))
+    assert packed.dtype == np.uint8 and np.array_equal(packed, lab.pack_pi_host(tape["Pi"]))
+    assert np.array_equal(lab.unpack_pi_host(packed, n * D), tape["Pi"])
+    if n == 4:
+        assert np.array_equal(packed, _pack_pi_numpy(tape["Pi"]))
     tape2 = dict(tape)
     del tape2["Pi"]
     tape2["Pi2"] = packed

@@ -128,7 +128,8 @@ def test_bincode_layout_hand_built_bytes():
     ])
     assert tr.serialize_transcript(t, q, tape) == want
     # the 2-bit tape (lab_prove_input.Pi2) serialises to the same bytes
-    f = (Pi + 1).astype(np.uint8).reshape(1, 256, D // 4, 4)
+    from labrador_snark_amd import pack_pi_host, unpack_pi_host
     tape2 = {k: v for k, v in tape.items() if k != "Pi"}
-    tape2["Pi2"] = f[..., 0] | (f[..., 1] << 2) | (f[..., 2] << 4) | (f[..., 3] << 6)
+    tape2["Pi2"] = pack_pi_host(Pi)
+    assert np.array_equal(unpack_pi_host(tape2["Pi2"], D), Pi)
     assert tr.serialize_transcript(t, q, tape2) == want
