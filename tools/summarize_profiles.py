@@ -38,7 +38,7 @@ def biggest(kind, name):
 fs, ws = biggest("fetch", "FETCH_SIZE"), biggest("write", "WRITE_SIZE")
 alg = bench["roofline"]["algorithmic_bytes_per_launch"]
 fetch_bytes, write_bytes = fs[0] * 1024 * 2, ws[0] * 1024
-out = {"kernel": "lab::" + DOM + " (step-3 launch of bench.py: nmat=96, rows=1024, cols=1024, all proofs of the step; one 30-bit limb per launch on the matrix-core path, both u32 limbs on the multiply-add path)",
+out = {"kernel": "lab::" + DOM + " (step-3 launch of bench.py: the outer commitment of all proofs of the step, nmat = r*t1 matrices of kappa1 x kappa; one limb of the CRS basis per launch on the matrix-core path)",
        "workload_key": [cfg["q"], cfg["n"], cfg["r"], cfg["kappa"], cfg["nlimbs"], cfg["crs_basis"] != "main basis", cfg["proofs_per_step_per_gpu"]],
        "digit_primes": cfg.get("digit_primes"),
        "step3": "mfma" if cfg.get("step3", "").startswith("int8") else "valu",
