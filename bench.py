@@ -417,6 +417,7 @@ def main():
                        if crs.compact else "main basis", "digit_primes": getattr(ctx, "digit_primes", None) if crs.compact else None, "proofs_per_step_per_gpu": nbatch,
                        "step3": "int8 MFMA GEMMs (signed base-256 digit planes, int32 accumulation, exact)" if use_mfma
                        else "64-bit multiply-add kernels", "parallelism": "%d independent proofs per gpu x %d gpus" % (nbatch, world)},
+            "constraints_per_proof": 1,        # K = 1 dot-product constraint per proof (src/constants.rs:26): constraints/s == proofs/s
             "ms_per_proof": elapsed / (args.steps * nbatch) * 1e3,
             "proofs_per_s": value, "witness_Rq_elems_per_s": value * n * r,
             "ring_products_per_proof": sum(counts.values()),

@@ -595,7 +595,7 @@ k_pi_fused(const JobPtrs projp, const JobPtrs Wp, const JobPtrs Pip, const JobPt
 constexpr int PI_LIMBS = 6;                        // 7-bit limbs of omega (< 2^42)
 
 template <bool SMALL, int CT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMALL ? 3 : 2, SMALL ? 3 : 2)))
 k_pi_mfma(const JobPtrs projp, const JobPtrs Wp, const JobPtrs Pip, const JobPtrs Sp, const JobPtrs omegap, unsigned n, unsigned r,
           unsigned ib, uint64_t q) {
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -606,13 +606,14 @@ k_pi_mfma(const JobPtrs projp, const JobPtrs Wp, const JobPtrs Pip, const JobPtr
   const uint64_t* __restrict__ S = static_cast<const uint64_t*>(Sp.p[blockIdx.z]);
   const uint64_t* __restrict__ omega = static_cast<const uint64_t*>(omegap.p[blockIdx.z]);
   __shared__ u32x4_t om_op[4][64];                 // A operand of k-step s: lane (limb = l & 15, kq = l >> 4): limb of omega[64s + 16kq + 0..15]
-  // row sums.  SMALL: every lane parks its 16 partial sums of a k-step (< 2^29 each) at [wave][s][lane][16 rows]; they are
-  // added up across the 16 lanes of a row group and the 4 waves once, at the end (LDS atomics into one shared area, and
+  // row sums.  SMALL: the 16 partial sums of a k-step (< 2^29 each) are added across groups of 4 lanes (two DPP steps) and
+  // parked at [wave][s][lane / 4][16 rows]; they are added up across the 4 groups of a row group and the 4 waves once, at
+  // the end (16 KB instead of 64: three blocks per CU — the waves of this kernel sit in s_waitcnt half of their time) (LDS atomics into one shared area, and
   // several witness columns per block to share it, were both slower).  Otherwise: per-wave totals from DPP reductions.
-  __shared__ u32x4_t parked[SMALL ? 4 * 4 * 64 * 4 : 1];
+  __shared__ u32x4_t parked[SMALL ? 4 * 4 * 16 * 4 : 1];    // (after two DPP steps: one lane in four parks)
   __shared__ long long rowsum[SMALL ? 1 : 4][SMALL ? 1 : 256];
   __shared__ long long wstage_own[SMALL ? 1 : 4 * CT * 32];   // W halves of a wave's columns on their way to the lanes that finish them
-  static_assert(!SMALL || sizeof(long long) * 4 * CT * 32 <= sizeof(u32x4_t) * 4 * 4 * 64 * 4, "W staging fits the parking area");
+  static_assert(!SMALL || sizeof(long long) * 4 * CT * 32 <= sizeof(u32x4_t) * 4 * 4 * 16 * 4, "W staging fits the parking area");
   __shared__ long long ssum[4];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -690,9 +691,18 @@ k_pi_mfma(const JobPtrs projp, const JobPtrs Wp, const JobPtrs Pip, const JobPtr
 #pragma unroll
       for (int c = 0; c < CT; c++) cur[c] = nxt[c];
       if constexpr (SMALL) {
-        u32x4_t* dst = parked + (((size_t)wave * 4 + s) * 64 + lane) * 4;
 #pragma unroll
-        for (int k4 = 0; k4 < 4; k4++) dst[k4] = u32x4_t{p_lo[4 * k4], p_lo[4 * k4 + 1], p_lo[4 * k4 + 2], p_lo[4 * k4 + 3]};
+        for (int k = 0; k < 16; k++) {             // sums of 4 neighbouring lanes (< 2^31) in lanes 3, 7, 11, ...
+          unsigned x = p_lo[k];
+          x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
+          x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
+          p_lo[k] = x;
+        }
+        if ((lane & 3) == 3) {
+          u32x4_t* dst = parked + (((size_t)wave * 4 + s) * 16 + (lane >> 2)) * 4;
+#pragma unroll
+          for (int k4 = 0; k4 < 4; k4++) dst[k4] = u32x4_t{p_lo[4 * k4], p_lo[4 * k4 + 1], p_lo[4 * k4 + 2], p_lo[4 * k4 + 3]};
+        }
       } else {
         // row sums of this k-step across the 16 lanes of each DPP row (row_shr 1, 2, 4, 8): the totals of rows
         // 64s + 16kq + k are valid in lane 15 of row kq
@@ -722,11 +732,11 @@ k_pi_mfma(const JobPtrs projp, const JobPtrs Wp, const JobPtrs Pip, const JobPtr
     {
       const int m = threadIdx.x;
       long long tot = 0;
-      if constexpr (SMALL) {   // row m = 64s + 16kq + k: the k-th dword of lanes 16kq .. 16kq+15 of k-step s, every wave
+      if constexpr (SMALL) {   // row m = 64s + 16kq + k: the k-th dword of lane groups 4kq .. 4kq+3 of k-step s, every wave
         const int sm = m >> 6, kqm = (m >> 4) & 3, km = m & 15;
         const uint32_t* pw = reinterpret_cast<const uint32_t*>(parked);
         for (int wv = 0; wv < 4; wv++)
-          for (int l16 = 0; l16 < 16; l16++) tot += pw[((((size_t)wv * 4 + sm) * 64 + 16 * kqm + l16) * 4) * 4 + km];
+          for (int g4 = 0; g4 < 4; g4++) tot += pw[((((size_t)wv * 4 + sm) * 16 + 4 * kqm + g4) * 4) * 4 + km];
       } else {
         tot = rowsum[0][m] + rowsum[1][m] + rowsum[2][m] + rowsum[3][m];
       }
