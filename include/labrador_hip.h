@@ -103,6 +103,13 @@ int lab_ctx_profile_begin(lab_ctx *ctx);
 int lab_ctx_profile_end(lab_ctx *ctx, double *kernel_ms, uint64_t *launches, double *algorithmic_bytes);
 /* name (template arguments included) of the kernel the most recent launch timed by the hook was dispatched to */
 const char *lab_ctx_profile_kernel(const lab_ctx *ctx);
+/* Diagnostic variants of that kernel (tools/gemm_ablation.py; the matrix-core outer commitment at 64 sets only, otherwise
+ * ignored).  mode 0: the product kernel.  1: the same loop, and every block writes the shader-clock (s_memtime) and
+ * constant-clock (s_memrealtime) ticks its K loop took to ticks[2*block], ticks[2*block + 1] (device memory, `words`
+ * uint64 long; NULL: nothing is written).  2: the loop without its global loads and LDS-DMA (multiply side alone),
+ * 3: without its matrix instructions and LDS reads (load side alone) — the commitments computed in modes 2 and 3 are
+ * MEANINGLESS; these modes exist to time the two sides of the loop separately.  Stays in force until set again. */
+int lab_ctx_gemm_diag(lab_ctx *ctx, int mode, uint64_t *ticks, size_t words);
 /* how the most recent lab_prove_core[_batch] call ran: 1 = step 1 in the digit basis (lab_prove_input.A8d), 2 = that was tried,
  * a witness exceeded beta_bound and the batch was redone in the main basis; 0 = main basis from the start */
 int lab_ctx_prove_flags(const lab_ctx *ctx);

@@ -118,6 +118,11 @@ class Context:
         self._check(self._lib.lab_ctx_profile_end(self._h, C.byref(ms), C.byref(n), C.byref(b)))
         return ms.value, int(n.value), b.value
 
+    def gemm_diag(self, mode, ticks=None):
+        """Diagnostic variant of the timed GEMM (include/labrador_hip.h: lab_ctx_gemm_diag); ticks: uint64 device tensor."""
+        ptr, words = (ticks.data_ptr(), ticks.numel()) if ticks is not None else (None, 0)
+        self._check(self._lib.lab_ctx_gemm_diag(self._h, int(mode), ptr, words))
+
     def profile_kernel(self):
         """Name of the kernel the most recent launch timed by the profiling hook was dispatched to."""
         return self._lib.lab_ctx_profile_kernel(self._h).decode()

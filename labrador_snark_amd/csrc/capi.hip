@@ -380,6 +380,16 @@ extern "C" const char* lab_ctx_profile_kernel(const lab_ctx* c) {
   return c ? c->prof_kernel.c_str() : "";
 }
 
+extern "C" int lab_ctx_gemm_diag(lab_ctx* c, int mode, uint64_t* ticks, size_t words) {
+  if (!c) return LAB_ERR_ARG;
+  if (mode < 0 || mode > 3) return fail(c, LAB_ERR_ARG, "lab_ctx_gemm_diag: mode %d (0..3)", mode);
+  LAB_HIP(c, hipStreamSynchronize(c->stream));
+  c->gemm_diag = mode;
+  c->gemm_diag_buf = mode ? ticks : nullptr;
+  c->gemm_diag_words = mode && ticks ? words : 0;
+  return LAB_OK;
+}
+
 extern "C" int lab_ctx_prove_flags(const lab_ctx* c) { return c ? c->prove_flags : 0; }
 
 extern "C" int lab_ctx_profile_end(lab_ctx* c, double* kernel_ms, uint64_t* launches, double* algorithmic_bytes) {

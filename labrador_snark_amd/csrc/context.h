@@ -45,6 +45,9 @@ struct lab_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   size_t prof_used = 0;
   double prof_bytes = 0.0;
+  int gemm_diag = 0;              // lab_ctx_gemm_diag (include/labrador_hip_diag.h): diagnostic variant of the timed GEMM
+  uint64_t* gemm_diag_buf = nullptr;
+  size_t gemm_diag_words = 0;
   std::string prof_kernel;        // kernel the last profiled mat-vec launch was dispatched to
   int prove_flags = 0;            // last lab_prove_core[_batch]: 1 = step 1 ran in the digit basis, 2 = tried and redone in the main basis
 };

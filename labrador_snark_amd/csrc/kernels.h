@@ -137,6 +137,9 @@ struct Gemm8Args {
   uint32_t pw[7];           // 256^e mod p, e = 0..6 (recombination weights)
   uint32_t bias;            // 2^31 * (sum_{i<planes} 256^i)^2 mod p: what entering every D as D + 2^31 adds to the sum
   uint32_t* stage;          // non-null: results go to stage[job][slot][row][set] (full-line stores), see k_slot_transpose
+  int diag = 0;             // lab_ctx_gemm_diag: 0 = the product kernel; 1 = + in-kernel clock stamps; 2 / 3 = load / multiply side removed
+  uint64_t* diag_buf = nullptr;   // [block][2]: shader-clock ticks (s_memtime) and constant-clock ticks (s_memrealtime) of the K loop
+  size_t diag_words = 0;
 };
 hipError_t launch_slot_transpose(uint32_t* out_plane, size_t out_set_stride, size_t out_job_stride, const uint32_t* stage,
                                  size_t rows, size_t rows_pad, size_t ns, size_t ns_valid, size_t njobs, size_t nsub, hipStream_t s);

@@ -104,6 +104,7 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
       g.bias = (uint32_t)((sum * sum % primes[l]) * ((1ull << 31) % primes[l]) % primes[l]);
     }
     g.stage = stage;
+    if (timed && c->gemm_diag) { g.diag = c->gemm_diag; g.diag_buf = c->gemm_diag_buf; g.diag_words = c->gemm_diag_words; }
     const bool prof = timed && c->prof_on && pl >= 3;   // `timed`: the outer commitment (the measurement hook's kernel)
     if (prof && c->prof_used == c->prof_events.size()) {
       hipEvent_t a, b;

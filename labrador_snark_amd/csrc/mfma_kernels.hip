@@ -589,10 +589,13 @@ k_gemm_i8(const Gemm8Args a) {
 constexpr int W3_KS = 2;       // k-tiles per stage
 constexpr int W3_RING = 4;     // ring slots (A registers and B LDS slots): 3 stages in flight behind the one being multiplied
 
-template <int NT>
+// DIAG != 0 (lab_ctx_gemm_diag, NT = 6 only): every block also records the shader-clock and constant-clock ticks its K loop
+// took; DIAG 2 / 3 run the loop without its loads / without its matrix instructions (the results are then meaningless).
+template <int NT, int DIAG = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_gemm_i8_w3(const Gemm8Args a) {
   static_assert(NT == 3 || NT == 6, "32 or 64 sets of 3 planes");
+  static_assert(DIAG == 0 || NT == 6, "the diagnostic variants exist for the outer commitment's shape");
   constexpr int HALVES = NT / 3;                    // 32-set halves: column n = i' * ns + s lies in tile i' * HALVES + s / 32
   constexpr int PIECES = W3_KS * NT;                // 1 KiB DMA pieces per stage
   constexpr int PPW = (PIECES + 3) / 4;             // ... per wave (NT = 3: the last wave repeats the third wave's pieces)
@@ -629,12 +632,28 @@ k_gemm_i8_w3(const Gemm8Args a) {
   "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]), "+a"(acc[8]),  \
       "+a"(acc[9]), "+a"(acc[10]), "+a"(acc[11]), "+a"(acc[12]), "+a"(acc[13]), "+a"(acc[14]), "+a"(acc[15]), "+v"(acc[16]),     \
       "+v"(acc[17]), "+v"(bg)
+    uint64_t tick0 = 0, real0 = 0;
+    if constexpr (DIAG != 0) { tick0 = __builtin_amdgcn_s_memtime(); real0 = __builtin_amdgcn_s_memrealtime(); }
+    if constexpr (DIAG == 2)
+      asm volatile(W3_LOOP_ASM_NT6_NOLOAD : W3_ACC_OPERANDS : "s"(a0), "s"(a1), "s"(a2), "v"(voff), "v"(vlds), "s"(m0b), "s"(nstages)
+                   : W3_LOOP_CLOBBERS_NT6_NTLOAD);
+    else if constexpr (DIAG == 3)
+      asm volatile(W3_LOOP_ASM_NT6_NOMFMA : W3_ACC_OPERANDS : "s"(a0), "s"(a1), "s"(a2), "v"(voff), "v"(vlds), "s"(m0b), "s"(nstages)
+                   : W3_LOOP_CLOBBERS_NT6_NTLOAD);
+    else
     if (a.njobs > 1)   // the matrix is shared by many jobs (Ajtai): keep it in L2
       asm volatile(W3_LOOP_ASM_NT6_PLAIN : W3_ACC_OPERANDS : "s"(a0), "s"(a1), "s"(a2), "v"(voff), "v"(vlds), "s"(m0b), "s"(nstages)
                    : W3_LOOP_CLOBBERS_NT6_PLAIN);
     else               // read once (outer commitment): non-temporal
       asm volatile(W3_LOOP_ASM_NT6_NTLOAD : W3_ACC_OPERANDS : "s"(a0), "s"(a1), "s"(a2), "v"(voff), "v"(vlds), "s"(m0b), "s"(nstages)
                    : W3_LOOP_CLOBBERS_NT6_NTLOAD);
+    if constexpr (DIAG != 0) {
+      const uint64_t tick1 = __builtin_amdgcn_s_memtime(), real1 = __builtin_amdgcn_s_memrealtime();
+      if (t == 0 && a.diag_buf && 2 * (size_t)blockIdx.x + 1 < a.diag_words) {
+        a.diag_buf[2 * blockIdx.x] = tick1 - tick0;
+        a.diag_buf[2 * blockIdx.x + 1] = real1 - real0;
+      }
+    }
 #undef W3_ACC_OPERANDS
   } else {
 #define W3_ACC_OPERANDS                                                                                                          \
@@ -727,7 +746,10 @@ hipError_t launch_gemm_i8(const Gemm8Args& a, size_t nt, int waves, hipStream_t 
   if (waves == 6) hipLaunchKernelGGL((k_gemm_i8<NTV, 6>), g, dim3(384), 0, s, a);                     \
   else hipLaunchKernelGGL((k_gemm_i8<NTV, 3>), g, dim3(192), 0, s, a)
   if (a.planes == 3 && waves == 4) {                // 3-plane limbs, one row tile (all three planes) per wave
-    if (nt == 6) hipLaunchKernelGGL((k_gemm_i8_w3<6>), g, dim3(256), 0, s, a);
+    if (nt == 6 && a.diag == 1 && a.njobs == 1) hipLaunchKernelGGL((k_gemm_i8_w3<6, 1>), g, dim3(256), 0, s, a);
+    else if (nt == 6 && a.diag == 2 && a.njobs == 1) hipLaunchKernelGGL((k_gemm_i8_w3<6, 2>), g, dim3(256), 0, s, a);
+    else if (nt == 6 && a.diag == 3 && a.njobs == 1) hipLaunchKernelGGL((k_gemm_i8_w3<6, 3>), g, dim3(256), 0, s, a);
+    else if (nt == 6) hipLaunchKernelGGL((k_gemm_i8_w3<6>), g, dim3(256), 0, s, a);
     else if (nt == 3) hipLaunchKernelGGL((k_gemm_i8_w3<3>), g, dim3(256), 0, s, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();

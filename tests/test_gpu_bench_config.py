@@ -169,3 +169,27 @@ def test_bench_batch_equals_the_multiply_add_path_word_for_word(bench_run):
             assert np.array_equal(_host(T1.projection_int), _host(R["Ts"][j].projection_int))
     finally:
         B.close()
+
+
+def test_gemm_diag_clock_stamps_leave_the_commitments_unchanged(bench_run):
+    """lab_ctx_gemm_diag mode 1 (tools/gemm_ablation.py): the product loop with s_memtime / s_memrealtime read around it —
+    the transcripts equal the product kernel's, and every block of the last limb launch left its two tick counts."""
+    import torch
+    import labrador_snark_amd as lab
+    R = bench_run
+    ctx = R["ctx"]
+    ticks = torch.zeros(2 * 512, dtype=torch.int64, device="cuda:0")      # 64 slots x 8 row groups of 4 tiles
+    ctx.gemm_diag(1, ticks)
+    try:
+        Ts = lab.prove_core_batch(ctx, R["k"], R["dSs"], R["sts"], R["crs"], R["dtapes"], device_outputs=True)
+        torch.cuda.synchronize()
+    finally:
+        ctx.gemm_diag(0, None)
+    for j in CHECKED:
+        for name in ("u_1", "u_2", "z"):
+            assert np.array_equal(_host(getattr(Ts[j], name)), _host(getattr(R["Ts"][j], name))), (j, name)
+    t = ticks.cpu().numpy().reshape(-1, 2)
+    assert (t > 0).all()
+    assert 0.5 < (t[:, 0] / t[:, 1]).mean() * 0.1 < 3.0          # shader clock in GHz against the 100 MHz constant clock
+    with pytest.raises(lab.LabradorError):
+        ctx.gemm_diag(7, None)

@@ -31,7 +31,9 @@ KS, RING, PF = 2, 4, 3
 RING0, FR0 = 120, 216
 
 
-def gen(NT, nt_loads):
+def gen(NT, nt_loads, mode="full"):
+    """mode: "full"; the diagnostic variants "noload" (no global loads / LDS-DMA: the multiply side alone) and "nomfma"
+    (no matrix instructions or LDS reads: the load side alone) keep everything else — waits, barriers, address updates"""
     nacc = 3 * NT
     pieces = KS * NT
     ppw = (pieces + 3) // 4
@@ -58,12 +60,13 @@ def gen(NT, nt_loads):
     # s40: index of the next stage to issue, s41: stage being multiplied, s[42:43]: 64-bit B increment, s44: A increment
     def vmem_ops(slot):
         """the instructions that issue one stage, in groups that are spread between the matrix instructions"""
-        grp = [["s_add_u32 m0, %%%d, %d" % (o_m0b, slot * slot_bytes), "s_nop 0", "global_load_lds_dwordx4 %%%d, off" % o_bg]]
+        ld = mode != "noload"
+        grp = [["s_add_u32 m0, %%%d, %d" % (o_m0b, slot * slot_bytes), "s_nop 0"] + (["global_load_lds_dwordx4 %%%d, off" % o_bg] if ld else [])]
         for q in range(1, ppw):
-            grp.append(["global_load_lds_dwordx4 %%%d, off offset:%d" % (o_bg, q * 1024)])
+            grp.append(["global_load_lds_dwordx4 %%%d, off offset:%d" % (o_bg, q * 1024)] if ld else [])
         for ks in range(KS):
             for i in range(3):
-                grp.append(["global_load_dwordx4 %s, %%%d, %s offset:%d%s" % (ring(slot, ks, i), o_voff, sa[i], ks * 1024, nt)])
+                grp.append(["global_load_dwordx4 %s, %%%d, %s offset:%d%s" % (ring(slot, ks, i), o_voff, sa[i], ks * 1024, nt)] if ld else [])
         # advance to the next stage unless this was the last one (then the last stage is fetched again, into a slot nobody reads)
         adv = ["s_add_u32 s40, s40, 1", "s_cmp_lt_u32 s40, %%%d" % o_nst,
                "s_cselect_b32 s42, %d, 0" % (pieces * 1024), "s_cselect_b32 s44, %d, 0" % (KS * 1024),
@@ -88,9 +91,12 @@ def gen(NT, nt_loads):
             ks, n = divmod(f, NT)
             emit("s_waitcnt lgkmcnt(%d)" % (PF - 1))
             for i in range(3):
-                emit("v_mfma_i32_32x32x32_i8 %%%d, %s, %s, %%%d" % (i * NT + n, ring(k, ks, i), fr(f % PF), i * NT + n))
+                if mode != "nomfma":
+                    emit("v_mfma_i32_32x32x32_i8 %%%d, %s, %s, %%%d" % (i * NT + n, ring(k, ks, i), fr(f % PF), i * NT + n))
             nxt = f + PF
-            if nxt < nm:
+            if mode == "nomfma":
+                pass
+            elif nxt < nm:
                 emit("ds_read_b128 %s, %%%d offset:%d" % (fr(f % PF), o_vlds, k * slot_bytes + nxt * 1024))
             else:
                 emit("ds_read_b128 %s, %%%d offset:%d" % (fr(f % PF), o_vlds, ((k + 1) % RING) * slot_bytes + (nxt - nm) * 1024))
@@ -112,7 +118,8 @@ def gen(NT, nt_loads):
     emit("s_waitcnt vmcnt(%d)" % (2 * ops))
     emit("s_barrier")
     for f in range(PF):
-        emit("ds_read_b128 %s, %%%d offset:%d" % (fr(f), o_vlds, f * 1024))
+        if mode != "nomfma":
+            emit("ds_read_b128 %s, %%%d offset:%d" % (fr(f), o_vlds, f * 1024))
     emit("1:")
     stage(0)
     stage(1)
@@ -145,6 +152,13 @@ def main():
             out.append("")
             out.append("#define W3_LOOP_CLOBBERS_%s %s" % (name, ", ".join(clob)))
             out.append("")
+    # diagnostic variants of the outer commitment's loop (NT = 6, non-temporal A loads): lab_ctx_gemm_diag modes 2 and 3
+    for mode in ("noload", "nomfma"):
+        L, clob = gen(6, 1, mode)
+        out.append("#define W3_LOOP_ASM_NT6_%s \\" % mode.upper())
+        for k, ins in enumerate(L):
+            out.append('    "%s\\n\\t"%s' % (ins, " \\" if k + 1 < len(L) else ""))
+        out.append("")
     sys.stdout.write("\n".join(out) + "\n")
 
 
