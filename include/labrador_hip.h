@@ -108,7 +108,8 @@ const char *lab_ctx_profile_kernel(const lab_ctx *ctx);
  * constant-clock (s_memrealtime) ticks its K loop took to ticks[2*block], ticks[2*block + 1] (device memory, `words`
  * uint64 long; NULL: nothing is written).  2: the loop without its global loads and LDS-DMA (multiply side alone),
  * 3: without its matrix instructions and LDS reads (load side alone) — the commitments computed in modes 2 and 3 are
- * MEANINGLESS; these modes exist to time the two sides of the loop separately.  Stays in force until set again. */
+ * MEANINGLESS; these modes exist to time the two sides of the loop separately.  4: like 1, for the launches that multiply
+ * one matrix with many jobs (the Ajtai product of a batch) instead.  Stays in force until set again. */
 int lab_ctx_gemm_diag(lab_ctx *ctx, int mode, uint64_t *ticks, size_t words);
 /* how the most recent lab_prove_core[_batch] call ran: 1 = step 1 in the digit basis (lab_prove_input.A8d), 2 = that was tried,
  * a witness exceeded beta_bound and the batch was redone in the main basis; 0 = main basis from the start */

@@ -382,7 +382,7 @@ extern "C" const char* lab_ctx_profile_kernel(const lab_ctx* c) {
 
 extern "C" int lab_ctx_gemm_diag(lab_ctx* c, int mode, uint64_t* ticks, size_t words) {
   if (!c) return LAB_ERR_ARG;
-  if (mode < 0 || mode > 3) return fail(c, LAB_ERR_ARG, "lab_ctx_gemm_diag: mode %d (0..3)", mode);
+  if (mode < 0 || mode > 4) return fail(c, LAB_ERR_ARG, "lab_ctx_gemm_diag: mode %d (0..4)", mode);
   LAB_HIP(c, hipStreamSynchronize(c->stream));
   c->gemm_diag = mode;
   c->gemm_diag_buf = mode ? ticks : nullptr;

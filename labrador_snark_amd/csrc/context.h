@@ -155,7 +155,14 @@ struct MfmaGramOut { uint32_t* out; size_t plane_stride, job_stride, r; bool don
 int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_mat8* m, ConstHatView V, size_t v_set_stride, int ns,
                      int ns_valid, void* scratch, size_t v_k_stride, size_t njobs, size_t out_job_stride, size_t v_job_stride,
                      bool timed = false, MfmaCoefOut* coef = nullptr, const int8_t* prepacked = nullptr,
-                     MfmaGramOut* gram = nullptr);
+                     MfmaGramOut* gram = nullptr, int8_t* keep_tiles = nullptr);
+// X_a = P_a^T S per proof on the matrix cores (mfma_api.hip): P_a as [n][r] coefficient matrices, the witness as the tiles
+// matvec_mfma_impl(keep_tiles) made of it for the Ajtai product
+bool gram_mfma_ok(const lab_mat8* m, size_t n, size_t r);
+size_t gram_mfma_tile_bytes(const lab_mat8* m, size_t njobs);
+size_t gram_mfma_scratch_bytes(const lab_mat8* m, size_t njobs);
+int gram_mfma_impl(lab_ctx* c, const lab_mat8* m, int nops, const HatView* outs, const JobPtrs* Pcoefs, const int8_t* s_tiles,
+                   size_t out_job_stride, size_t n, size_t r, size_t njobs, void* scratch);
 // B-operand tiles of every limb straight from 16-bit decomposition digits (to_hat + packing fused, mfma_kernels.hip);
 // hand the buffer to matvec_mfma_impl as `prepacked` (njobs = 1)
 size_t mfma_prepacked_bytes(const lab_mat8* m, int ns);

@@ -145,15 +145,19 @@ hipError_t launch_slot_transpose(uint32_t* out_plane, size_t out_set_stride, siz
                                  size_t rows, size_t rows_pad, size_t ns, size_t ns_valid, size_t njobs, size_t nsub, hipStream_t s);
 int gemm_i8_waves(int planes, size_t rt_count, size_t nt);   // waves per block (4 or 8) the launcher will use
 hipError_t launch_gemm_i8(const Gemm8Args& a, size_t nt, int waves, hipStream_t s);
-// G = S^T S per proof from the B-operand tiles of its (at most 32) witness columns, 3-plane limb (see k_gram_v8); `sub` source
-// jobs share one tile set (2 when two proofs were packed as one 64-set job)
-hipError_t launch_gram_v8(const int8_t* V8, size_t v8_job_stride, size_t kt_count, size_t kt_real, size_t nt_count, size_t sub, size_t r,
-                          size_t njobs, uint32_t* out_plane, size_t out_job_stride, uint32_t p, const uint32_t* pw, uint32_t bias,
-                          const LimbTable* tab, hipStream_t s);
+// X = P^T S per proof (G = S^T S when P8a is null or S8; two operands in one pass when P8b is given) from the B-operand tiles of its (at most 32) columns, 3-plane limb (see
+// k_gram_v8); `sub` source jobs share one tile set (2 when two proofs were packed as one 64-set job)
+hipError_t launch_gram_v8(const int8_t* P8a, const int8_t* P8b, const int8_t* S8, size_t v8_job_stride, size_t kt_count, size_t kt_real,
+                          size_t nt_count, size_t sub, size_t r, size_t njobs, uint32_t* out_a, uint32_t* out_b, size_t out_job_stride,
+                          uint32_t p, const uint32_t* pw, uint32_t bias, const LimbTable* tab, hipStream_t s);
 // 16-bit decomposition digits ([ktotal][64] per set, src16.p[s]) -> transform -> B-operand tiles of every limb
 // (dst + l*limb_stride), see k_digits_to_v8; digits must be below every limb prime
 hipError_t launch_digits_to_v8(const JobPtrs& src16, size_t ktotal, int8_t* dst, size_t limb_stride, size_t kt_count, int ns,
                                int ns_valid, int nlimbs, const LimbTable* tabs, const int* planes, const size_t* nt, hipStream_t s);
+// the columns of [n][r] coefficient matrices (64-bit words below q < 2^40, one matrix per proof) -> B-operand tiles of every limb
+// (limb primes below 2^23), ns / 32 proofs per job
+hipError_t launch_coefs_to_v8(const JobPtrs& src64, size_t n, size_t r, int8_t* dst, size_t limb_stride, size_t job_stride, size_t kt_count,
+                              int ns, size_t njobs, int nlimbs, const LimbTable* tabs, const int* planes, const size_t* nt, hipStream_t s);
 // tiled Gram: partial[chunk][i][k], gram_chunks(..) <= gram_num_chunks(n) chunks, to be summed with launch_sum_terms(rows = r*r)
 size_t gram_num_chunks(size_t n);
 size_t gram_chunks(size_t n, size_t r, int nlimbs, size_t njobs);

@@ -49,6 +49,68 @@ static size_t stage_bytes(const lab_mat8* m, int ns, size_t njobs) {
 }
 size_t mfma_scratch_bytes(const lab_mat8* m, int ns, size_t njobs) { return v8_job_bytes(m, ns) * njobs + stage_bytes(m, ns, njobs); }
 
+// recombination weights 256^e mod p and the bias that entering every int32 D as D + 2^31 adds to the sum
+static void recomb_consts(uint32_t p, int pl, uint32_t (&pw)[7], uint32_t* bias) {
+  pw[0] = 1 % p;
+  for (int e = 1; e < 7; e++) pw[e] = (uint32_t)(((uint64_t)pw[e - 1] * 256) % p);
+  uint64_t sum = 0;
+  for (int i = 0; i < pl; i++) sum += pw[i];
+  sum %= p;
+  *bias = (uint32_t)((sum * sum % p) * ((1ull << 31) % p) % p);
+}
+
+// ---- X_a = P_a^T S per proof on the matrix cores (steps 6-8: phi'^T S and W^T S), a < nops <= 2.
+// P_a and S are [n][r] matrices of transform-domain residues in the basis of m (every limb 3 planes), element (x, i) at
+// base + job*v_job_stride + (x*r + i)*64; out_a[i*r + k] = sum_x P_a[x][i] S[x][k] at outs[a].base + job*out_job_stride.
+// Same tiles, same pairing of two 32-column proofs into one 64-set tile as the Ajtai product of matvec_mfma_impl.
+static bool gram_mfma_pairs(size_t njobs, int ns) { return njobs >= 2 && njobs % 2 == 0 && ns == 32; }
+// bytes of the witness tiles of every limb (matvec_mfma_impl's `keep_tiles`) and of gram_mfma_impl's scratch (two operands)
+size_t gram_mfma_tile_bytes(const lab_mat8* m, size_t njobs) {
+  const bool paired = gram_mfma_pairs(njobs, 32);
+  return (size_t)m->nlimbs * v8_job_bytes(m, paired ? 64 : 32) * (paired ? njobs / 2 : njobs);
+}
+size_t gram_mfma_scratch_bytes(const lab_mat8* m, size_t njobs) { return 2 * gram_mfma_tile_bytes(m, njobs); }
+bool gram_mfma_ok(const lab_mat8* m, size_t n, size_t r) {
+  if (!m || m->nmat * m->cols != n || r <= 16 || r > 32) return false;
+  for (int l = 0; l < m->nlimbs; l++)
+    if (m->planes[l] != 3) return false;
+  return true;
+}
+// Pcoefs[a].p[job]: the [n][r][64] coefficient matrix (64-bit words below q) of proof `job`; s_tiles: the witness tiles of
+// every limb as matvec_mfma_impl(keep_tiles) left them; out_a[i*r + k] = sum_x P_a[x][i] S[x][k] (transform domain, basis of
+// m) at outs[a].base + job*out_job_stride.  One pass per operand makes its tiles of all limbs (reduce + NTT + packing fused,
+// k_digits_to_v8<true>), one launch per limb multiplies both operands with the witness tiles.
+int gram_mfma_impl(lab_ctx* c, const lab_mat8* m, int nops, const HatView* outs, const JobPtrs* Pcoefs, const int8_t* s_tiles,
+                   size_t out_job_stride, size_t n, size_t r, size_t njobs, void* scratch) {
+  if (!gram_mfma_ok(m, n, r) || nops < 1 || nops > 2) return fail(c, LAB_ERR_ARG, "gram_mfma_impl: shape not taken");
+  const uint32_t* primes = m->basis ? c->dg_primes : c->primes;
+  const LimbTable* tabs = m->basis ? c->dg_tabs : c->d_tabs;
+  const size_t src_jobs = njobs;
+  const bool paired = gram_mfma_pairs(njobs, 32);
+  const int ns = paired ? 64 : 32;
+  if (paired) njobs /= 2;
+  const size_t v8_stride = v8_job_bytes(m, ns), limb_stride = v8_stride * njobs;
+  size_t nts[MAX_LIMBS];
+  for (int l = 0; l < m->nlimbs; l++) nts[l] = nt_for(ns, 3);
+  int8_t* p8[2] = {static_cast<int8_t*>(scratch), static_cast<int8_t*>(scratch) + (size_t)m->nlimbs * limb_stride};
+  for (int a = 0; a < nops; a++) {
+    // k tiles past ceil(n / 64) * 2 are not written (zero padding of kt_count): the multiplication stops after ceil(n / 32)
+    if (((n + 63) / 64) * 2 < (n + 31) / 32) return fail(c, LAB_ERR_ARG, "gram_mfma_impl: internal: tile count");
+    LAB_HIP(c, launch_coefs_to_v8(Pcoefs[a], n, r, p8[a], limb_stride, v8_stride, m->kt_count, ns, njobs, m->nlimbs, tabs, m->planes, nts,
+                                  c->stream));
+  }
+  for (int l = 0; l < m->nlimbs; l++) {
+    uint32_t pw[7], bias;
+    recomb_consts(primes[l], 3, pw, &bias);
+    LAB_HIP(c, launch_gram_v8(p8[0] + (size_t)l * limb_stride, nops > 1 ? p8[1] + (size_t)l * limb_stride : nullptr,
+                              s_tiles + (size_t)l * limb_stride, v8_stride, m->kt_count, (n + 31) / 32, nts[l], paired ? 2 : 1, r, src_jobs,
+                              outs[0].base + (size_t)l * outs[0].plane_stride,
+                              nops > 1 ? outs[1].base + (size_t)l * outs[1].plane_stride : nullptr, out_job_stride, primes[l], pw, bias,
+                              tabs + l, c->stream));
+  }
+  return LAB_OK;
+}
+
 // For every job b < njobs: out_s[rho] (s < ns_valid; hat elements at out.base + b*out_job_stride + s*out_set_stride)
 //   = sum_k M[rho][k] V_s[k],  V_s[k] at V.base + b*v_job_stride + s*v_set_stride + k*v_k_stride
 // (v_k_stride = 64 words for vectors stored set by set).  ns in {8,16,32,64} is the padded set count the GEMM runs with;
@@ -57,7 +119,7 @@ size_t mfma_scratch_bytes(const lab_mat8* m, int ns, size_t njobs) { return v8_j
 // limbs are bracketed by events.
 int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_mat8* m, ConstHatView V, size_t v_set_stride, int ns,
                      int ns_valid, void* scratch, size_t v_k_stride, size_t njobs, size_t out_job_stride, size_t v_job_stride,
-                     bool timed, MfmaCoefOut* coef, const int8_t* prepacked, MfmaGramOut* gram) {
+                     bool timed, MfmaCoefOut* coef, const int8_t* prepacked, MfmaGramOut* gram, int8_t* keep_tiles) {
   const uint32_t* primes = m->basis ? c->dg_primes : c->primes;
   const size_t ktotal = m->nmat * m->cols;
   // Many 32-set jobs sharing the matrix (the Ajtai product of a batch): two source jobs are multiplied as ONE 64-set job,
@@ -81,6 +143,7 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
   for (int l = 0; l < m->nlimbs; l++) {
     const int pl = m->planes[l];
     const size_t nt = nt_for(ns, pl);
+    if (keep_tiles) v8 = keep_tiles + (size_t)l * v8_stride * njobs;    // the caller wants the tiles of every limb afterwards
     if (prepacked) v8 = const_cast<int8_t*>(prepacked) + (size_t)l * v8_stride * njobs;   // digits_to_v8_impl made every limb's tiles
     else
       LAB_HIP(c, launch_pack_vectors_i8(ns, ns_valid, v8, V.base + (size_t)l * V.plane_stride, v_set_stride, v_k_stride, ktotal,
@@ -95,16 +158,11 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
     g.rgroups = (unsigned)((m->rt_count + tpb - 1) / tpb); g.njobs = (unsigned)njobs; g.rows = (unsigned)m->rows;
     g.ns = (unsigned)ns; g.ns_valid = (unsigned)ns_valid; g.nsub = (unsigned)nsub; g.p = primes[l];
     g.tab = (m->basis ? c->dg_tabs : c->d_tabs) + l;
-    g.pw[0] = 1 % primes[l];
-    for (int e = 1; e < 7; e++) g.pw[e] = (uint32_t)(((uint64_t)g.pw[e - 1] * 256) % primes[l]);
-    {
-      uint64_t sum = 0;
-      for (int i = 0; i < pl; i++) sum += g.pw[i];
-      sum %= primes[l];
-      g.bias = (uint32_t)((sum * sum % primes[l]) * ((1ull << 31) % primes[l]) % primes[l]);
-    }
+    recomb_consts(primes[l], pl, g.pw, &g.bias);
     g.stage = stage;
-    if (timed && c->gemm_diag) { g.diag = c->gemm_diag; g.diag_buf = c->gemm_diag_buf; g.diag_words = c->gemm_diag_words; }
+    if ((timed && c->gemm_diag >= 1 && c->gemm_diag <= 3) || (njobs > 1 && c->gemm_diag == 4)) {
+      g.diag = c->gemm_diag; g.diag_buf = c->gemm_diag_buf; g.diag_words = c->gemm_diag_words;
+    }
     const bool prof = timed && c->prof_on && pl >= 3;   // `timed`: the outer commitment (the measurement hook's kernel)
     if (prof && c->prof_used == c->prof_events.size()) {
       hipEvent_t a, b;
@@ -125,8 +183,8 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
                        (double)ns_valid * m->rows * D * 4;
     }
     if (gram && pl == 3 && !prepacked && ns >= 32 && gram->r <= 32 && (size_t)ns_valid == gram->r)   // one tile per plane
-      LAB_HIP(c, launch_gram_v8(v8, v8_stride, m->kt_count, (ktotal + 31) / 32, nt, paired ? 2 : 1, gram->r, njobs * (paired ? 2 : 1),
-                                gram->out + (size_t)l * gram->plane_stride, gram->job_stride, primes[l], g.pw, g.bias,
+      LAB_HIP(c, launch_gram_v8(nullptr, nullptr, v8, v8_stride, m->kt_count, (ktotal + 31) / 32, nt, paired ? 2 : 1, gram->r, njobs * (paired ? 2 : 1),
+                                gram->out + (size_t)l * gram->plane_stride, nullptr, gram->job_stride, primes[l], g.pw, g.bias,
                                 (m->basis ? c->dg_tabs : c->d_tabs) + l, c->stream));
     else if (gram) gram_ok = false;
     if (stage && coef)

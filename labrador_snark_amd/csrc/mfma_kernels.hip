@@ -159,19 +159,42 @@ k_pack_vectors_i8(int8_t* __restrict__ dst, const uint32_t* __restrict__ src, si
 // them to the block through LDS, 16 slots at a time; thread (slot, k block of 16, set) then gathers the 16 words of its
 // 16 k, picks each plane's byte with v_perm and stores 16 bytes per plane — the 8 sets of the block are 8 neighbouring
 // lanes of the B tile, i.e. one 128-byte line per (slot, plane, k block).
-constexpr int DV_ROW = 8 * D + 4;  // words per slot row of the exchange buffer: 8 sets x 64 k (+ padding, 16-byte aligned)
+template <int NSETS> constexpr int DV_ROW = NSETS * D + 4;  // words per slot row of the exchange buffer: NSETS sets x 64 k (+ padding, 16-byte aligned)
 
 struct PlaneCounts { int n[MAX_LIMBS]; unsigned nt[MAX_LIMBS]; };   // digit planes and column tiles per limb
 
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// MATRIX64: the sets are the columns of [ktotal][r] matrices of 64-bit coefficients below q < 2^40 (phi', W of steps 6-8), nsub
+// columns of proof job * (ns / nsub) + s / nsub per tile set (src.p[proof]; element (x, col) at (x*r + col)*64); every limb
+// prime below 2^29 (reduce_small16).  blockIdx.z = job, its tiles at + job * job_stride of every limb.
+// NSETS = 8 or 4 sets (waves) per block: with 4, two blocks share a CU and one loads while the other transforms.
+template <bool MATRIX64, int NSETS>
+__global__ void __launch_bounds__(64 * NSETS) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_digits_to_v8(const JobPtrs src, size_t ktotal, int8_t* __restrict__ dst, size_t limb_stride, unsigned kt_count, unsigned ns,
-               unsigned ns_valid, int nlimbs, const LimbTable* __restrict__ tabs, const PlaneCounts planes) {
-  __shared__ __attribute__((aligned(16))) uint32_t ex[16 * DV_ROW];   // [slot of the pass][set][k]: writes and reads conflict-free
+               unsigned ns_valid, int nlimbs, const LimbTable* __restrict__ tabs, const PlaneCounts planes, unsigned r, unsigned nsub,
+               size_t job_stride) {
+  constexpr int ROW = DV_ROW<NSETS>, SB = NSETS == 8 ? 3 : 2;          // log2(NSETS)
+  static_assert(NSETS == 8 || NSETS == 4, "8 or 4 sets per block");
+  __shared__ __attribute__((aligned(16))) uint32_t ex[16 * ROW];   // [slot of the pass][set][k]: writes and reads conflict-free
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const size_t k0 = (size_t)blockIdx.x * D;
-  const unsigned s_mine = blockIdx.y * 8 + w;
+  const unsigned s_mine = blockIdx.y * NSETS + w;
   uint32_t clo[D];
-  {
+  uint32_t chi[MATRIX64 ? D / 4 : 1];
+  if constexpr (MATRIX64) {
+    dst += (size_t)blockIdx.z * job_stride;
+    const unsigned proof = blockIdx.z * (ns / nsub) + s_mine / nsub, col = s_mine % nsub;
+    const bool have = col < ns_valid && k0 + lane < ktotal;
+    const uint64_t* p = have ? static_cast<const uint64_t*>(src.p[proof]) + ((k0 + lane) * r + col) * D : nullptr;
+#pragma unroll
+    for (int i = 0; i < D / 4; i++) chi[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      u32x4_t v = {0, 0, 0, 0};
+      if (have) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p) + i);
+      clo[2 * i] = v.x; clo[2 * i + 1] = v.z;
+      chi[i / 2] |= ((v.y & 0xFFu) << (8 * ((2 * i) & 3))) | ((v.w & 0xFFu) << (8 * ((2 * i + 1) & 3)));
+    }
+  } else {
     const bool have = s_mine < ns_valid && k0 + lane < ktotal;
     const uint16_t* p = have ? static_cast<const uint16_t*>(src.p[s_mine]) + (k0 + lane) * D : nullptr;
 #pragma unroll
@@ -183,13 +206,20 @@ k_digits_to_v8(const JobPtrs src, size_t ktotal, int8_t* __restrict__ dst, size_
     }
   }
   // gather role: set (fastest: neighbouring lanes of the B tile), k block, slot inside the pass
-  const unsigned g_set = t & 7, g_kb = (t >> 3) & 3, g_jl = t >> 5;
-  const unsigned g_s = blockIdx.y * 8 + g_set;
+  const unsigned g_set = t & (NSETS - 1), g_kb = (t >> SB) & 3, g_jl = t >> (SB + 2);
+  const unsigned g_s = blockIdx.y * NSETS + g_set;
 #pragma unroll 1
   for (int l = 0; l < nlimbs; l++) {
     uint32_t x[D];
+    if constexpr (MATRIX64) {
+      const LimbTable* tab = tabs + l;
+      const uint32_t p = tab->p, m = (uint32_t)(4294967296.0 * tab->inv_p) - 1, r1 = tab->r1;
 #pragma unroll
-    for (int k = 0; k < D; k++) x[k] = clo[k];
+      for (int k = 0; k < D; k++) x[k] = reduce_small16((chi[k / 4] >> (8 * (k & 3))) & 0xFFu, clo[k], p, m, r1);
+    } else {
+#pragma unroll
+      for (int k = 0; k < D; k++) x[k] = clo[k];
+    }
     ntt64_forward(x, tabs + l);
     const int pl = planes.n[l];
     const uint32_t offs = digit_offsets(pl);
@@ -198,12 +228,12 @@ k_digits_to_v8(const JobPtrs src, size_t ktotal, int8_t* __restrict__ dst, size_
 #pragma unroll
     for (int q = 0; q < 4; q++) {
 #pragma unroll
-      for (int c = 0; c < 16; c++) ex[c * DV_ROW + w * D + lane] = signed_digit_word(x[16 * q + c], offs);
+      for (int c = 0; c < 16; c++) ex[c * ROW + w * D + lane] = signed_digit_word(x[16 * q + c], offs);
       __syncthreads();
       uint32_t wd[16];
 #pragma unroll
       for (int b = 0; b < 4; b++) {
-        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&ex[g_jl * DV_ROW + g_set * D + g_kb * 16 + 4 * b]);
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&ex[g_jl * ROW + g_set * D + g_kb * 16 + 4 * b]);
         wd[4 * b] = v.x; wd[4 * b + 1] = v.y; wd[4 * b + 2] = v.z; wd[4 * b + 3] = v.w;
       }
       const unsigned j = 16 * q + g_jl;
@@ -234,75 +264,121 @@ hipError_t launch_digits_to_v8(const JobPtrs& src16, size_t ktotal, int8_t* dst,
   if (ns % 8 || ns > 64 || nlimbs > MAX_LIMBS) return hipErrorInvalidValue;
   PlaneCounts pc;
   for (int l = 0; l < MAX_LIMBS; l++) { pc.n[l] = l < nlimbs ? planes[l] : 0; pc.nt[l] = l < nlimbs ? (unsigned)nt[l] : 0; }
-  hipLaunchKernelGGL(k_digits_to_v8, dim3((unsigned)((ktotal + D - 1) / D), (unsigned)(ns / 8)), dim3(512), 0, s, src16, ktotal, dst,
-                     limb_stride, (unsigned)kt_count, (unsigned)ns, (unsigned)ns_valid, nlimbs, tabs, pc);
+  hipLaunchKernelGGL((k_digits_to_v8<false, 8>), dim3((unsigned)((ktotal + D - 1) / D), (unsigned)(ns / 8)), dim3(512), 0, s, src16, ktotal, dst,
+                     limb_stride, (unsigned)kt_count, (unsigned)ns, (unsigned)ns_valid, nlimbs, tabs, pc, 0u, 1u, (size_t)0);
   return hipGetLastError();
 }
 
-// ---- G = S^T S of one proof from the B-operand tiles its witness columns were packed into for step 1 (3-plane limbs).
+// the columns of [n][r] coefficient matrices (one per proof, 64-bit words below q < 2^40) -> reduce -> transform -> B-operand
+// tiles of every limb: `ns` (32 or 64) sets per job = ns / 32 proofs x 32 columns (r <= 32 of them valid)
+hipError_t launch_coefs_to_v8(const JobPtrs& src64, size_t n, size_t r, int8_t* dst, size_t limb_stride, size_t job_stride, size_t kt_count,
+                              int ns, size_t njobs, int nlimbs, const LimbTable* tabs, const int* planes, const size_t* nt, hipStream_t s) {
+  if ((ns != 32 && ns != 64) || r > 32 || nlimbs > MAX_LIMBS || njobs * (ns / 32) > MAX_JOBS || njobs > 65535) return hipErrorInvalidValue;
+  PlaneCounts pc;
+  for (int l = 0; l < MAX_LIMBS; l++) { pc.n[l] = l < nlimbs ? planes[l] : 0; pc.nt[l] = l < nlimbs ? (unsigned)nt[l] : 0; }
+  hipLaunchKernelGGL((k_digits_to_v8<true, 4>), dim3((unsigned)((n + D - 1) / D), (unsigned)(ns / 4), (unsigned)njobs), dim3(256), 0, s, src64, n, dst,
+                     limb_stride, (unsigned)kt_count, (unsigned)ns, (unsigned)r, nlimbs, tabs, pc, (unsigned)r, 32u, job_stride);
+  return hipGetLastError();
+}
+
+// ---- X = P^T S of one proof (G = S^T S when P is S) from B-operand tiles: the witness columns packed for step 1, and
+// the columns of phi' / W packed the same way (3-plane limbs).
 // A B-operand tile (lane l: column l & 31, 16 consecutive k of half l >> 5) is byte for byte an A-operand tile with the
-// columns as rows, so the tiles of plane i and plane i' multiply directly: D[i][i'][col][col'] = sum_x S_i[x][col] S_i'[x][col'].
-// One wave per (proof, NTT slot): 3 tiles per k tile, 9 MFMAs, all nine int32 tiles of the wave have the same element
-// in the same register of the same lane, so the recombination needs no LDS.  Blocks of one proof share an XCD (the 64
-// slots of a result line are written by 64 blocks).
+// columns as rows, so the tiles of plane i of P and plane i' of S multiply directly:
+// D[i][i'][col][col'] = sum_x P_i[x][col] S_i'[x][col'].
+// One wave per (proof, NTT slot): 3 (6) tiles per k tile, 9 MFMAs, two k tiles in flight behind the one being multiplied;
+// all nine int32 tiles of the wave have the same element in the same register of the same lane, so the recombination
+// needs no LDS.  Blocks of one proof share an XCD (the 64 slots of a result line are written by 64 blocks).
+// NP = 2: two P operands against the same S tiles in one pass (phi'^T S and W^T S: the S tiles are read once).
+template <bool SAME, int NP>
 __global__ void __launch_bounds__(64)
-k_gram_v8(const int8_t* __restrict__ V8, size_t v8_job_stride, unsigned kt_count, unsigned kt_real, unsigned nt_count, unsigned sub,
-          unsigned r, uint32_t* __restrict__ out, size_t out_job_stride, uint32_t p, uint32_t pw0, uint32_t pw1, uint32_t pw2,
-          uint32_t pw3, uint32_t pw4, uint32_t bias, const LimbTable* __restrict__ tab) {
+k_gram_v8(const int8_t* __restrict__ P8a, const int8_t* __restrict__ P8b, const int8_t* __restrict__ S8, size_t v8_job_stride,
+          unsigned kt_count, unsigned kt_real, unsigned nt_count, unsigned sub, unsigned r, uint32_t* __restrict__ outa,
+          uint32_t* __restrict__ outb, size_t out_job_stride, uint32_t p, uint32_t pw0, uint32_t pw1, uint32_t pw2, uint32_t pw3,
+          uint32_t pw4, uint32_t bias, const LimbTable* __restrict__ tab) {
+  static_assert(!SAME || NP == 1, "G = S^T S has one operand");
   const unsigned job = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
   const unsigned g = job / sub, sb = job % sub;
-  const u32x4_t* base = reinterpret_cast<const u32x4_t*>(V8 + (size_t)g * v8_job_stride) + (size_t)j * kt_count * nt_count * 64 + lane;
-  i32x16_t acc[3][3];
+  const size_t off = (size_t)g * v8_job_stride / 16 + (size_t)j * kt_count * nt_count * 64 + lane;
+  const u32x4_t* sbase = reinterpret_cast<const u32x4_t*>(S8) + off;
+  const u32x4_t* pbase[2] = {reinterpret_cast<const u32x4_t*>(P8a) + off, reinterpret_cast<const u32x4_t*>(NP > 1 ? P8b : P8a) + off};
+  i32x16_t acc[NP][3][3];
 #pragma unroll
-  for (int a = 0; a < 3; a++)
-#pragma unroll
-    for (int b = 0; b < 3; b++)
-#pragma unroll
-      for (int e = 0; e < 16; e++) acc[a][b][e] = 0;
-  auto load = [&](unsigned kt, u32x4_t (&t)[3]) {
-#pragma unroll
-    for (int pl = 0; pl < 3; pl++) t[pl] = base[((size_t)kt * nt_count + pl * sub + sb) * 64];
-  };
-  u32x4_t cur[3], nxt[3];
-  load(0, cur);
-  for (unsigned kt = 0; kt < kt_real; kt++) {
-    if (kt + 1 < kt_real) load(kt + 1, nxt);
+  for (int o = 0; o < NP; o++)
 #pragma unroll
     for (int a = 0; a < 3; a++)
 #pragma unroll
-      for (int b = 0; b < 3; b++) {
-        const i32x4_t af = {(int)cur[a].x, (int)cur[a].y, (int)cur[a].z, (int)cur[a].w};
-        const i32x4_t bf = {(int)cur[b].x, (int)cur[b].y, (int)cur[b].z, (int)cur[b].w};
-        acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[a][b], 0, 0, 0);
-      }
+      for (int b = 0; b < 3; b++)
 #pragma unroll
-    for (int pl = 0; pl < 3; pl++) cur[pl] = nxt[pl];
+        for (int e = 0; e < 16; e++) acc[o][a][b][e] = 0;
+  u32x4_t st[3][3], pt[SAME ? 1 : 3][NP][3];       // [ring slot]([operand])[plane]
+  auto load = [&](unsigned kt, int slot) {
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) {
+      const size_t o = ((size_t)kt * nt_count + pl * sub + sb) * 64;
+      st[slot][pl] = sbase[o];
+      if constexpr (!SAME) {
+#pragma unroll
+        for (int op = 0; op < NP; op++) pt[slot][op][pl] = pbase[op][o];
+      }
+    }
+  };
+  load(0, 0);
+  if (kt_real > 1) load(1, 1);
+  for (unsigned kt = 0; kt < kt_real; kt += 3) {
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+      if (kt + u < kt_real) {
+        if (kt + u + 2 < kt_real) load(kt + u + 2, (u + 2) % 3);
+#pragma unroll
+        for (int op = 0; op < NP; op++)
+#pragma unroll
+          for (int a = 0; a < 3; a++) {
+            const u32x4_t av = SAME ? st[u][a] : pt[SAME ? 0 : u][op][a];
+            const i32x4_t af = {(int)av.x, (int)av.y, (int)av.z, (int)av.w};
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+              const i32x4_t bf = {(int)st[u][b].x, (int)st[u][b].y, (int)st[u][b].z, (int)st[u][b].w};
+              acc[op][a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[op][a][b], 0, 0, 0);
+            }
+          }
+      }
+    }
   }
   const uint32_t pw[5] = {pw0, pw1, pw2, pw3, pw4};
   const uint32_t p2 = tab->p2, pinv = tab->pinv, r2 = tab->r2;
-  uint32_t* o = out + (size_t)job * out_job_stride + j;
   const unsigned col = lane & 31;
 #pragma unroll
-  for (int e = 0; e < 16; e++) {
-    const unsigned row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-    uint64_t s64 = 0;                               // 9 products < 2^32 * p: the high word stays below 9p < 2^27
+  for (int op = 0; op < NP; op++) {
+    uint32_t* o = (op ? outb : outa) + (size_t)job * out_job_stride + j;
 #pragma unroll
-    for (int a = 0; a < 3; a++)
+    for (int e = 0; e < 16; e++) {
+      const unsigned row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      uint64_t s64 = 0;                               // 9 products < 2^32 * p: the high word stays below 9p < 2^27
 #pragma unroll
-      for (int b = 0; b < 3; b++) s64 += (uint64_t)((uint32_t)acc[a][b][e] ^ 0x80000000u) * pw[a + b];
-    uint32_t hi = (uint32_t)(s64 >> 32);
-    hi = min(hi, hi - 8 * p); hi = min(hi, hi - 4 * p); hi = min(hi, hi - p2); hi = min(hi, hi - p);
-    const uint32_t v = mont_mul(redc64(((uint64_t)hi << 32) | (uint32_t)s64, p, pinv), r2, p, pinv);
-    if (row < r && col < r) o[((size_t)row * r + col) * D] = csub(v + p - bias, p);
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) s64 += (uint64_t)((uint32_t)acc[op][a][b][e] ^ 0x80000000u) * pw[a + b];
+      uint32_t hi = (uint32_t)(s64 >> 32);
+      hi = min(hi, hi - 8 * p); hi = min(hi, hi - 4 * p); hi = min(hi, hi - p2); hi = min(hi, hi - p);
+      const uint32_t v = mont_mul(redc64(((uint64_t)hi << 32) | (uint32_t)s64, p, pinv), r2, p, pinv);
+      if (row < r && col < r) o[((size_t)row * r + col) * D] = csub(v + p - bias, p);   // row: column of P, col: column of S
+    }
   }
 }
 
-hipError_t launch_gram_v8(const int8_t* V8, size_t v8_job_stride, size_t kt_count, size_t kt_real, size_t nt_count, size_t sub, size_t r,
-                          size_t njobs, uint32_t* out_plane, size_t out_job_stride, uint32_t p, const uint32_t* pw, uint32_t bias,
-                          const LimbTable* tab, hipStream_t s) {
-  if (r > 32 || njobs == 0 || p >= (1u << 23)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_gram_v8, dim3((unsigned)njobs, D), dim3(64), 0, s, V8, v8_job_stride, (unsigned)kt_count, (unsigned)kt_real,
-                     (unsigned)nt_count, (unsigned)sub, (unsigned)r, out_plane, out_job_stride, p, pw[0], pw[1], pw[2], pw[3], pw[4], bias, tab);
+// P8a null (or S8): G = S^T S.  P8b non-null: a second operand, result to out_b.
+hipError_t launch_gram_v8(const int8_t* P8a, const int8_t* P8b, const int8_t* S8, size_t v8_job_stride, size_t kt_count, size_t kt_real,
+                          size_t nt_count, size_t sub, size_t r, size_t njobs, uint32_t* out_a, uint32_t* out_b, size_t out_job_stride,
+                          uint32_t p, const uint32_t* pw, uint32_t bias, const LimbTable* tab, hipStream_t s) {
+  if (r > 32 || njobs == 0 || p >= (1u << 23) || (v8_job_stride % 16)) return hipErrorInvalidValue;
+  const dim3 g((unsigned)njobs, D);
+#define LAB_GRAM_ARGS v8_job_stride, (unsigned)kt_count, (unsigned)kt_real, (unsigned)nt_count, (unsigned)sub, (unsigned)r, out_a, out_b, \
+                      out_job_stride, p, pw[0], pw[1], pw[2], pw[3], pw[4], bias, tab
+  if (!P8a || P8a == S8) hipLaunchKernelGGL((k_gram_v8<true, 1>), g, dim3(64), 0, s, S8, S8, S8, LAB_GRAM_ARGS);
+  else if (!P8b) hipLaunchKernelGGL((k_gram_v8<false, 1>), g, dim3(64), 0, s, P8a, P8a, S8, LAB_GRAM_ARGS);
+  else hipLaunchKernelGGL((k_gram_v8<false, 2>), g, dim3(64), 0, s, P8a, P8b, S8, LAB_GRAM_ARGS);
+#undef LAB_GRAM_ARGS
   return hipGetLastError();
 }
 
@@ -746,7 +822,7 @@ hipError_t launch_gemm_i8(const Gemm8Args& a, size_t nt, int waves, hipStream_t 
   if (waves == 6) hipLaunchKernelGGL((k_gemm_i8<NTV, 6>), g, dim3(384), 0, s, a);                     \
   else hipLaunchKernelGGL((k_gemm_i8<NTV, 3>), g, dim3(192), 0, s, a)
   if (a.planes == 3 && waves == 4) {                // 3-plane limbs, one row tile (all three planes) per wave
-    if (nt == 6 && a.diag == 1 && a.njobs == 1) hipLaunchKernelGGL((k_gemm_i8_w3<6, 1>), g, dim3(256), 0, s, a);
+    if (nt == 6 && ((a.diag == 1 && a.njobs == 1) || (a.diag == 4 && a.njobs > 1))) hipLaunchKernelGGL((k_gemm_i8_w3<6, 1>), g, dim3(256), 0, s, a);
     else if (nt == 6 && a.diag == 2 && a.njobs == 1) hipLaunchKernelGGL((k_gemm_i8_w3<6, 2>), g, dim3(256), 0, s, a);
     else if (nt == 6 && a.diag == 3 && a.njobs == 1) hipLaunchKernelGGL((k_gemm_i8_w3<6, 3>), g, dim3(256), 0, s, a);
     else if (nt == 6) hipLaunchKernelGGL((k_gemm_i8_w3<6>), g, dim3(256), 0, s, a);

@@ -119,15 +119,6 @@ k_reduce_u64(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, size_
   }
 }
 
-// v < 2^40 mod a prime p < 2^23 (the limbs of a digit basis that are not main-basis primes): Barrett with m ~ 2^32 / p,
-// all in 32 bits.  umulhi(x, m) underestimates floor(x / p) by at most 2, so the remainder is below 3p < 2^25.
-__device__ __forceinline__ uint32_t reduce_small16(uint32_t hi8, uint32_t lo, uint32_t p, uint32_t m, uint32_t r1) {
-  uint32_t b = lo - __umulhi(lo, m) * p;          // lo mod p, in [0, 3p)
-  uint32_t s = hi8 * r1 + b;                       // hi * (2^32 mod p) + ...: < 2^8 * 2^23 + 2^25 < 2^32
-  s -= __umulhi(s, m) * p;
-  return csub(csub(s, 2 * p), p);
-}
-
 // ---- to_hat in one pass: coefficients (u64 mod q) -> residues -> forward NTT, for every limb, without the
 // intermediate residue planes (k_reduce_u64 + k_ntt64 move 44 bytes per coefficient, this kernel 8 + 4 per limb).
 // One wave per block, one polynomial per thread: the wave's 64 polynomials (32 KiB of u64) come in two halves of 32

@@ -171,8 +171,10 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
                       (uint64_t)in->b1 <= (b8 ? mat8_min_prime(c, b8) : basis_min_prime(c, bdig));
   // ---------------- workspace plan: one arena per basis, proof j owns elements [j*per, (j+1)*per) of every plane
   const int L = c->nlimbs;
+  const bool sd_only = a8d && gram_mfma_ok(a8d, n, r);   // every product with the witness in the basis of B, C, D (see hPd below)
   HatArena ha;
-  const size_t hS = ha.take(nr), hphi = ha.take(nr), hT = ha.take(rk), hG = ha.take(rr), hphipp = ha.take(nr),
+  const size_t hS = ha.take(sd_only ? 1 : nr), hphi = ha.take(sd_only ? 1 : nr), hT = ha.take(rk), hG = ha.take(rr),
+               hphipp = ha.take(sd_only ? 1 : nr),
                happ = ha.take(rr), hGc = ha.take(rr), hbpp = ha.take(2), hX1 = ha.take(rr), hX2 = ha.take(rr),
                hX = ha.take(rr), hc = ha.take(r), hz = ha.take(n), hab = ha.take(2);
   size_t part_elems = 512;  // inner_product_impl splits a long inner product into <= 512 partials
@@ -189,6 +191,11 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   const size_t hpartd = hd.take(partd_elems);
   const size_t hSd = a8d ? hd.take(nr) : 0, hTd = a8d ? hd.take(rk) : 0;   // witness and t = A s in the digit basis
   const size_t hGd = a8d ? hd.take(rr) : 0;                                 // G = S^T S from the same packed operands
+  // Under the same norm bound every other product with the witness is exact in that basis too (|<x, s>| <= |x|_2 |s|_2 for any
+  // x with entries below q): phi'^T S, W^T S (steps 6-8) on the matrix cores from packed tiles, z = sum_i c_i s_i (step 10)
+  // from the digit-basis witness — the main-basis transforms of S, phi' and W are then never made.
+  const size_t hX1d = sd_only ? hd.take(rr) : 0, hXWd = sd_only ? hd.take(rr) : 0, hzd = sd_only ? hd.take(n) : 0,
+               hcd = sd_only ? hd.take(r) : 0;
   const int Ld = basis_nlimbs(c, bdig);
   const LimbTable* tabsd = basis_tabs(c, bdig);
   const size_t per = ha.total, perd = hd.total;
@@ -221,12 +228,16 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   const int a8_ns = r <= 8 ? 8 : r <= 16 ? 16 : 32;       // witness columns per Ajtai GEMM pass
   if (a8 && mfma_scratch_bytes(a8, a8_ns, np) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(a8, a8_ns, np) + 4096;
   if (a8d && mfma_scratch_bytes(a8d, a8_ns, np) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(a8d, a8_ns, np) + 4096;
+  if (sd_only && gram_mfma_scratch_bytes(a8d, np) + 4096 > mf_bytes) mf_bytes = gram_mfma_scratch_bytes(a8d, np) + 4096;
+  const size_t stile_bytes = sd_only ? gram_mfma_tile_bytes(a8d, np) + 4096 : 0;   // the witness tiles of every limb, kept from step 1 to step 7
+  bytes += stile_bytes;
   if (c8 && mfma_scratch_bytes(c8, mf_ns, 1) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(c8, mf_ns, 1) + 4096;
   if (d8 && mfma_scratch_bytes(d8, mf_ns, 1) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(d8, mf_ns, 1) + 4096;
   bytes += mf_bytes;
   if ((rc = ensure_scratch(c, bytes + (1 << 16)))) return rc;
   Carver cv(c->scratch);
   char* mf_scratch = mf_bytes ? cv.take<char>(mf_bytes) : nullptr;
+  int8_t* s_tiles = stile_bytes ? cv.take<int8_t>(stile_bytes) : nullptr;
   uint32_t* hat_base = cv.take<uint32_t>((size_t)L * hat_words);
   uint32_t* hatd_base = cv.take<uint32_t>((size_t)Ld * hatd_words);
   // from_hat scratch: a dense [L][count][64] buffer (its plane stride is count*64, not the arena's)
@@ -315,8 +326,10 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   };
 
   // ================= phase A: transforms
-  if ((rc = to_hat_jobs(JP(&Job::dS), hS, nr, false))) return rc;
-  if ((rc = to_hat_jobs(JP(&Job::dphi), hphi, nr, false))) return rc;
+  if (!sd_only) {
+    if ((rc = to_hat_jobs(JP(&Job::dS), hS, nr, false))) return rc;
+    if ((rc = to_hat_jobs(JP(&Job::dphi), hphi, nr, false))) return rc;
+  }
   if ((rc = to_hat_jobs(JP(&Job::dalpha), hab, 1, false))) return rc;
   if ((rc = to_hat_jobs(JP(&Job::dbeta), hab + 1, 1, false))) return rc;
   if ((rc = to_hat_jobs(JP(&Job::dc), hc, r, false))) return rc;
@@ -334,7 +347,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
       MfmaCoefOut co{dense_tmp + i0 * kappa * D, rk * D, tmp_js, kappa, false};   // t is only wanted as coefficients
       MfmaGramOut go{HD(0, hGd).base, hatd_words, perd * D, r, false};            // step 2 (G = S^T S) from the same tiles
       if ((rc = matvec_mfma_impl(c, HD(0, hTd + i0 * kappa), kappa * D, a8d, HD(0, hSd + i0), D, a8_ns, valid, mf_scratch, r * D, np,
-                                 perd * D, perd * D, false, &co, nullptr, r <= 32 ? &go : nullptr))) return rc;
+                                 perd * D, perd * D, false, &co, nullptr, r <= 32 ? &go : nullptr, s_tiles))) return rc;
       t_in_dense = co.done;
       g_in_digit = go.done;
     }
@@ -364,6 +377,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     return rc;
   }
   // step 2 (:59-70): G = S^T S
+  if (sd_only && !g_in_digit) return fail(c, LAB_ERR_ARG, "lab_prove_core: internal: the digit-basis Gram product was not taken");
   if (g_in_digit) {
     if ((rc = from_hat_jobs(hGd, rr, JP(&Job::cG), true))) return rc;
   } else {
@@ -486,14 +500,22 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     LAB_HIP(c, launch_coef_elementwise_jobs(JP(&Job::capp), JP(&Job::da), none, rr, q, psi, 0, np, s));   // a'' = psi a'
   }
   if ((rc = to_hat_jobs(JP(&Job::capp), happ, rr, false))) return rc;
-  if ((rc = to_hat_jobs(JP(&Job::cW), hphipp, nr, false))) return rc;          // W in the transform domain
+  if (!sd_only && (rc = to_hat_jobs(JP(&Job::cW), hphipp, nr, false))) return rc;   // W in the transform domain
   if ((rc = to_hat_jobs(JP(&Job::cG), hGc, rr, false))) return rc;
   if ((rc = inner_product_jobs(hbpp, happ, hGc, rr))) return rc;               // sum a''_ij g_ij
   if ((rc = from_hat_jobs(hbpp, 1, JP(&Job::cab), false))) return rc;
-  if ((rc = gram_jobs(hX1, hphi, hS))) return rc;
-  if ((rc = gram_jobs(hX2, hphipp, hS))) return rc;
-  if ((rc = from_hat_jobs(hX1, rr, JP(&Job::cX1), false))) return rc;
-  if ((rc = from_hat_jobs(hX2, rr, JP(&Job::cX), false))) return rc;           // XW
+  if (sd_only) {   // both Gram products on the matrix cores, in the basis of the witness tiles
+    const HatView xo[2] = {HD(0, hX1d), HD(0, hXWd)};
+    const JobPtrs xp[2] = {JP(&Job::dphi), JP(&Job::cW)};
+    if ((rc = gram_mfma_impl(c, a8d, 2, xo, xp, s_tiles, jsd, n, r, np, mf_scratch))) return rc;
+    if ((rc = from_hat_jobs(hX1d, rr, JP(&Job::cX1), true))) return rc;
+    if ((rc = from_hat_jobs(hXWd, rr, JP(&Job::cX), true))) return rc;        // XW
+  } else {
+    if ((rc = gram_jobs(hX1, hphi, hS))) return rc;
+    if ((rc = gram_jobs(hX2, hphipp, hS))) return rc;
+    if ((rc = from_hat_jobs(hX1, rr, JP(&Job::cX1), false))) return rc;
+    if ((rc = from_hat_jobs(hX2, rr, JP(&Job::cX), false))) return rc;           // XW
+  }
   LAB_HIP(c, launch_coef_elementwise_jobs(JP(&Job::cX2), JP(&Job::cX1), JP(&Job::cX), rr, q, psi, 1, np, s));   // X2 = psi X1 + XW
   LAB_HIP(c, launch_add_trace_jobs(JP(&Job::cbpp), JP(&Job::cab), JP(&Job::cX2), r, q, np, s));                  // b''
   if ((rc = to_hat_jobs(JP(&Job::cX1), hX1, rr, false))) return rc;
@@ -513,8 +535,14 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if ((rc = from_hat_jobs(hu2, k2, JP(&Job::cu2), true))) return rc;
 
   // ================= step 10 (:380-399): z = sum_i c_i s_i
-  LAB_HIP(c, launch_matvec_partial(HV(0, hz), HV(0, hS), HV(0, hc), 1, n, r, L, tabs, s, np, js));
-  if ((rc = from_hat_jobs(hz, n, JP(&Job::cz), false))) return rc;
+  if (sd_only) {
+    if ((rc = to_hat_jobs(JP(&Job::dc), hcd, r, true))) return rc;
+    LAB_HIP(c, launch_matvec_partial(HD(0, hzd), HD(0, hSd), HD(0, hcd), 1, n, r, Ld, tabsd, s, np, jsd));
+    if ((rc = from_hat_jobs(hzd, n, JP(&Job::cz), true))) return rc;
+  } else {
+    LAB_HIP(c, launch_matvec_partial(HV(0, hz), HV(0, hS), HV(0, hc), 1, n, r, L, tabs, s, np, js));
+    if ((rc = from_hat_jobs(hz, n, JP(&Job::cz), false))) return rc;
+  }
 
   // ================= copy-out and the two verifier callbacks that can reject
   std::vector<uint64_t> hst(np * (256 + 256 + D + 1));
