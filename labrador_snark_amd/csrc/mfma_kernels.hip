@@ -174,7 +174,9 @@ k_digits_to_v8(const JobPtrs src, size_t ktotal, int8_t* __restrict__ dst, size_
                size_t job_stride) {
   constexpr int ROW = DV_ROW<NSETS>, SB = NSETS == 8 ? 3 : 2;          // log2(NSETS)
   static_assert(NSETS == 8 || NSETS == 4, "8 or 4 sets per block");
-  __shared__ __attribute__((aligned(16))) uint32_t ex[16 * ROW];   // [slot of the pass][set][k]: writes and reads conflict-free
+  // [slot of the pass][set][k]: writes and reads conflict-free; MATRIX64: first the load tile [set][x][16 coefficients], pitch 36 words
+  constexpr int LDSW = MATRIX64 && 64 * NSETS * 36 > 16 * ROW ? 64 * NSETS * 36 : 16 * ROW;
+  __shared__ __attribute__((aligned(16))) uint32_t ex[LDSW];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const size_t k0 = (size_t)blockIdx.x * D;
   const unsigned s_mine = blockIdx.y * NSETS + w;
@@ -183,16 +185,45 @@ k_digits_to_v8(const JobPtrs src, size_t ktotal, int8_t* __restrict__ dst, size_
   if constexpr (MATRIX64) {
     dst += (size_t)blockIdx.z * job_stride;
     const unsigned proof = blockIdx.z * (ns / nsub) + s_mine / nsub, col = s_mine % nsub;
-    const bool have = col < ns_valid && k0 + lane < ktotal;
-    const uint64_t* p = have ? static_cast<const uint64_t*>(src.p[proof]) + ((k0 + lane) * r + col) * D : nullptr;
+    // the block's 64 x NSETS polynomials: for every x the NSETS columns are contiguous (NSETS * 512 B).  Four passes of 16
+    // coefficients: piece id = it * threads + t -> polynomial id >> 3 (x = poly / NSETS, column poly % NSETS), 16-byte piece
+    // id & 7 — eight lanes fetch one full 128-byte line — parked at row column * 64 + x of the tile, read back by the
+    // thread that owns the polynomial (wave = column, lane = x).
+    const unsigned col0 = col - w;                                    // first column of the block
+    const uint64_t* mat = static_cast<const uint64_t*>(src.p[proof]);
+    auto fetch = [&](int q, u32x4_t (&v)[8]) {
+#pragma unroll
+      for (int it = 0; it < 8; it++) {
+        const unsigned id = it * (64 * NSETS) + t, poly = id >> 3, piece = id & 7, x = poly / NSETS, c = poly % NSETS;
+        const u32x4_t z = {0, 0, 0, 0};
+        v[it] = (col0 + c < ns_valid && k0 + x < ktotal)
+                    ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(mat + ((k0 + x) * r + col0 + c) * D + q * 16) + piece)
+                    : z;
+      }
+    };
 #pragma unroll
     for (int i = 0; i < D / 4; i++) chi[i] = 0;
+    u32x4_t cur[8], nxt[8];
+    fetch(0, cur);
 #pragma unroll
-    for (int i = 0; i < 32; i++) {
-      u32x4_t v = {0, 0, 0, 0};
-      if (have) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p) + i);
-      clo[2 * i] = v.x; clo[2 * i + 1] = v.z;
-      chi[i / 2] |= ((v.y & 0xFFu) << (8 * ((2 * i) & 3))) | ((v.w & 0xFFu) << (8 * ((2 * i + 1) & 3)));
+    for (int q = 0; q < 4; q++) {
+      if (q < 3) fetch(q + 1, nxt);
+#pragma unroll
+      for (int it = 0; it < 8; it++) {
+        const unsigned id = it * (64 * NSETS) + t, poly = id >> 3, piece = id & 7, x = poly / NSETS, c = poly % NSETS;
+        *reinterpret_cast<u32x4_t*>(&ex[(c * 64 + x) * 36 + piece * 4]) = cur[it];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int piece = 0; piece < 8; piece++) {
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&ex[(w * 64 + lane) * 36 + piece * 4]);
+        const int k = q * 16 + piece * 2;
+        clo[k] = v.x; clo[k + 1] = v.z;
+        chi[k / 4] |= ((v.y & 0xFFu) << (8 * (k & 3))) | ((v.w & 0xFFu) << (8 * ((k + 1) & 3)));
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 8; it++) cur[it] = nxt[it];
     }
   } else {
     const bool have = s_mine < ns_valid && k0 + lane < ktotal;
