@@ -88,6 +88,11 @@ typedef struct {
  * `max_len` = longest reduction (inner-product length) the caller will ask
  * for; it fixes the number of RNS limbs.  Pass 0 for the default (65536). */
 int lab_ctx_create(uint64_t q, int device, uint64_t max_len, lab_ctx **out);
+/* flags: LAB_CTX_RNS_ONLY — never use q as its own NTT prime (the generic exact path even for an NTT-friendly q), e.g. to
+ * time both paths of SURVEY section 7 at one modulus.  lab_ctx_create == flags 0: a prime q == 1 (mod 128) below 2^32 runs
+ * single-limb (4 bytes per coefficient, no CRT; strict 32-bit arithmetic when q >= 2^30), every other q on RNS limbs. */
+#define LAB_CTX_RNS_ONLY 1
+int lab_ctx_create_ex(uint64_t q, int device, uint64_t max_len, int flags, lab_ctx **out);
 void lab_ctx_destroy(lab_ctx *ctx);
 int lab_ctx_info(const lab_ctx *ctx, lab_info *out);
 const char *lab_last_error(const lab_ctx *ctx);

@@ -73,6 +73,7 @@ class lab_info(C.Structure):
 # name -> (restype, argtypes); also the list the "exports every symbol" test walks
 SIGNATURES = {
     "lab_ctx_create": (C.c_int, [C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "lab_ctx_create_ex": (C.c_int, [C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]),
     "lab_ctx_destroy": (None, [C.c_void_p]),
     "lab_ctx_info": (C.c_int, [C.c_void_p, C.POINTER(lab_info)]),
     "lab_last_error": (C.c_char_p, [C.c_void_p]),

@@ -51,10 +51,11 @@ def _nelems(a):
 class Context:
     """One modulus q on one GPU.  `max_len` bounds inner-product lengths (it fixes the RNS limb count)."""
 
-    def __init__(self, q, device=0, max_len=0):
+    def __init__(self, q, device=0, max_len=0, rns_only=False):
+        """rns_only: never run single-limb on q itself (lab_ctx_create_ex, LAB_CTX_RNS_ONLY)."""
         self._lib = _lib.load()
         h = C.c_void_p()
-        rc = self._lib.lab_ctx_create(int(q), int(device), int(max_len), C.byref(h))
+        rc = self._lib.lab_ctx_create_ex(int(q), int(device), int(max_len), 1 if rns_only else 0, C.byref(h))
         _lib.check(None, rc)
         self._h = h
         info = _lib.lab_info()

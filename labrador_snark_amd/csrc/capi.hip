@@ -112,10 +112,12 @@ static uint32_t shoup(uint32_t w, uint32_t p) { return (uint32_t)(((uint64_t)w <
 // NTT-friendly primes below 2^30 (p == 1 mod 128), largest first.
 static const uint32_t kLimbPrimes[MAX_LIMBS] = {1073741441u, 1073739649u, 1073738753u, 1073736449u};
 
-static bool build_limb_table(uint32_t p, LimbTable* t) {
+// wide: 2^30 <= p < 2^32 (the single-limb strict-32 path, zq_device.h Zp<true>): constants of the transforms in Montgomery form
+static bool build_limb_table(uint32_t p, LimbTable* t, bool wide = false) {
   memset(t, 0, sizeof *t);
   t->p = p;
-  t->p2 = 2 * p;
+  t->p2 = wide ? 0u : 2 * p;
+  t->wide = wide ? 1u : 0u;
   // p^-1 mod 2^32 by Newton iteration
   uint32_t inv = p;
   for (int i = 0; i < 5; i++) inv *= 2u - p * inv;
@@ -135,10 +137,15 @@ static bool build_limb_table(uint32_t p, LimbTable* t) {
   uint64_t psi_inv = invmod_prime(psi, p);
   for (uint32_t k = 0; k < (uint32_t)D; k++) {
     uint32_t w = (uint32_t)powmod(psi, brv6(k), p), wi = (uint32_t)powmod(psi_inv, brv6(k), p);
+    if (wide) { w = (uint32_t)(((u128)w << 32) % p); wi = (uint32_t)(((u128)wi << 32) % p); }
     t->fwd[k][0] = w;  t->fwd[k][1] = shoup(w, p);
     t->inv[k][0] = wi; t->inv[k][1] = shoup(wi, p);
   }
   uint64_t ninv = invmod_prime(D, p);
+  if (wide) {   // n^-1 * 2^32 mod p; the R^e variants of the lazy path do not exist here
+    t->scale_lo[0][0] = (uint32_t)(((u128)ninv << 32) % p);
+    return true;
+  }
   uint64_t re = 1;
   for (int e = 0; e < 4; e++) {
     uint32_t lo = (uint32_t)((u128)ninv * re % p);
@@ -177,6 +184,10 @@ static void build_crt_table(uint64_t q, int nlimbs, const uint32_t* primes, CrtT
 
 // ------------------------------------------------------------- context
 extern "C" int lab_ctx_create(uint64_t q, int device, uint64_t max_len, lab_ctx** out) {
+  return lab_ctx_create_ex(q, device, max_len, 0, out);
+}
+
+extern "C" int lab_ctx_create_ex(uint64_t q, int device, uint64_t max_len, int flags, lab_ctx** out) {
   if (!out) return LAB_ERR_ARG;
   *out = nullptr;
   if (q < 3 || (q & 1) == 0 || q >= (1ull << 40)) return LAB_ERR_ARG;
@@ -190,8 +201,12 @@ extern "C" int lab_ctx_create(uint64_t q, int device, uint64_t max_len, lab_ctx*
   c->q = q;
   c->device = device;
   if (max_len == 0) max_len = 65536;
-  if (q < (1ull << 30) && q % (2 * D) == 1 && is_prime_u64(q)) {
+  if (flags & ~LAB_CTX_RNS_ONLY) { delete c; return LAB_ERR_ARG; }
+  if (!(flags & LAB_CTX_RNS_ONLY) && q < (1ull << 32) && q % (2 * D) == 1 && is_prime_u64(q)) {
+    // q is its own NTT prime: one limb, 4 bytes per coefficient, no CRT.  Below 2^30 on the lazy kernels; in [2^30, 2^32)
+    // on the strict-32 instantiations (LimbTable.wide)
     c->direct = true;
+    c->wide = q >= (1ull << 30);
     c->nlimbs = 1;
     c->primes[0] = (uint32_t)q;
     c->max_len = 1ull << 40;  // arithmetic is mod q itself: any length is exact
@@ -211,7 +226,7 @@ extern "C" int lab_ctx_create(uint64_t q, int device, uint64_t max_len, lab_ctx*
     for (int l = 0; l < c->nlimbs; l++) c->primes[l] = kLimbPrimes[l];
   }
   for (int l = 0; l < c->nlimbs; l++)
-    if (!build_limb_table(c->primes[l], &c->h_tabs[l])) { delete c; return LAB_ERR_ARG; }
+    if (!build_limb_table(c->primes[l], &c->h_tabs[l], c->wide)) { delete c; return LAB_ERR_ARG; }
   build_crt_table(c->q, c->nlimbs, c->primes, &c->h_crt);
 
   hipError_t e = hipSetDevice(device);
@@ -225,12 +240,14 @@ extern "C" int lab_ctx_create(uint64_t q, int device, uint64_t max_len, lab_ctx*
     lab_ctx_destroy(c);
     return LAB_ERR_HIP;
   }
+  limb_tables_register(c->d_tabs, c->wide);
   *out = c;
   return LAB_OK;
 }
 
 extern "C" void lab_ctx_destroy(lab_ctx* c) {
   if (!c) return;
+  if (c->d_tabs) limb_tables_register(c->d_tabs, false);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& ev : c->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (c->scratch) (void)hipFree(c->scratch);

@@ -17,6 +17,7 @@ struct lab_ctx {
   int device = 0;
   int nlimbs = 0;
   bool direct = false;             // q itself is the single NTT prime
+  bool wide = false;               // ... and 2^30 <= q < 2^32: the strict-32 kernels (LimbTable.wide)
   uint32_t primes[lab::MAX_LIMBS] = {0, 0, 0, 0};
   uint64_t max_len = 0;
   hipStream_t stream = nullptr;

@@ -50,6 +50,25 @@ struct CrtTable {
 
 // ---- ntt_kernels.hip
 // njobs > 1: job b works on src + b*src_js / dst + b*dst_js (word strides inside a plane)
+// single-limb strict-32 contexts (LimbTable.wide): the launchers pick their instantiation from the device table pointer
+void limb_tables_register(const LimbTable* dev_tabs, bool wide);
+bool limb_tables_wide(const LimbTable* dev_tabs);
+// The sum-of-products form every transform-domain reduction takes on the single-limb strict-32 path (wide_kernels.hip):
+// out[o][j] = sum_{k<K} A[abase(o) + k*ak + j] * B[bbase(o) + k*bk + j] mod p for the five-level output index o = (i0..i4), i4
+// fastest; the bases are sum_l i_l * stride_l (words).  chunk_level >= 0: index n[chunk_level] walks chunks of K terms of a
+// Ktotal-term sum (its A/B strides advance by one chunk; the last chunk is short).
+struct WideDot {
+  uint32_t* out;
+  const uint32_t* A;
+  const uint32_t* B;
+  unsigned n[5];
+  size_t os[5], as[5], bs[5];
+  unsigned K, Ktotal;
+  int chunk_level;
+  size_t ak, bk;
+  const LimbTable* tab;
+};
+hipError_t launch_wide_dot(const WideDot& d, hipStream_t s);
 hipError_t launch_ntt(bool forward, ConstHatView src, HatView dst, size_t count, int nlimbs, const LimbTable* tabs,
                       int escale, hipStream_t s, size_t njobs = 1, size_t src_js = 0, size_t dst_js = 0);
 // inverse transform of a multi-job GEMM's slot-major staging array into dense [count][64] planes (see k_intt_from_stage)

@@ -15,7 +15,7 @@
 namespace lab {
 
 // ---------------------------------------------------------------- pointwise
-template <int OP>
+template <int OP, bool WIDE>
 __global__ void __launch_bounds__(256)
 k_pointwise(uint32_t* __restrict__ out, size_t out_ps, const uint32_t* __restrict__ a, size_t a_ps,
             const uint32_t* __restrict__ b, size_t b_ps, size_t nquads, const LimbTable* __restrict__ tabs, unsigned nlimbs,
@@ -31,6 +31,17 @@ k_pointwise(uint32_t* __restrict__ out, size_t out_ps, const uint32_t* __restric
   for (; i < nquads; i += stride) {
     const uint4 x = A[i], y = B[i];
     uint4 r;
+    if constexpr (WIDE) {  // single-limb strict-32 path: plain products (KEEP_SCALE has no scale to keep), carry-corrected sums
+      const ZpConsts c = zp_consts(tabs + limb);
+      typedef Zp<true> Z;
+      if (OP == PW_MUL || OP == PW_MUL_KEEP_SCALE) {
+        r.x = Z::mul(x.x, y.x, c); r.y = Z::mul(x.y, y.y, c); r.z = Z::mul(x.z, y.z, c); r.w = Z::mul(x.w, y.w, c);
+      } else if (OP == PW_ADD) {
+        r.x = Z::add(x.x, y.x, c); r.y = Z::add(x.y, y.y, c); r.z = Z::add(x.z, y.z, c); r.w = Z::add(x.w, y.w, c);
+      } else {
+        r.x = Z::sub(x.x, y.x, c); r.y = Z::sub(x.y, y.y, c); r.z = Z::sub(x.z, y.z, c); r.w = Z::sub(x.w, y.w, c);
+      }
+    } else
     if (OP == PW_MUL) {  // (x*y*R^-1) * R^2 * R^-1 = x*y
       r.x = mont_mul(mont_mul(x.x, y.x, p, pinv), r2, p, pinv);
       r.y = mont_mul(mont_mul(x.y, y.y, p, pinv), r2, p, pinv);
@@ -56,9 +67,11 @@ hipError_t launch_pointwise(PointwiseOp op, HatView out, ConstHatView a, ConstHa
   unsigned blocks = (unsigned)((nquads + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   dim3 grid(blocks, (unsigned)(nlimbs * njobs));
-#define LAUNCH_PW(OPV)                                                                                              \
-  hipLaunchKernelGGL(k_pointwise<OPV>, grid, dim3(256), 0, s, out.base, out.plane_stride, a.base, a.plane_stride, \
+  const bool wide = limb_tables_wide(tabs);
+#define LAUNCH_PW1(OPV, W)                                                                                              \
+  hipLaunchKernelGGL((k_pointwise<OPV, W>), grid, dim3(256), 0, s, out.base, out.plane_stride, a.base, a.plane_stride, \
                      b.base, b.plane_stride, nquads, tabs, (unsigned)nlimbs, out_js, a_js, b_js)
+#define LAUNCH_PW(OPV) do { if (wide) LAUNCH_PW1(OPV, true); else LAUNCH_PW1(OPV, false); } while (0)
   switch (op) {
     case PW_MUL: LAUNCH_PW(PW_MUL); break;
     case PW_ADD: LAUNCH_PW(PW_ADD); break;
@@ -66,6 +79,7 @@ hipError_t launch_pointwise(PointwiseOp op, HatView out, ConstHatView a, ConstHa
     case PW_MUL_KEEP_SCALE: LAUNCH_PW(PW_MUL_KEEP_SCALE); break;
   }
 #undef LAUNCH_PW
+#undef LAUNCH_PW1
   return hipGetLastError();
 }
 
@@ -780,6 +794,17 @@ hipError_t launch_matmul_bcast(HatView out, size_t out_set_stride, size_t out_jo
                                size_t s_set_stride, size_t s_col_stride, size_t s_job_stride, size_t njobs, size_t rows,
                                size_t inner, size_t nsets, int nlimbs, const LimbTable* tabs, hipStream_t s) {
   if (njobs == 0 || rows == 0 || nsets == 0) return hipSuccess;
+  if (limb_tables_wide(tabs)) {   // single-limb strict-32 path: (job, set, row) outputs of an `inner`-term sum
+    if (nlimbs != 1) return hipErrorInvalidValue;
+    WideDot d{};
+    d.out = out.base; d.A = A.base; d.B = S.base; d.tab = tabs;
+    d.n[0] = d.n[1] = 1; d.n[2] = (unsigned)njobs; d.n[3] = (unsigned)nsets; d.n[4] = (unsigned)rows;
+    d.os[2] = out_job_stride; d.os[3] = out_set_stride; d.os[4] = D;
+    d.as[4] = inner * D; d.ak = D;
+    d.bs[2] = s_job_stride; d.bs[3] = s_set_stride; d.bk = s_col_stride;
+    d.K = d.Ktotal = (unsigned)inner; d.chunk_level = -1;
+    return launch_wide_dot(d, s);
+  }
   if (nsets % 8 || inner % BC_COLS || inner == 0 || rows < (size_t)BC_ROWS / 2 || (uint64_t)(64 * inner + 2) * 256 >= (1ull << 32) ||
       (s_set_stride * 2 + s_col_stride) * 4 >= (1ull << 32) || njobs * (nsets / 8) > 65535)
     return hipErrorNotSupported;
@@ -804,6 +829,17 @@ template <typename MT>
 static hipError_t launch_axpy_bcast(int nb, uint32_t* partial, size_t partial_ps, size_t partial_bs, const uint32_t* G, size_t g_ps,
                                     size_t g_bs, const MT* C, size_t c_ps, size_t nterms, size_t chunk, size_t len, int nlimbs,
                                     const LimbTable* tabs, hipStream_t s) {
+  if (limb_tables_wide(tabs)) {   // single-limb strict-32 path: (set, chunk, rho) outputs, chunks of `chunk` terms
+    if (sizeof(MT) != 4 || nlimbs != 1 || chunk == 0) return hipErrorInvalidValue;
+    WideDot d{};
+    d.out = partial; d.A = G; d.B = reinterpret_cast<const uint32_t*>(C); d.tab = tabs;
+    d.n[0] = d.n[1] = 1; d.n[2] = (unsigned)nb; d.n[3] = (unsigned)((nterms + chunk - 1) / chunk); d.n[4] = (unsigned)len;
+    d.os[2] = partial_bs; d.os[3] = len * D; d.os[4] = D;
+    d.as[2] = g_bs; d.as[3] = chunk * D; d.ak = D;
+    d.bs[3] = chunk * len * D; d.bs[4] = D; d.bk = len * D;
+    d.K = (unsigned)chunk; d.Ktotal = (unsigned)nterms; d.chunk_level = 3;
+    return launch_wide_dot(d, s);
+  }
   if (nb < 2 || len < (size_t)BC_ROWS / 2 || chunk % BC_COLS || nterms % chunk || (63 * D + len * D) * sizeof(MT) >= (1ull << 32) ||
       g_bs * 8 >= (1ull << 32))
     return hipErrorNotSupported;
@@ -841,12 +877,25 @@ hipError_t launch_axpy_bcast_u16(int nb, uint32_t* partial_plane, size_t partial
   return launch_axpy_bcast<uint16_t>(nb, partial_plane, 0, partial_bs, G_plane, 0, g_bs, C, 0, nterms, chunk, len, 1, tab, s);
 }
 
+static void set_last_matvec_kernel(const char* n);
 template <typename MT>
 static hipError_t launch_matvec_nb(int nb, uint32_t* partial, size_t partial_ps, size_t partial_bs, const MT* M, size_t m_ps,
                                    const uint32_t* V, size_t v_ps, size_t v_bs, size_t nmat, size_t rows, size_t cols,
                                    int nlimbs, const LimbTable* tabs, hipStream_t s, size_t njobs = 1, size_t js = 0) {
   if (nmat == 0 || rows == 0 || nlimbs == 0 || njobs == 0) return hipSuccess;
   if (njobs > 1 && nb != 1) return hipErrorInvalidValue;   // jobs are served by the single-set kernel only
+  if (limb_tables_wide(tabs)) {   // single-limb strict-32 path: (job, set, matrix, row) outputs of a `cols`-term sum
+    if (sizeof(MT) != 4 || nlimbs != 1) return hipErrorInvalidValue;
+    WideDot d{};
+    d.out = partial; d.A = reinterpret_cast<const uint32_t*>(M); d.B = V; d.tab = tabs;
+    d.n[0] = 1; d.n[1] = (unsigned)njobs; d.n[2] = (unsigned)nb; d.n[3] = (unsigned)nmat; d.n[4] = (unsigned)rows;
+    d.os[1] = js; d.os[2] = partial_bs; d.os[3] = rows * D; d.os[4] = D;
+    d.as[1] = js; d.as[3] = rows * cols * D; d.as[4] = cols * D; d.ak = D;
+    d.bs[1] = js; d.bs[2] = v_bs; d.bs[3] = cols * D; d.bk = D;
+    d.K = d.Ktotal = (unsigned)cols; d.chunk_level = -1;
+    set_last_matvec_kernel("k_wide_dot");
+    return launch_wide_dot(d, s);
+  }
   if (nb > 1 && rows >= (size_t)BC_ROWS / 2 && (v_bs % 4) == 0 && cols % BC_COLS == 0 &&
       (uint64_t)(64 * cols + 2) * 256 < (1ull << 32) && v_bs * 8 < (1ull << 32)) {  // ... tiles by LDS-DMA
     dim3 g((unsigned)((rows + BC_ROWS - 1) / BC_ROWS), (unsigned)nmat, (unsigned)nlimbs);
@@ -1077,6 +1126,17 @@ k_matmul_t(uint32_t* __restrict__ out, size_t out_ps, const uint32_t* __restrict
 hipError_t launch_matmul_t(HatView out, ConstHatView A, ConstHatView S, size_t rows, size_t inner, size_t ncols,
                            int nlimbs, const LimbTable* tabs, hipStream_t s) {
   if (rows == 0 || ncols == 0) return hipSuccess;
+  if (limb_tables_wide(tabs)) {   // single-limb strict-32 path: out[col][row] = sum_x A[row][x] S[x][col]
+    if (nlimbs != 1) return hipErrorInvalidValue;
+    WideDot d{};
+    d.out = out.base; d.A = A.base; d.B = S.base; d.tab = tabs;
+    d.n[0] = d.n[1] = d.n[2] = 1; d.n[3] = (unsigned)ncols; d.n[4] = (unsigned)rows;
+    d.os[3] = rows * D; d.os[4] = D;
+    d.as[4] = inner * D; d.ak = D;
+    d.bs[3] = D; d.bk = ncols * D;
+    d.K = d.Ktotal = (unsigned)inner; d.chunk_level = -1;
+    return launch_wide_dot(d, s);
+  }
   unsigned col_groups = (unsigned)((ncols + MM_CT - 1) / MM_CT);
   unsigned wy = col_groups < 4 ? col_groups : 4;
   dim3 block(64, wy);
@@ -1151,6 +1211,17 @@ static hipError_t launch_axpy_nb(int nb, uint32_t* partial, size_t partial_ps, s
                                  size_t g_bs, const MT* C, size_t c_ps, size_t nterms, size_t len, int nlimbs,
                                  const LimbTable* tabs, hipStream_t s) {
   if (nterms == 0 || len == 0 || nlimbs == 0) return hipSuccess;
+  if (limb_tables_wide(tabs)) {   // single-limb strict-32 path: (set, chunk, rho) outputs, chunks of AX_CHUNK terms
+    if (sizeof(MT) != 4 || nlimbs != 1) return hipErrorInvalidValue;
+    WideDot d{};
+    d.out = partial; d.A = G; d.B = reinterpret_cast<const uint32_t*>(C); d.tab = tabs;
+    d.n[0] = d.n[1] = 1; d.n[2] = (unsigned)nb; d.n[3] = (unsigned)axpy_num_chunks(nterms); d.n[4] = (unsigned)len;
+    d.os[2] = partial_bs; d.os[3] = len * D; d.os[4] = D;
+    d.as[2] = g_bs; d.as[3] = (size_t)AX_CHUNK * D; d.ak = D;
+    d.bs[3] = (size_t)AX_CHUNK * len * D; d.bs[4] = D; d.bk = len * D;
+    d.K = AX_CHUNK; d.Ktotal = (unsigned)nterms; d.chunk_level = 3;
+    return launch_wide_dot(d, s);
+  }
   dim3 grid((unsigned)((len + 15) / 16), (unsigned)axpy_num_chunks(nterms), (unsigned)nlimbs);
 #define LAB_AX(NBV)                                                                                                   \
   hipLaunchKernelGGL((k_axpy_partial<MT, NBV>), grid, dim3(256), 0, s, partial, partial_ps, partial_bs, G, g_ps, g_bs, C, \
@@ -1222,6 +1293,7 @@ hipError_t launch_pack_u16(uint16_t* dst, const uint32_t* src, size_t count, boo
 }
 
 // out[k] = poly * v[k]  (poly_by_poly_vec, src/util.rs:289-296); plain products
+template <bool WIDE>
 __global__ void __launch_bounds__(256)
 k_poly_by_vec(uint32_t* __restrict__ out, size_t out_ps, const uint32_t* __restrict__ poly, size_t poly_ps,
               const uint32_t* __restrict__ v, size_t v_ps, size_t nquads, const LimbTable* __restrict__ tabs, unsigned nlimbs,
@@ -1237,6 +1309,12 @@ k_poly_by_vec(uint32_t* __restrict__ out, size_t out_ps, const uint32_t* __restr
   for (; i < nquads; i += stride) {
     const uint4 a = Pq[i & 15], b = Vq[i];
     uint4 r;
+    if constexpr (WIDE) {
+      const ZpConsts c = zp_consts(tabs + limb);
+      r.x = Zp<true>::mul(a.x, b.x, c); r.y = Zp<true>::mul(a.y, b.y, c); r.z = Zp<true>::mul(a.z, b.z, c); r.w = Zp<true>::mul(a.w, b.w, c);
+      O[i] = r;
+      continue;
+    }
     r.x = mont_mul(mont_mul(a.x, b.x, p, pinv), r2, p, pinv);
     r.y = mont_mul(mont_mul(a.y, b.y, p, pinv), r2, p, pinv);
     r.z = mont_mul(mont_mul(a.z, b.z, p, pinv), r2, p, pinv);
@@ -1251,8 +1329,12 @@ hipError_t launch_poly_by_vec(HatView out, ConstHatView poly, ConstHatView v, si
   size_t nquads = len * D / 4;
   unsigned blocks = (unsigned)((nquads + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_poly_by_vec, dim3(blocks, (unsigned)(nlimbs * njobs)), dim3(256), 0, s, out.base, out.plane_stride,
-                     poly.base, poly.plane_stride, v.base, v.plane_stride, nquads, tabs, (unsigned)nlimbs, js);
+  if (limb_tables_wide(tabs))
+    hipLaunchKernelGGL(k_poly_by_vec<true>, dim3(blocks, (unsigned)(nlimbs * njobs)), dim3(256), 0, s, out.base, out.plane_stride,
+                       poly.base, poly.plane_stride, v.base, v.plane_stride, nquads, tabs, (unsigned)nlimbs, js);
+  else
+    hipLaunchKernelGGL(k_poly_by_vec<false>, dim3(blocks, (unsigned)(nlimbs * njobs)), dim3(256), 0, s, out.base, out.plane_stride,
+                       poly.base, poly.plane_stride, v.base, v.plane_stride, nquads, tabs, (unsigned)nlimbs, js);
   return hipGetLastError();
 }
 
@@ -1385,6 +1467,17 @@ hipError_t launch_gram_tiled(HatView partial, ConstHatView P, ConstHatView S, si
   const size_t nchunks = gram_chunks(n, r, nlimbs, njobs);
   const size_t want = nchunks;
   const unsigned xchunk = (unsigned)(((n + want - 1) / want + 7) / 8 * 8);
+  if (limb_tables_wide(tabs)) {   // single-limb strict-32 path: (job, chunk, i, k) outputs, chunks of xchunk terms
+    if (nlimbs != 1) return hipErrorInvalidValue;
+    WideDot d{};
+    d.out = partial.base; d.A = P.base; d.B = S.base; d.tab = tabs;
+    d.n[0] = 1; d.n[1] = (unsigned)njobs; d.n[2] = (unsigned)nchunks; d.n[3] = (unsigned)r; d.n[4] = (unsigned)r;
+    d.os[1] = js; d.os[2] = r * r * D; d.os[3] = r * D; d.os[4] = D;
+    d.as[1] = js; d.as[2] = (size_t)xchunk * r * D; d.as[3] = D; d.ak = r * D;
+    d.bs[1] = js; d.bs[2] = (size_t)xchunk * r * D; d.bs[4] = D; d.bk = r * D;
+    d.K = xchunk; d.Ktotal = (unsigned)n; d.chunk_level = 2;
+    return launch_wide_dot(d, s);
+  }
   dim3 grid((unsigned)((r + GL_TI - 1) / GL_TI), (unsigned)((r + GL_TK - 1) / GL_TK), (unsigned)(nlimbs * nchunks * njobs));
   const bool same = P.base == S.base && P.plane_stride == S.plane_stride && r <= (size_t)GL_TK;
   if (same)

@@ -6,15 +6,35 @@
 // marshalling around it (src/algebraic.rs:385-399, 407-420).
 #include "kernels.h"
 
+#include <mutex>
+#include <vector>
+
 namespace lab {
 typedef unsigned __int128 u128;
+
+// Host-side record of which device tables belong to a single-limb strict-32 context (LimbTable.wide): the launchers take
+// device pointers and pick the kernel instantiation from it.
+static std::mutex g_wide_mu;
+static std::vector<const LimbTable*> g_wide_tabs;
+void limb_tables_register(const LimbTable* dev_tabs, bool wide) {
+  std::lock_guard<std::mutex> g(g_wide_mu);
+  for (size_t i = 0; i < g_wide_tabs.size(); i++)
+    if (g_wide_tabs[i] == dev_tabs) { g_wide_tabs.erase(g_wide_tabs.begin() + i); break; }
+  if (wide) g_wide_tabs.push_back(dev_tabs);
+}
+bool limb_tables_wide(const LimbTable* dev_tabs) {
+  std::lock_guard<std::mutex> g(g_wide_mu);
+  for (const LimbTable* t : g_wide_tabs)
+    if (t == dev_tabs) return true;
+  return false;
+}
 
 // One polynomial per thread, one wave per block: the wave's 64 polynomials
 // (16 KiB) are fetched with 16-byte coalesced loads, transposed through LDS,
 // transformed entirely in registers (192 lazy butterflies, twiddles from
 // scalar loads) and written back the same way.
 // Algorithmic traffic: 256 B in + 256 B out per polynomial per limb.
-template <bool FWD>
+template <bool FWD, bool WIDE>
 __global__ void __launch_bounds__(64)
 k_ntt64(const uint32_t* __restrict__ src, size_t src_ps, uint32_t* __restrict__ dst, size_t dst_ps, size_t count,
         const LimbTable* __restrict__ tabs, int escale, size_t src_js, size_t dst_js) {
@@ -25,7 +45,7 @@ k_ntt64(const uint32_t* __restrict__ src, size_t src_ps, uint32_t* __restrict__ 
   const int lane = threadIdx.x;
   uint32_t x[D];
   tile_load_u32(x, src + (size_t)limb * src_ps + (size_t)blockIdx.z * src_js, base, count, lds, lane);
-  if (FWD) ntt64_forward(x, tab); else ntt64_inverse(x, tab, escale);
+  if (FWD) ntt64_fwd<WIDE>(x, tab); else ntt64_inv<WIDE>(x, tab, escale);
   tile_store_u32(x, dst + (size_t)limb * dst_ps + (size_t)blockIdx.z * dst_js, base, count, lds, lane);
 }
 
@@ -78,20 +98,22 @@ hipError_t launch_ntt(bool forward, ConstHatView src, HatView dst, size_t count,
                       int escale, hipStream_t s, size_t njobs, size_t src_js, size_t dst_js) {
   if (count == 0 || njobs == 0) return hipSuccess;
   dim3 grid((unsigned)((count + 63) / 64), (unsigned)nlimbs, (unsigned)njobs);
-  if (forward)
-    hipLaunchKernelGGL(k_ntt64<true>, grid, dim3(64), 0, s, src.base, src.plane_stride, dst.base, dst.plane_stride,
-                       count, tabs, escale, src_js, dst_js);
-  else
-    hipLaunchKernelGGL(k_ntt64<false>, grid, dim3(64), 0, s, src.base, src.plane_stride, dst.base, dst.plane_stride,
-                       count, tabs, escale, src_js, dst_js);
+  const bool wide = limb_tables_wide(tabs);
+#define LAB_NTT(F, W) hipLaunchKernelGGL((k_ntt64<F, W>), grid, dim3(64), 0, s, src.base, src.plane_stride, dst.base, dst.plane_stride, \
+                                         count, tabs, escale, src_js, dst_js)
+  if (forward) { if (wide) LAB_NTT(true, true); else LAB_NTT(true, false); }
+  else { if (wide) LAB_NTT(false, true); else LAB_NTT(false, false); }
+#undef LAB_NTT
   return hipGetLastError();
 }
 
 // coefficient u64 in [0,q) -> residue mod each limb prime (q < 2^40, so x = hi*2^32 + lo with hi < 2^8).
 // Division-free: hi*2^32 mod p by a Shoup multiplication with the tabulated 2^32 mod p; lo mod p by conditional
 // subtractions when p > 2^29 (lo < 2^32 < 8p), by mod_u64 for the small limb of the digit basis.
+template <bool WIDE = false>
 __device__ __forceinline__ uint32_t reduce_u40(uint64_t v, const LimbTable& tb) {
   const uint32_t p = tb.p, lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  if constexpr (WIDE) return (uint32_t)mod_u64_near(v, p, tb.inv_p);   // p >= 2^30: quotient < 2^10
   if (p > (1u << 29)) {
     uint32_t b = lo;
     b = min(b, b - 4 * p);   // wraps (and is discarded by min) unless b >= 4p; 4p < 2^32 as p < 2^30
@@ -115,7 +137,9 @@ k_reduce_u64(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, size_
     // nwords is a multiple of 64, so the pair (i, i+1) is always in range
     const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(coeffs + i);
     for (int l = 0; l < nlimbs; l++)
-      *reinterpret_cast<uint2*>(dst + (size_t)l * dst_ps + i) = make_uint2(reduce_u40(v.x, tabs[l]), reduce_u40(v.y, tabs[l]));
+      *reinterpret_cast<uint2*>(dst + (size_t)l * dst_ps + i) =
+          tabs[l].wide ? make_uint2(reduce_u40<true>(v.x, tabs[l]), reduce_u40<true>(v.y, tabs[l]))
+                       : make_uint2(reduce_u40(v.x, tabs[l]), reduce_u40(v.y, tabs[l]));
   }
 }
 
@@ -129,7 +153,7 @@ k_reduce_u64(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, size_
 // src/util.rs:195-202) to norm_sum[job] — saturating: a polynomial with a coefficient above norm_vmax or a partial sum
 // above norm_limit counts as norm_limit + 1, so the total exceeds norm_limit exactly when the true norm does and never
 // overflows ((blocks + 1) * (norm_limit + 1) < 2^64 is the caller's business).
-template <bool NORM, bool SRC16>
+template <bool NORM, bool SRC16, bool WIDE = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_to_hat_fused(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, size_t dst_js, size_t count, int nlimbs,
                const LimbTable* __restrict__ tabs, uint64_t in_bound, unsigned long long* __restrict__ norm_sum,
@@ -216,6 +240,18 @@ k_to_hat_fused(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, siz
   for (int l = 0; l < nlimbs; l++) {
     const LimbTable* tab = tabs + l;
     uint32_t x[D];
+    if constexpr (WIDE) {                // single-limb strict-32 path: q itself, 2^30 <= q < 2^32
+      if (in_bound <= tab->p) {
+#pragma unroll
+        for (int k = 0; k < D; k++) x[k] = clo[k];
+      } else {
+        const uint32_t p = tab->p;
+        const double ip = tab->inv_p;
+#pragma unroll
+        for (int k = 0; k < D; k++)
+          x[k] = (uint32_t)mod_u64_near(((uint64_t)((chi[k / 4] >> (8 * (k & 3))) & 0xFFu) << 32) | clo[k], p, ip);
+      }
+    } else
     if (in_bound <= tab->p) {            // the caller vouches for coefficients below in_bound (decomposition digits): nothing to reduce
 #pragma unroll
       for (int k = 0; k < D; k++) x[k] = clo[k];
@@ -231,7 +267,7 @@ k_to_hat_fused(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, siz
 #pragma unroll
       for (int k = 0; k < D; k++) x[k] = reduce_small16((chi[k / 4] >> (8 * (k & 3))) & 0xFFu, clo[k], p, m, r1);
     }
-    ntt64_forward(x, tab);
+    ntt64_fwd<WIDE>(x, tab);
     tile_store_u32(x, dst + (size_t)l * dst_ps, base, count, lds, lane);
   }
 }
@@ -248,8 +284,19 @@ hipError_t launch_to_hat_fused(const JobPtrs& coeffs, HatView dst, size_t dst_js
     while ((uint64_t)vmax * vmax > norm_limit) vmax--;
     while ((uint64_t)(vmax + 1) * (vmax + 1) <= norm_limit) vmax++;
     if (src_u16) return hipErrorInvalidValue;
+    if (limb_tables_wide(tabs))
+      hipLaunchKernelGGL((k_to_hat_fused<true, false, true>), g, dim3(64), 0, s, coeffs, dst.base, dst.plane_stride, dst_js, count, nlimbs, tabs,
+                         in_bound, norm_sum, norm_limit, vmax);
+    else
     hipLaunchKernelGGL((k_to_hat_fused<true, false>), g, dim3(64), 0, s, coeffs, dst.base, dst.plane_stride, dst_js, count, nlimbs, tabs,
                        in_bound, norm_sum, norm_limit, vmax);
+  } else if (limb_tables_wide(tabs)) {
+    if (src_u16)
+      hipLaunchKernelGGL((k_to_hat_fused<false, true, true>), g, dim3(64), 0, s, coeffs, dst.base, dst.plane_stride, dst_js, count, nlimbs, tabs,
+                         in_bound, nullptr, (uint64_t)0, (uint32_t)0);
+    else
+      hipLaunchKernelGGL((k_to_hat_fused<false, false, true>), g, dim3(64), 0, s, coeffs, dst.base, dst.plane_stride, dst_js, count, nlimbs,
+                         tabs, in_bound, nullptr, (uint64_t)0, (uint32_t)0);
   } else if (src_u16) {
     hipLaunchKernelGGL((k_to_hat_fused<false, true>), g, dim3(64), 0, s, coeffs, dst.base, dst.plane_stride, dst_js, count, nlimbs, tabs,
                        in_bound, nullptr, (uint64_t)0, (uint32_t)0);

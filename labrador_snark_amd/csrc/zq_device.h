@@ -25,12 +25,14 @@ constexpr int MAX_LIMBS = 4;
 
 // Per-limb constants, resident in device memory (one per RNS prime).
 struct LimbTable {
-  uint32_t p;            // prime, p == 1 (mod 128), p < 2^30
+  uint32_t p;            // prime, p == 1 (mod 128), p < 2^30 (p < 2^32 when `wide`)
   uint32_t p2;           // 2p
   uint32_t pinv;         // p^-1 mod 2^32  (signed Montgomery REDC)
   uint32_t r1;           // 2^32 mod p
   uint32_t r2;           // 2^64 mod p
-  uint32_t pad[3];
+  uint32_t wide;         // 1: 2^30 <= p < 2^32, q itself as the only prime ("single-limb strict-32 path", see Zp<true> below): strict
+                         // arithmetic, fwd/inv/scale_lo hold Montgomery forms w * 2^32 mod p in [..][0]
+  uint32_t pad[2];
   uint32_t q_hi_mul;     // 2^32 mod p, used to fold 64-bit coefficients: x = hi*2^32+lo
   uint32_t q_hi_mul_sh;  // Shoup companion of q_hi_mul
   double inv_p;          // 1.0 / p for the division-free reductions (mod_u64)
@@ -180,6 +182,121 @@ __device__ __forceinline__ void ntt64_inverse(uint32_t (&x)[D], const LimbTable*
     x[j] = csub(mul_shoup_lazy(U + V, s0, s0p, p), p);
     x[j + D / 2] = csub(mul_shoup_lazy(U - V + p2, s1, s1p, p), p);
   }
+}
+
+// ---- Arithmetic policy of the transform-domain kernels.  Zp<false>: limb primes below 2^30, lazy 32-bit arithmetic (values
+// up to 4p in a word, 64-bit accumulators of products folded every 8 terms).  Zp<true>: the single-limb strict-32 path for an
+// NTT-friendly q in [2^30, 2^32) (reference anchor: the commented 32-bit Q of src/constants.rs:195-196 behind the seam
+// src/algebraic.rs:379-404): q itself is the only prime, residues are canonical 32-bit words (4 B per coefficient, no CRT),
+// sums and differences are corrected with the carry, products are reduced exactly, and a sum of products is kept as two
+// 64-bit accumulators (low and high words of the 64-bit products: no fold for 2^32 terms).
+struct ZpConsts { uint32_t p, p2, pinv, r2; double inv_p; };
+__device__ __forceinline__ ZpConsts zp_consts(const LimbTable* __restrict__ t) { return ZpConsts{t->p, t->p2, t->pinv, t->r2, t->inv_p}; }
+
+template <bool WIDE> struct Zp;
+template <> struct Zp<false> {
+  typedef uint64_t acc_t;
+  static __device__ __forceinline__ acc_t zero() { return 0; }
+  static __device__ __forceinline__ void mad(acc_t& a, uint32_t x, uint32_t y) { a += (uint64_t)x * y; }
+  static __device__ __forceinline__ acc_t fold(acc_t a, const ZpConsts& c) { return acc_fold(a, c.p, c.p2); }         // after <= 8 mads
+  static __device__ __forceinline__ acc_t fold_lazy(acc_t a, const ZpConsts& c) { return acc_fold_lazy(a, c.p2); }
+  // the sum as a plain canonical residue (the accumulator folded or holding at most 8 products)
+  static __device__ __forceinline__ uint32_t finish(acc_t a, const ZpConsts& c) {
+    return mont_mul(redc64(acc_fold(a, c.p, c.p2), c.p, c.pinv), c.r2, c.p, c.pinv);
+  }
+  static __device__ __forceinline__ uint32_t mul(uint32_t x, uint32_t y, const ZpConsts& c) {
+    return mont_mul(mont_mul(x, y, c.p, c.pinv), c.r2, c.p, c.pinv);
+  }
+  static __device__ __forceinline__ uint32_t add(uint32_t x, uint32_t y, const ZpConsts& c) { return csub(x + y, c.p); }
+  static __device__ __forceinline__ uint32_t sub(uint32_t x, uint32_t y, const ZpConsts& c) { return csub(x + c.p - y, c.p); }
+};
+template <> struct Zp<true> {
+  struct acc_t { uint64_t lo, hi; };
+  static __device__ __forceinline__ acc_t zero() { return acc_t{0, 0}; }
+  static __device__ __forceinline__ void mad(acc_t& a, uint32_t x, uint32_t y) {
+    const uint64_t t = (uint64_t)x * y;
+    a.lo += (uint32_t)t;
+    a.hi += t >> 32;
+  }
+  static __device__ __forceinline__ acc_t fold(acc_t a, const ZpConsts&) { return a; }
+  static __device__ __forceinline__ acc_t fold_lazy(acc_t a, const ZpConsts&) { return a; }
+  static __device__ __forceinline__ uint32_t add(uint32_t x, uint32_t y, const ZpConsts& c) {
+    const uint32_t s = x + y;
+    return (s < x || s >= c.p) ? s - c.p : s;
+  }
+  static __device__ __forceinline__ uint32_t sub(uint32_t x, uint32_t y, const ZpConsts& c) {
+    const uint32_t d = x - y;
+    return x < y ? d + c.p : d;
+  }
+  static __device__ __forceinline__ uint32_t mul(uint32_t x, uint32_t y, const ZpConsts& c) {
+    return (uint32_t)mod_u64_near((uint64_t)x * y, c.p, c.inv_p);          // quotient < 2^32
+  }
+  static __device__ __forceinline__ uint32_t finish(acc_t a, const ZpConsts& c) {   // (hi * 2^32 + lo) mod p, quotients < 2^34
+    const uint64_t h = mod_u64_near(a.hi, c.p, c.inv_p);
+    const uint64_t t = mod_u64_near(h << 32, c.p, c.inv_p) + mod_u64_near(a.lo, c.p, c.inv_p);
+    return (uint32_t)(t >= c.p ? t - c.p : t);
+  }
+  // x * w mod p for a constant held in Montgomery form wm = w * 2^32 mod p: signed REDC, the sign taken from the compare
+  static __device__ __forceinline__ uint32_t mul_const(uint32_t x, uint32_t wm, uint32_t p, uint32_t pinv) {
+    const uint64_t ab = (uint64_t)x * wm;
+    const uint32_t hi = (uint32_t)(ab >> 32), mh = __umulhi((uint32_t)ab * pinv, p);
+    const uint32_t t = hi - mh;
+    return hi < mh ? t + p : t;
+  }
+};
+
+// The 64-point transforms of the strict-32 path: canonical values throughout, twiddles in Montgomery form (LimbTable.wide).
+__device__ __forceinline__ void ntt64_forward_wide(uint32_t (&x)[D], const LimbTable* __restrict__ tab) {
+  const uint32_t p = tab->p, pinv = tab->pinv;
+  const ZpConsts c{p, 0, pinv, 0, 0.0};
+  int t = D;
+#pragma unroll
+  for (int m = 1; m < D; m <<= 1) {
+    t >>= 1;
+#pragma unroll
+    for (int i = 0; i < m; i++) {
+      const uint32_t w = tab->fwd[m + i][0];
+#pragma unroll
+      for (int j = 2 * i * t; j < 2 * i * t + t; j++) {
+        const uint32_t X = x[j], T = Zp<true>::mul_const(x[j + t], w, p, pinv);
+        x[j] = Zp<true>::add(X, T, c);
+        x[j + t] = Zp<true>::sub(X, T, c);
+      }
+    }
+  }
+}
+// inverse; the escale argument of the lazy path (Montgomery factors left by PW_MUL_KEEP_SCALE) has no meaning here:
+// products of the strict path are always plain
+__device__ __forceinline__ void ntt64_inverse_wide(uint32_t (&x)[D], const LimbTable* __restrict__ tab) {
+  const uint32_t p = tab->p, pinv = tab->pinv;
+  const ZpConsts c{p, 0, pinv, 0, 0.0};
+  int t = 1;
+#pragma unroll
+  for (int m = D; m > 1; m >>= 1) {
+    const int h = m >> 1;
+#pragma unroll
+    for (int i = 0; i < h; i++) {
+      const uint32_t w = tab->inv[h + i][0];
+#pragma unroll
+      for (int j = 2 * i * t; j < 2 * i * t + t; j++) {
+        const uint32_t U = x[j], V = x[j + t];
+        x[j] = Zp<true>::add(U, V, c);
+        x[j + t] = Zp<true>::mul_const(Zp<true>::sub(U, V, c), w, p, pinv);
+      }
+    }
+    t <<= 1;
+  }
+  const uint32_t ninv = tab->scale_lo[0][0];
+#pragma unroll
+  for (int j = 0; j < D; j++) x[j] = Zp<true>::mul_const(x[j], ninv, p, pinv);
+}
+template <bool WIDE>
+__device__ __forceinline__ void ntt64_fwd(uint32_t (&x)[D], const LimbTable* __restrict__ tab) {
+  if constexpr (WIDE) ntt64_forward_wide(x, tab); else ntt64_forward(x, tab);
+}
+template <bool WIDE>
+__device__ __forceinline__ void ntt64_inv(uint32_t (&x)[D], const LimbTable* __restrict__ tab, int e) {
+  if constexpr (WIDE) ntt64_inverse_wide(x, tab); else ntt64_inverse(x, tab, e);
 }
 
 // ---- wave-tile transposition through LDS: a one-wave block owns 64 consecutive

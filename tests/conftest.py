@@ -12,10 +12,25 @@ if ROOT not in sys.path:
 Q_DEFAULT = 8191
 Q_REF33 = (1 << 32) + 15
 Q_DIRECT = 1073738753
-# the largest prime below 2^32 with q == 1 (mod 128): SURVEY §7's "NTT-friendly 32-bit q" (path (b)); on the GPU it runs
-# through the exact 3-limb RNS path (a single-limb strict-32 policy is not built), in oracle/fastcpu.c as one limb
+# the largest prime below 2^32 with q == 1 (mod 128): SURVEY §7's "NTT-friendly 32-bit q" (path (b)): one limb, 4 bytes per
+# coefficient, on the strict-32 kernels (csrc/zq_device.h Zp<true>, csrc/wide_kernels.hip)
 Q_NTT32 = 4294966657
-ALL_Q = [Q_DEFAULT, Q_REF33, Q_DIRECT, Q_NTT32]
+
+
+class RnsOnly(int):
+    """A modulus whose context is created with LAB_CTX_RNS_ONLY: the generic exact RNS path although q is NTT-friendly."""
+    rns_only = True
+
+
+Q_NTT32_RNS = RnsOnly(Q_NTT32)
+# Q_NTT32 runs single-limb on the strict-32 kernels (SURVEY section 7 path (b)); Q_NTT32_RNS is the same modulus on three RNS
+# limbs (path (a)): every test parametrised over ALL_Q compares both with the oracle
+ALL_Q = [Q_DEFAULT, Q_REF33, Q_DIRECT, Q_NTT32, Q_NTT32_RNS]
+
+
+def ctx_kw(q):
+    """keyword arguments for lab.Context(q, ...) that honour the RnsOnly marker"""
+    return {"rns_only": True} if getattr(q, "rns_only", False) else {}
 
 
 def pytest_configure(config):
@@ -42,9 +57,10 @@ def contexts():
     cache = {}
 
     def get(q, max_len=0):
-        key = (q, max_len)
+        rns = bool(getattr(q, "rns_only", False))
+        key = (int(q), max_len, rns)
         if key not in cache:
-            cache[key] = lab.Context(q, 0, max_len)
+            cache[key] = lab.Context(int(q), 0, max_len, rns_only=rns)
         return cache[key]
 
     yield get

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import Q_DEFAULT, Q_REF33, Q_DIRECT
+from conftest import Q_DEFAULT, Q_REF33, Q_DIRECT, ctx_kw
 
 from oracle import coracle as co
 from oracle import pyref
@@ -165,7 +165,7 @@ def test_streamed_crs_matvec_equals_materialise_then_multiply(mfma_basis, nmat, 
     # CRS restatement + schoolbook products on sample rows.  300 and 130 rows: three resp. two slabs, the last one ragged.
     import labrador_snark_amd as lab
     q = Q_REF33
-    ctx = lab.Context(q, 0)
+    ctx = lab.Context(q, 0, **ctx_kw(q))
     ctx.enable_digit_basis(nmat * cols, 1625, mfma=mfma_basis)
     base = bytes((i * 29 + 5) % 256 for i in range(32))
     # matrix m starts at an arbitrary offset (one beyond 64 bits); its rows are consecutive in seed space
@@ -199,7 +199,7 @@ def test_prover_with_B_streamed_from_the_seed(nproofs):
     import labrador_snark_amd as lab
     import cases
     q, n, r, kappa, kappa1 = Q_REF33, 2, 2, 5, 4
-    ctx = lab.Context(q, 0)
+    ctx = lab.Context(q, 0, **ctx_kw(q))
     p = cases.Params(q, n, r, kappa, kappa1)
     k = lab.RuntimeConstants(q, n, r, kappa, kappa1, kappa1)
     base = bytes((i * 37 + 11) % 256 for i in range(32))

@@ -13,7 +13,7 @@ import copy
 import numpy as np
 import pytest
 
-from conftest import Q_REF33
+from conftest import Q_REF33, ctx_kw
 
 pytestmark = pytest.mark.gpu
 D = 64
@@ -32,7 +32,7 @@ def bench_run():
     import labrador_snark_amd as lab
     q, n, r, kappa = Q_REF33, 1024, 32, 1024
     k = lab.RuntimeConstants(q, n, r, kappa, kappa, kappa)
-    ctx = lab.Context(q, 0, max(65536, n * r + r * r))
+    ctx = lab.Context(q, 0, max(65536, n * r + r * r, **ctx_kw(q)))
     ctx.use_torch_stream()
     dev = torch.device("cuda", 0)
     dSs, sts, dtapes, crs = bench.build_workload(lab, ctx, k, q, dev, NB, 50, 1000, use_mfma=True, basis23=True, compact=True)

@@ -10,6 +10,8 @@ import sys
 import numpy as np
 import pytest
 
+from conftest import ctx_kw
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 D = 64
@@ -24,7 +26,7 @@ def _worker(rank, world, port, q, r, t1, kappa1, kappa, ns, use_mfma, ret):
     import labrador_snark_amd as lab
     from labrador_snark_amd import parallel
     torch.cuda.set_device(0)
-    ctx = lab.Context(q, 0, 1 << 16)
+    ctx = lab.Context(q, 0, 1 << 16, **ctx_kw(q))
     ctx.enable_digit_basis(r * t1 * kappa, 1625, mfma=use_mfma)
     nmat = r * t1
     lo, hi = parallel.ik_shard(r, t1, rank, world)

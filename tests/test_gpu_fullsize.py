@@ -6,7 +6,7 @@ import copy
 import numpy as np
 import pytest
 
-from conftest import Q_REF33, Q_DIRECT
+from conftest import Q_REF33, Q_DIRECT, ctx_kw
 
 import cases
 
@@ -75,7 +75,7 @@ def test_config3_full_prover_n1024_r32_self_consistent(contexts):
     import labrador_snark_amd as lab
     from oracle import coracle as co
     q, n, r, kappa, kappa1 = Q_REF33, 1024, 32, 1024, 64
-    ctx = lab.Context(q, 0, 1 << 17)
+    ctx = lab.Context(q, 0, 1 << 17, **ctx_kw(q))
     p = cases.Params(q, n, r, kappa, kappa1)
     k = lab.RuntimeConstants(q, n, r, kappa, kappa1, kappa1)
     S, phi, a, tape = cases.make_inputs(p, seed=3)

@@ -3,7 +3,7 @@ Bit-exact integer work; every call goes through the C ABI."""
 import numpy as np
 import pytest
 
-from conftest import ALL_Q, Q_DEFAULT, Q_REF33, Q_DIRECT
+from conftest import ALL_Q, Q_DEFAULT, Q_REF33, Q_DIRECT, ctx_kw
 
 pytestmark = pytest.mark.gpu
 D = 64
@@ -162,7 +162,7 @@ def test_digit_basis_matvec_and_axpy(q, compact):
     # matrices times decomposition DIGITS in the smaller RNS basis (u16 last limb when compact): same exact result
     import labrador_snark_amd as lab
     from oracle import coracle as co
-    ctx = lab.Context(q, 0)
+    ctx = lab.Context(q, 0, **ctx_kw(q))
     bound = 1625
     nmat, rows, cols = 3, 9, 40
     primes, small, nbytes = ctx.enable_digit_basis(5000, bound)
@@ -259,7 +259,7 @@ def test_matvec_sum_batched_all_kernels(nb, rows, cols, nmat, compact):
     import labrador_snark_amd as lab
     from oracle import coracle as co
     q = Q_REF33
-    ctx = lab.Context(q, 0)
+    ctx = lab.Context(q, 0, **ctx_kw(q))
     bound = 1625
     ctx.enable_digit_basis(5000, bound)
     rng = np.random.default_rng(nb * 1000 + rows)
@@ -308,7 +308,7 @@ def test_axpy_commit_batched_all_kernels(nb, nterms, length, compact):
     import labrador_snark_amd as lab
     from oracle import coracle as co
     q = Q_REF33
-    ctx = lab.Context(q, 0)
+    ctx = lab.Context(q, 0, **ctx_kw(q))
     bound = 1625
     ctx.enable_digit_basis(5000, bound)
     rng = np.random.default_rng(nb * 7 + nterms)
@@ -338,7 +338,7 @@ def test_matvec_sum_mfma_digit_basis(ns, nmat, rows, cols, compact):
     import labrador_snark_amd as lab
     from oracle import coracle as co
     q = Q_REF33
-    ctx = lab.Context(q, 0)
+    ctx = lab.Context(q, 0, **ctx_kw(q))
     bound = 1625
     ctx.enable_digit_basis(5000, bound)
     rng = np.random.default_rng(ns + rows)
@@ -371,7 +371,7 @@ def test_matvec_sum_mfma_three_plane_basis(ns, nmat, rows, cols):
     import labrador_snark_amd as lab
     from oracle import coracle as co
     q = Q_REF33
-    ctx = lab.Context(q, 0)
+    ctx = lab.Context(q, 0, **ctx_kw(q))
     bound = 1625
     primes, small, nbytes = ctx.enable_digit_basis(5000, bound, mfma=True)
     assert not small and all(pr < (1 << 23) - 0x8080 and pr % 128 == 1 for pr in primes) and nbytes == 4 * len(primes)
@@ -409,6 +409,10 @@ def test_matvec_sum_mfma_main_basis_full_residues(contexts, q):
     M[0, :3] = q - 1
     V[1] = q - 1
     hM, hV = ctx.vec_from(M), ctx.vec_from(V)
+    if max(ctx.primes) - 1 > 2139127679:      # the single-limb strict-32 prime does not fit four signed byte planes: refused
+        with pytest.raises(lab.LabradorError):
+            lab.Mat8(ctx, hM, nmat, rows, cols)
+        return
     M8 = lab.Mat8(ctx, hM, nmat, rows, cols)
     got = lab.matvec_sum_mfma(ctx, M8, hV, ns).store().reshape(ns, rows, D)
     for b in range(ns):
@@ -456,7 +460,7 @@ def test_matvec_sum_mfma_prime_between_8355711_and_2p23():
     from oracle import coracle as co
     q = 8380417
     assert _signed_digits(q - 1, 3)[2] > 127          # the three-plane form would wrap its top digit
-    ctx = lab.Context(q, 0)
+    ctx = lab.Context(q, 0, **ctx_kw(q))
     assert ctx.nlimbs == 1 and ctx.primes == [q]
     rng = np.random.default_rng(23)
     ns, nmat, rows, cols = 8, 2, 40, 150
@@ -491,7 +495,7 @@ def test_matvec_sum_mfma_long_sums_three_plane_basis(K):
     import labrador_snark_amd as lab
     from oracle import coracle as co
     q = Q_REF33
-    ctx = lab.Context(q, 0, 1 << 17)
+    ctx = lab.Context(q, 0, 1 << 17, **ctx_kw(q))
     bound = 1625
     primes, _, _ = ctx.enable_digit_basis(1 << 17, bound, mfma=True)
     assert all(pr < (1 << 23) - 0x8080 for pr in primes)
@@ -548,7 +552,7 @@ def test_matvec_sum_mfma_long_sums_main_basis(K):
     import labrador_snark_amd as lab
     from oracle import coracle as co
     q = Q_REF33
-    ctx = lab.Context(q, 0, 1 << 17)
+    ctx = lab.Context(q, 0, 1 << 17, **ctx_kw(q))
     ns, rows = 64, 32
     lo = 63 * (1 << 24) - 128 * 65536 - 128 * 256 - 128
     hi = 62 * (1 << 24) + 127 * 65536 + 127 * 256 + 127

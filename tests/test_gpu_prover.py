@@ -6,7 +6,7 @@ import copy
 import numpy as np
 import pytest
 
-from conftest import ALL_Q, Q_DEFAULT, Q_REF33, Q_DIRECT, Q_NTT32
+from conftest import ALL_Q, Q_DEFAULT, Q_REF33, Q_DIRECT, Q_NTT32, ctx_kw
 
 import cases
 
@@ -153,7 +153,7 @@ def test_prove_and_verify_with_compact_crs(q, n, r, kappa, kappa1):
     # transcript is bit-identical to the oracle's and to the main-basis run, and the GPU verifier accepts it
     import copy
     import labrador_snark_amd as lab
-    ctx = lab.Context(q, 0)
+    ctx = lab.Context(q, 0, **ctx_kw(q))
     p = cases.Params(q, n, r, kappa, kappa1)
     case, (S, phi, a, tape) = cases.oracle_case(p, seed=21)
     want = case.prove()
@@ -188,7 +188,7 @@ def test_prove_core_batch_equals_separate_proofs(nb, kappa1, compact):
     # (kappa1 = 20 runs the LDS "sets" kernel in step 3, kappa1 >= 32 the lane=row kernel with the LDS-DMA ring)
     import labrador_snark_amd as lab
     q, n, r, kappa = Q_REF33, 4, 8, 64
-    ctx = lab.Context(q, 0)
+    ctx = lab.Context(q, 0, **ctx_kw(q))
     p = cases.Params(q, n, r, kappa, kappa1)
     k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
     crs = lab.ResidentCRS(ctx, k, compact=compact).fill_synthetic(1000)
@@ -222,7 +222,7 @@ def test_prove_core_batch_on_matrix_cores(nb, kappa1, compact):
     # sets): transcripts bit-identical to the VALU path and the oracle; B itself can be dropped afterwards
     import labrador_snark_amd as lab
     q, n, r, kappa = Q_REF33, 4, 8, 64
-    ctx = lab.Context(q, 0)
+    ctx = lab.Context(q, 0, **ctx_kw(q))
     p = cases.Params(q, n, r, kappa, kappa1)
     k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
     # "mfma23": B, C, D in the digit basis of primes below 2^23 (three byte planes, 3- and 6-wave GEMM blocks)
@@ -254,7 +254,7 @@ def test_digit_basis_ajtai_and_its_fallback():
     # the main basis — either way every transcript equals the multiply-add path's
     import labrador_snark_amd as lab
     q, n, r, kappa, kappa1 = Q_REF33, 4, 8, 64, 20
-    ctx = lab.Context(q, 0)
+    ctx = lab.Context(q, 0, **ctx_kw(q))
     p = cases.Params(q, n, r, kappa, kappa1)
     k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
     crs = lab.ResidentCRS(ctx, k, mfma_basis=True).fill_synthetic(1000)
@@ -292,7 +292,7 @@ def test_matrix_core_basis_with_other_moduli(q):
     # limb) and next to a small q: same transcripts as the multiply-add path, whichever basis step 1 ends up in
     import labrador_snark_amd as lab
     n, r, kappa, kappa1 = 4, 8, 64, 20
-    ctx = lab.Context(q, 0)
+    ctx = lab.Context(q, 0, **ctx_kw(q))
     p = cases.Params(q, n, r, kappa, kappa1)
     k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
     if k.T_1 < 1 or k.T_2 < 1 or k.B_1 < 2 or k.B_2 < 2:
@@ -318,7 +318,7 @@ def test_verifier_needs_the_unpacked_B():
     # a prover-only process may drop B after packing it for the matrix cores; lab_verify_core then refuses cleanly
     import labrador_snark_amd as lab
     q, n, r, kappa, kappa1 = Q_REF33, 4, 8, 64, 20
-    ctx = lab.Context(q, 0)
+    ctx = lab.Context(q, 0, **ctx_kw(q))
     p = cases.Params(q, n, r, kappa, kappa1)
     k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
     crs = lab.ResidentCRS(ctx, k, compact=True).fill_synthetic(1000)
@@ -341,7 +341,7 @@ def test_prove_core_batch_matrix_cores_r32(nb, mfma_basis):
     # (paired jobs), an odd number keeps one 32-set job per proof; both equal the multiply-add path and the oracle
     import labrador_snark_amd as lab
     q, n, r, kappa, kappa1 = Q_REF33, 6, 32, 40, 36
-    ctx = lab.Context(q, 0)
+    ctx = lab.Context(q, 0, **ctx_kw(q))
     p = cases.Params(q, n, r, kappa, kappa1)
     k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
     crs = lab.ResidentCRS(ctx, k, compact=True, mfma_basis=mfma_basis).fill_synthetic(1000)
@@ -385,7 +385,7 @@ def test_packed_pi_gives_the_same_transcript(q, n, r):
     # integer value is still produced); 256, 4160 (one full + one ragged 4096-column chunk) and 8192 columns
     import labrador_snark_amd as lab
     kappa, kappa1 = 8, 5
-    ctx = lab.Context(q, 0)
+    ctx = lab.Context(q, 0, **ctx_kw(q))
     p = cases.Params(q, n, r, kappa, kappa1)
     k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
     crs = lab.ResidentCRS(ctx, k).fill_synthetic(1000)
@@ -425,7 +425,7 @@ def test_packed_pi_on_the_norm_bounded_fast_path_and_its_fallback():
     # pass in the redone batch — both equal the int8 form
     import labrador_snark_amd as lab
     q, n, r, kappa, kappa1 = Q_REF33, 4, 8, 64, 20
-    ctx = lab.Context(q, 0)
+    ctx = lab.Context(q, 0, **ctx_kw(q))
     p = cases.Params(q, n, r, kappa, kappa1)
     k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
     crs = lab.ResidentCRS(ctx, k, mfma_basis=True).fill_synthetic(1000)
@@ -468,7 +468,7 @@ def test_state_gen_f_and_transcript_bytes_from_a_gpu_proof(q):
     from oracle import coracle as co
     from test_transcript import Reader
     n, r, kappa, kappa1 = 4, 3, 6, 5
-    ctx = lab.Context(q, 0)
+    ctx = lab.Context(q, 0, **ctx_kw(q))
     p = cases.Params(q, n, r, kappa, kappa1)
     k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
     S, _, _, tape = cases.make_inputs(p, seed=5)
