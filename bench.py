@@ -567,7 +567,49 @@ def side_measurements(lab, ctx, q, dev):
         c1.close()
     except Exception as e:  # never let a side measurement break the headline line
         out["outer_commitment_single_limb_q1073738753"] = {"error": str(e)}
+    # SURVEY section 8(d) "q: report both": the NTT-friendly 32-bit q = 4294966657 on path (b) (q its own NTT prime: one limb,
+    # 4 B per coefficient, strict-32 kernels) and on path (a) (LAB_CTX_RNS_ONLY: three 30-bit RNS limbs)
+    try:
+        out["q4294966657_both_paths"] = both_paths_q32(lab, dev)
+    except Exception as e:
+        out["q4294966657_both_paths"] = {"error": repr(e)}
     return out
+
+
+def both_paths_q32(lab, dev, q=4294966657, kappa=1024):
+    import torch
+    res = {"q": q, "workload": "n=1024 r=32 kappa=kappa1=kappa2=%d; one proof per call (B streamed on the multiply-add kernels)" % kappa}
+    n, r = 1024, 32
+    for name, rns in (("path_b_single_limb", False), ("path_a_rns", True)):
+        ctx = lab.Context(q, dev.index or 0, max(65536, n * r + r * r), rns_only=rns)
+        ctx.use_torch_stream()
+        k = lab.RuntimeConstants(q, n, r, kappa, kappa, kappa)
+        L = ctx.nlimbs
+        rec = {"limbs": L}
+        x = torch.randint(0, 1 << 29, (L, 1 << 20, D), dtype=torch.int32, device=dev)
+        tf = _time(lambda: ctx.ntt_forward(x, 1 << 20), 10)
+        ti = _time(lambda: ctx.ntt_inverse(x, 1 << 20), 10)
+        rec["ntt_batch_2p20"] = {"fwd_us": tf * 1e6, "inv_us": ti * 1e6, "polynomials_per_s": 2 * (1 << 20) / (tf + ti),
+                                 "algorithmic_GBps": 2 * L * (1 << 20) * 512 / (tf + ti) / 1e9}
+        del x
+        # the best single-proof configuration of each path: (b) B, C, D in the main basis = 4 B per coefficient; (a) B, C, D in
+        # the compact digit basis (10 B per coefficient)
+        dSs, sts, dtapes, crs = build_workload(lab, ctx, k, q, dev, 1, 50, 1000, use_mfma=False, basis23=False, compact=True)
+        step = lambda: lab.prove_core(ctx, k, dSs[0], sts[0], crs, dtapes[0], device_outputs=True)
+        step()
+        torch.cuda.synchronize()
+        ctx.profile_begin()
+        t = _time(step, 5, warm=1)
+        ms, launches, alg = ctx.profile_end()
+        rec["single_proof"] = {"proofs_per_s": 1.0 / t, "ms_per_proof": t * 1e3, "crs_bytes_per_coefficient": 4 * L if not crs.compact else None,
+                               "crs_basis": "digit basis %s" % getattr(ctx, "digit_primes", None) if crs.compact else "main basis (q itself)" if L == 1 else "main basis",
+                               "step3_kernel": ctx.profile_kernel(), "step3_launch_ms": ms / max(launches, 1),
+                               "step3_algorithmic_GBps": alg / max(launches, 1) / (ms / max(launches, 1) / 1e3) / 1e9 if launches else None}
+        crs.close()
+        ctx.close()
+        torch.cuda.synchronize()
+        res[name] = rec
+    return res
 
 
 if __name__ == "__main__":

@@ -175,7 +175,7 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
     if (prof) {
       LAB_HIP(c, hipEventRecord(c->prof_events[c->prof_used++].second, c->stream));
       char kname[48];
-      if (pl == 3 && waves == 4) snprintf(kname, sizeof kname, "k_gemm_i8_w3<%d>", (int)nt);
+      if (pl == 3 && waves == 4) snprintf(kname, sizeof kname, "k_gemm_i8_w3<%d, %d>", (int)nt, nt == 6 && njobs == 1 ? g.diag : 0);
       else snprintf(kname, sizeof kname, "k_gemm_i8<%d, %d>", (int)nt, waves);
       c->prof_kernel = kname;
       // the matrix digit planes once, the B-operand tiles once per 32-row block (from L2), the residues out
