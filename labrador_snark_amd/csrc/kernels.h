@@ -67,6 +67,7 @@ struct WideDot {
   int chunk_level;
   size_t ak, bk;
   const LimbTable* tab;
+  bool stream_a;           // A is read once (a CRS matrix): non-temporal loads
 };
 hipError_t launch_wide_dot(const WideDot& d, hipStream_t s);
 hipError_t launch_ntt(bool forward, ConstHatView src, HatView dst, size_t count, int nlimbs, const LimbTable* tabs,

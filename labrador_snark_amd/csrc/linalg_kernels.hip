@@ -893,6 +893,7 @@ static hipError_t launch_matvec_nb(int nb, uint32_t* partial, size_t partial_ps,
     d.as[1] = js; d.as[3] = rows * cols * D; d.as[4] = cols * D; d.ak = D;
     d.bs[1] = js; d.bs[2] = v_bs; d.bs[3] = cols * D; d.bk = D;
     d.K = d.Ktotal = (unsigned)cols; d.chunk_level = -1;
+    d.stream_a = nmat * rows * cols >= ((size_t)1 << 22);   // a matrix of 1 GiB or more is a stream, not a working set
     set_last_matvec_kernel("k_wide_dot");
     return launch_wide_dot(d, s);
   }
