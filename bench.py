@@ -143,6 +143,14 @@ def cpu_baseline(k, q, products_per_proof):
     res["b1_honest_fast"] = {kk: b1[kk] for kk in ("value", "s_per_proof", "cores", "rns_limbs", "crs_fill_s", "extrapolated")}
     res["b0_reference_faithful"] = b0
     res["config1_single_product"] = cpu_config1()
+    # SURVEY section 8(d) "q: report both": the same CPU prover at the NTT-friendly 32-bit q (one limb, like the GPU's path (b))
+    try:
+        import labrador_snark_amd as lab
+        q32 = 4294966657
+        b32 = cpu_baseline_b1(lab.RuntimeConstants(q32, k.N, k.R, k.KAPPA, k.KAPPA_1, k.KAPPA_2), q32)
+        res["b1_q4294966657_single_limb"] = {kk: b32[kk] for kk in ("value", "s_per_proof", "cores", "rns_limbs", "crs_fill_s", "bpp_check_ok")}
+    except Exception as e:
+        res["b1_q4294966657_single_limb"] = {"error": repr(e)}
     return res
 
 
