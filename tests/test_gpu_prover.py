@@ -363,6 +363,36 @@ def test_prove_core_batch_matrix_cores_r32(nb, mfma_basis):
     ctx.close()
 
 
+@pytest.mark.parametrize("r", [16, 17, 24, 31])
+@pytest.mark.parametrize("nb", [2, 3])
+def test_prove_core_batch_digit_basis_gram_products_ragged_r(nb, r):
+    # steps 6-8 and 10 from the digit-basis witness (phi'^T S and W^T S on the matrix cores from packed tiles, z from the
+    # digit-basis transform) for 17 <= r <= 32 columns (zero columns in the 32-wide tiles, ragged k tiles: n = 70), the
+    # multiply-add Gram kernels for r = 16: every field equals the multiply-add path and the oracle
+    import labrador_snark_amd as lab
+    q, n, kappa, kappa1 = Q_REF33, 70, 33, 36
+    ctx = lab.Context(q, 0)
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
+    crs = lab.ResidentCRS(ctx, k, compact=True, mfma_basis=True).fill_synthetic(1000)
+    ws, sts, tapes, wants = [], [], [], []
+    for j in range(nb):
+        case, (S, phi, a, tape) = cases.oracle_case(p, seed=900 + j)
+        ws.append(S); sts.append(lab.State(phi, a, case.b_prime)); tapes.append(tape)
+        wants.append(case.prove())
+    ref = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes)
+    crs.pack_mfma()
+    got = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes)
+    assert ctx.prove_flags() == 1                       # the digit-basis path ran (no fallback)
+    for j in range(nb):
+        for f in ("t_i_all", "g_mat", "h_mat", "u_1", "u_2", "z", "b_prime_prime", "projection_int"):
+            assert np.array_equal(getattr(got[j], f), getattr(ref[j], f)), (j, f)
+        w = wants[j]
+        assert np.array_equal(got[j].h_mat, w["H"]) and np.array_equal(got[j].z, w["z"]) and np.array_equal(got[j].b_prime_prime, w["bpp"])
+    crs.close()
+    ctx.close()
+
+
 def _pack_pi_numpy(Pi):
     """independent restatement of the tiled 2-bit layout (include/labrador_hip.h, lab_prove_input.Pi2), entry by entry"""
     mats, rows, cols = Pi.shape
