@@ -83,6 +83,37 @@ k_decompose(const JobPtrs outp, const JobPtrs inp, size_t nwords, uint64_t q, ui
   }
 }
 
+// The library-internal form (16-bit digits, base < 2^16 <= ... <= q) four coefficients per thread: 32 bytes in, one 8-byte
+// store per digit (the one-word-per-thread kernel above is bound by its 2-byte stores and its block count).
+__global__ void __launch_bounds__(256)
+k_decompose_u16x4(const JobPtrs outp, const JobPtrs inp, size_t nquads, uint64_t q, uint32_t b32, int exp, size_t group) {
+  uint16_t* __restrict__ out = static_cast<uint16_t*>(outp.p[blockIdx.y]);
+  const ulonglong2* __restrict__ in = static_cast<const ulonglong2*>(inp.p[blockIdx.y]);
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const uint64_t half = (b32 / 2) % q;
+  const uint32_t bm = (uint32_t)(0x100000000ull / b32);
+  for (; i < nquads; i += stride) {
+    const ulonglong2 lo = in[2 * i], hi = in[2 * i + 1];
+    uint64_t v[4] = {lo.x, lo.y, hi.x, hi.y};
+    const size_t w0 = i * 4;
+    const uint32_t e = (uint32_t)(w0 / D), g = (uint32_t)group, eg = e / g;
+    uint16_t* const o = out + ((size_t)eg * exp * g + (e - eg * g)) * D + w0 % D;
+    for (int k = 0; k < exp; k++) {
+      uint32_t r[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        uint64_t qq;
+        const uint32_t r0 = divmod_u40_u16((uint32_t)(v[c] >> 32), (uint32_t)v[c], b32, bm, &qq);
+        r[c] = r0 > half ? b32 - r0 : r0;
+        const uint64_t w = submod(v[c], r[c], q);
+        (void)divmod_u40_u16((uint32_t)(w >> 32), (uint32_t)w, b32, bm, &v[c]);
+      }
+      *reinterpret_cast<uint2*>(o + (size_t)k * g * D) = make_uint2(r[0] | (r[1] << 16), r[2] | (r[3] << 16));
+    }
+  }
+}
+
 hipError_t launch_decompose_jobs(const JobPtrs& out, const JobPtrs& in, size_t count, uint64_t q, uint64_t base, int exp,
                                  size_t group, size_t njobs, hipStream_t s, bool out_u16) {
   if (count == 0 || exp == 0 || njobs == 0) return hipSuccess;
@@ -93,6 +124,13 @@ hipError_t launch_decompose_jobs(const JobPtrs& out, const JobPtrs& in, size_t c
   const bool fast = base < 65536 && base <= q && q < (1ull << 40);
   const dim3 gr(blocks, (unsigned)njobs);
   if (out_u16 && base > 65536) return hipErrorInvalidValue;
+  if (out_u16 && fast) {
+    const size_t nquads = nwords / 4;
+    unsigned b4 = (unsigned)((nquads + 255) / 256);
+    if (b4 > 8192) b4 = 8192;
+    hipLaunchKernelGGL(k_decompose_u16x4, dim3(b4, (unsigned)njobs), dim3(256), 0, s, out, in, nquads, q, (uint32_t)base, exp, group);
+    return hipGetLastError();
+  }
 #define LAB_DEC(OT, F) hipLaunchKernelGGL((k_decompose<OT, F>), gr, dim3(256), 0, s, out, in, nwords, q, base, exp, group)
   if (out_u16) { if (fast) LAB_DEC(uint16_t, true); else LAB_DEC(uint16_t, false); }
   else { if (fast) LAB_DEC(uint64_t, true); else LAB_DEC(uint64_t, false); }
