@@ -6,7 +6,7 @@ import copy
 import numpy as np
 import pytest
 
-from conftest import Q_REF33, Q_DIRECT, ctx_kw
+from conftest import Q_REF33, Q_DIRECT, Q_NTT32, ctx_kw
 
 import cases
 
@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 D = 64
 
 
-@pytest.mark.parametrize("q", [Q_REF33, Q_DIRECT])
+@pytest.mark.parametrize("q", [Q_REF33, Q_DIRECT, Q_NTT32])
 def test_config2_batch_4096_forward_inverse_and_convolution(contexts, q):
     # configs[1]: 4096 d=64 forward+inverse NTTs: identity round trip; INTT(NTT a . NTT b) == oracle product
     import torch
@@ -38,7 +38,7 @@ def test_config2_batch_4096_forward_inverse_and_convolution(contexts, q):
     assert torch.equal(planes, ref)
 
 
-@pytest.mark.parametrize("q", [Q_REF33])
+@pytest.mark.parametrize("q", [Q_REF33, Q_NTT32])      # Q_NTT32: the single-limb strict-32 path (k_wide_dot)
 def test_config4_ajtai_2p14_x_2p10_linearity_and_spot_rows(contexts, q):
     # configs[3]: A = 2^14 x 2^10 ring elements resident in the transform domain (4 GiB per limb)
     import labrador_snark_amd as lab
@@ -67,20 +67,21 @@ def test_config4_ajtai_2p14_x_2p10_linearity_and_spot_rows(contexts, q):
     A.close()
 
 
-def test_config3_full_prover_n1024_r32_self_consistent(contexts):
+@pytest.mark.parametrize("q", [Q_REF33, Q_NTT32])      # Q_NTT32: SURVEY section 8(d) "q: report both", path (b)
+def test_config3_full_prover_n1024_r32_self_consistent(contexts, q):
     # configs[2]: full proof_gen at n = 1024, r = 32, kappa = kappa1 = kappa2 = 1024 (bench.py's workload, here
     # with kappa1 = kappa2 = 64 to keep the resident B at 3.75 GiB in the test): the GPU verifier's identities
     # (checks 8-9, 15-20 recomputed with independent kernels) accept it, tampering is caught, and a handful of
     # outputs are compared with the oracle.
     import labrador_snark_amd as lab
     from oracle import coracle as co
-    q, n, r, kappa, kappa1 = Q_REF33, 1024, 32, 1024, 64
+    n, r, kappa, kappa1 = 1024, 32, 1024, 64
     ctx = lab.Context(q, 0, 1 << 17, **ctx_kw(q))
     p = cases.Params(q, n, r, kappa, kappa1)
     k = lab.RuntimeConstants(q, n, r, kappa, kappa1, kappa1)
     S, phi, a, tape = cases.make_inputs(p, seed=3)
     crs = lab.ResidentCRS(ctx, k, compact=True).fill_synthetic(1000)
-    assert crs.B.compact
+    assert crs.B.compact == (ctx.nlimbs > 1)       # single-limb: B, C, D stay in the main basis (4 B per coefficient)
     # b' from the product's own kernels (src/structs.rs:320-341, 373)
     hS, hphi, ha = ctx.vec_from(S), ctx.vec_from(phi), ctx.vec_from(a)
     G = lab.gram(ctx, hS, hS, n, r).store()
