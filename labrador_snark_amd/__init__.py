@@ -7,5 +7,5 @@ from ._lib import (BppCheckFailed, JLRejected, LabradorError, LengthMismatch, No
                    load)
 from .api import *  # noqa: F401,F403
 from .api import Context, HatVec, D  # noqa: F401
-from .prover import (CRS, Prover, ResidentCRS, RuntimeConstants, State, Transcript, Verifier, fetch_challenge, gen_f_b, operator_norm, pack_pi, pack_pi_host, unpack_pi_host, prove_core, prove_core_batch,  # noqa: F401
+from .prover import (BatchPlan, CRS, Prover, ResidentCRS, RuntimeConstants, State, Transcript, Verifier, fetch_challenge, gen_f_b, operator_norm, pack_pi, pack_pi_host, unpack_pi_host, prove_core, prove_core_batch,  # noqa: F401
                      verify_core)  # noqa: F401

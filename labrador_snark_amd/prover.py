@@ -453,6 +453,40 @@ def prove_core_batch(ctx, k, witnesses, states, crs, tapes, device_outputs=False
     return [io[2] for io in ios], codes
 
 
+class BatchPlan:
+    """lab_prove_core_batch with the boundary structures built ONCE: the proofs' witness / state / tape arrays and the output
+    buffers are persistent (device tensors or host arrays the caller refills between runs), every run() proves what they hold
+    now and returns the same Transcript objects, overwritten.  What a prover service that reuses its buffers does; it takes
+    the per-call marshalling (0.4 ms for 64 proofs) out of the loop."""
+
+    def __init__(self, ctx, k, witnesses, states, crs, tapes, device_outputs=True):
+        self.ctx, self.nb = ctx, len(witnesses)
+        nb = self.nb
+        views = [None] * nb
+        if device_outputs:
+            import torch
+            big = {name: torch.empty((nb,) + shape, dtype=torch.int64, device="cuda") for name, shape in _out_shapes(k).items()}
+            base = [(big[name].data_ptr(), big[name][0].numel() * 8) for name in _OUT_FIELDS]
+            views = [(big, j, [p + j * step for p, step in base]) for j in range(nb)]
+        template = _io_template(k, crs)
+        self._keep = (witnesses, states, crs, tapes)          # the arrays the structures point into
+        self._ios = [_prove_io(ctx, k, witnesses[j], states[j], crs, tapes[j], device_outputs, views[j], template) for j in range(nb)]
+        self._pins = (C.POINTER(_lib.lab_prove_input) * nb)(*[C.pointer(io[0]) for io in self._ios])
+        self._trs = (C.POINTER(_lib.lab_transcript) * nb)(*[C.pointer(io[1]) for io in self._ios])
+        self._status = (C.c_int * nb)()
+        self.transcripts = [io[2] for io in self._ios]
+
+    def run(self, raise_on_reject=True):
+        ctx = self.ctx
+        ctx._check(ctx._lib.lab_prove_core_batch(ctx._h, self.nb, self._pins, self._trs, self._status))
+        if raise_on_reject:
+            for code in self._status:
+                if code:
+                    _lib.check(ctx._h, int(code))
+            return self.transcripts
+        return self.transcripts, [int(x) for x in self._status]
+
+
 def verify_core(ctx, k, st, b_poly, crs, T, tape=None):
     """Verifier::verify (src/verification.rs:25-438) on the GPU via lab_verify_core.
     Returns (failed_line, line14_sum): failed_line == 0 means the reference would return true, otherwise it is

@@ -393,6 +393,32 @@ def test_prove_core_batch_digit_basis_gram_products_ragged_r(nb, r):
     ctx.close()
 
 
+def test_batch_plan_reuses_its_buffers():
+    # lab.BatchPlan: the boundary structures built once; run() proves what the persistent buffers hold NOW
+    import labrador_snark_amd as lab
+    q, n, r, kappa, kappa1 = Q_REF33, 6, 3, 8, 5
+    ctx = lab.Context(q, 0)
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
+    crs = lab.ResidentCRS(ctx, k).fill_synthetic(1000)
+    ws, sts, tapes = [], [], []
+    for j in range(3):
+        case, (S, phi, a, tape) = cases.oracle_case(p, seed=700 + j)
+        ws.append(np.ascontiguousarray(S)); sts.append(lab.State(phi, a, case.b_prime)); tapes.append(tape)
+    plan = lab.BatchPlan(ctx, k, ws, sts, crs, tapes, device_outputs=False)
+    fields = ("t_i_all", "g_mat", "h_mat", "u_1", "u_2", "z", "b_prime_prime", "projection_int")
+    for rounds in range(2):
+        got, codes = plan.run(raise_on_reject=False)
+        ref, rcodes = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes, raise_on_reject=False)
+        assert codes == rcodes
+        for j in range(3):
+            for f in fields:
+                assert np.array_equal(getattr(got[j], f), getattr(ref[j], f)), (rounds, j, f)
+        ws[1][0, 0, :] = (ws[1][0, 0, :] + 1) % 3          # refill a witness buffer in place; b' no longer matches: status only
+    crs.close()
+    ctx.close()
+
+
 def _pack_pi_numpy(Pi):
     """independent restatement of the tiled 2-bit layout (include/labrador_hip.h, lab_prove_input.Pi2), entry by entry"""
     mats, rows, cols = Pi.shape
