@@ -251,6 +251,7 @@ extern "C" void lab_ctx_destroy(lab_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& ev : c->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (c->scratch) (void)hipFree(c->scratch);
+  if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->d_tabs) (void)hipFree(c->d_tabs);
   if (c->d_crt) (void)hipFree(c->d_crt);
   if (c->dg_tabs) (void)hipFree(c->dg_tabs);

@@ -29,6 +29,8 @@ struct lab_ctx {
   // growable device scratch, carved per call
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  uint64_t* pinned = nullptr;      // page-locked host words for the small device-to-host copies that end a call (grown on demand)
+  size_t pinned_words = 0;
   mutable std::string err;
   // digit basis (lab_ctx_enable_digit_basis): RNS basis for reductions whose vector operand is a decomposition
   // digit (< dg_vmax): dg_nlimbs limbs = a prefix of the main primes plus, when dg_small, one prime < 2^16 whose

@@ -545,10 +545,17 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   }
 
   // ================= copy-out and the two verifier callbacks that can reject
-  std::vector<uint64_t> hst(np * (256 + 256 + D + 1));
-  const int64_t* hproj = reinterpret_cast<const int64_t*>(hst.data());
-  const uint64_t* homega = hst.data() + np * 256;
-  const uint64_t* hbpp_st = hst.data() + np * 512;
+  const size_t hst_words = np * (256 + 256 + D + 1);
+  if (c->pinned_words < hst_words) {   // page-locked: the copy is one DMA, not a staged pageable transfer
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    c->pinned = nullptr; c->pinned_words = 0;
+    LAB_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->pinned), hst_words * 8, hipHostMallocDefault));
+    c->pinned_words = hst_words;
+  }
+  uint64_t* const hst = c->pinned;
+  const int64_t* hproj = reinterpret_cast<const int64_t*>(hst);
+  const uint64_t* homega = hst + np * 256;
+  const uint64_t* hbpp_st = hst + np * 512;
   LAB_HIP(c, launch_gather_jobs(host_stage + np * 256, JP(&Job::domega), 256, np, s));
   LAB_HIP(c, launch_gather_jobs(host_stage + np * 512, JP(&Job::cbpp), D, np, s));
   {  // integer projections to device-resident caller buffers (host ones are filled from the staged copy below)
@@ -570,10 +577,10 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     for (auto& e : cp)   // results produced in place (device-resident caller buffers) need no copy
       if (e.dst && e.dst != e.src) LAB_HIP(c, hipMemcpyAsync(e.dst, e.src, e.words * 8, hipMemcpyDefault, s));
   }
-  LAB_HIP(c, hipMemcpyAsync(hst.data(), host_stage, hst.size() * 8, hipMemcpyDeviceToHost, s));
+  LAB_HIP(c, hipMemcpyAsync(hst, host_stage, hst_words * 8, hipMemcpyDeviceToHost, s));
   LAB_HIP(c, hipStreamSynchronize(s));
   if (a8d) {   // a witness above the declared norm bound: step 1 may have left the CRT range; redo the batch in the main basis
-    const uint64_t* hnorm = hst.data() + np * (256 + 256 + D);
+    const uint64_t* hnorm = hst + np * (256 + 256 + D);
     bool over = false;
     for (size_t j = 0; j < np; j++) over = over || hnorm[j] > norm_limit;
     if (over) {
