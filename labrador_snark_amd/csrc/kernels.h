@@ -85,8 +85,10 @@ hipError_t launch_to_hat_fused(const JobPtrs& coeffs, HatView dst, size_t dst_js
                                unsigned long long* norm_sum = nullptr /* [njobs], += saturating sum of squares */, uint64_t norm_limit = 0,
                                bool src_u16 = false /* coefficients are 16-bit words (digits from launch_decompose_jobs) */);
 hipError_t launch_crt_to_u64(ConstHatView src, uint64_t* coeffs, size_t count, const CrtTable* crt, int nlimbs, hipStream_t s);
+// decomposition digits written by the CRT pass itself: out16.p[job] as launch_decompose_jobs(.., out_u16 = true) lays them out
+struct CrtDigits { JobPtrs out16; uint32_t base; int exp; size_t group; uint64_t q; };
 hipError_t launch_crt_to_u64_jobs(ConstHatView src, size_t src_js, const JobPtrs& coeffs, size_t count, const CrtTable* crt,
-                                  int nlimbs, size_t njobs, hipStream_t s);
+                                  int nlimbs, size_t njobs, hipStream_t s, const CrtDigits* dg = nullptr);
 hipError_t launch_synth_fill_u64(uint64_t* coeffs, size_t count, uint64_t seed, uint64_t first_elem, uint64_t bound,
                                  hipStream_t s);
 

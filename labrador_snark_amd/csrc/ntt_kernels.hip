@@ -376,41 +376,77 @@ __device__ __forceinline__ uint64_t crt_one(const uint32_t (&r)[L], const CrtTab
   return acc;
 }
 
-template <int L>
+// Four coefficients per thread (16-byte loads per limb, 32 bytes out).  DIG: the value is also decomposed on the spot
+// (decompose_polynomial_vec, src/util.rs:360-442, in the library-internal form of k_decompose_u16x4: 16-bit digits, base below
+// 2^16 and not above q) — the digits of t = A s leave with t itself, its coefficients are not read back.
+template <int L, bool DIG>
 __global__ void __launch_bounds__(256)
-k_crt_to_u64(const uint32_t* __restrict__ src, size_t src_ps, const JobPtrs dstp, size_t nwords,
-             const CrtTable* __restrict__ crt, size_t src_js) {
+k_crt_to_u64(const uint32_t* __restrict__ src, size_t src_ps, const JobPtrs dstp, size_t nquads,
+             const CrtTable* __restrict__ crt, size_t src_js, const CrtDigits dg) {
   uint64_t* __restrict__ coeffs = static_cast<uint64_t*>(dstp.p[blockIdx.y]);
+  uint16_t* __restrict__ digits = DIG ? static_cast<uint16_t*>(dg.out16.p[blockIdx.y]) : nullptr;
   src += (size_t)blockIdx.y * src_js;
   const uint64_t q = crt->q;
   const double inv_q = crt->inv_q;
-  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
-  const size_t stride = (size_t)gridDim.x * blockDim.x * 2;
-  for (; i < nwords; i += stride) {   // nwords is a multiple of 64: the pair (i, i+1) is always in range
-    uint32_t r0[L], r1[L];
+  const uint32_t b32 = dg.base, bm = DIG ? (uint32_t)(0x100000000ull / dg.base) : 0;
+  const uint64_t half = DIG ? (dg.base / 2) % q : 0;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < nquads; i += stride) {
+    uint32_t r[4][L];
 #pragma unroll
     for (int l = 0; l < L; l++) {
-      typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-      const u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(src + (size_t)l * src_ps + i));
-      r0[l] = v.x; r1[l] = v.y;
+      typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+      const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(src + (size_t)l * src_ps) + i);
+      r[0][l] = v.x; r[1][l] = v.y; r[2][l] = v.z; r[3][l] = v.w;
     }
-    ulonglong2 o;
-    o.x = crt_one<L>(r0, crt, q, inv_q);
-    o.y = crt_one<L>(r1, crt, q, inv_q);
-    *reinterpret_cast<ulonglong2*>(coeffs + i) = o;
+    uint64_t v[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) v[c] = crt_one<L>(r[c], crt, q, inv_q);
+    ulonglong2 o0, o1;
+    o0.x = v[0]; o0.y = v[1]; o1.x = v[2]; o1.y = v[3];
+    reinterpret_cast<ulonglong2*>(coeffs)[2 * i] = o0;
+    reinterpret_cast<ulonglong2*>(coeffs)[2 * i + 1] = o1;
+    if constexpr (DIG) {
+      const size_t w0 = i * 4;
+      const uint32_t e = (uint32_t)(w0 / D), g = (uint32_t)dg.group, eg = e / g;
+      uint16_t* const o = digits + ((size_t)eg * dg.exp * g + (e - eg * g)) * D + w0 % D;
+      for (int k = 0; k < dg.exp; k++) {
+        uint32_t d[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          // v = qq*b + r0.  The reference continues with (v - r) / b, r = r0 or b - r0: that is qq in both cases (r0 > b/2 gives
+          // (qq - 1)*b + 2*r0 with b < 2*r0 < 2b), and v - r never wraps mod q here (base <= q): one division per digit
+          uint64_t qq;
+          const uint32_t r0 = divmod_u40_u16((uint32_t)(v[c] >> 32), (uint32_t)v[c], b32, bm, &qq);
+          d[c] = r0 > half ? b32 - r0 : r0;
+          v[c] = qq;
+        }
+        *reinterpret_cast<uint2*>(o + (size_t)k * g * D) = make_uint2(d[0] | (d[1] << 16), d[2] | (d[3] << 16));
+      }
+    }
   }
 }
 
+// dg (optional): also write the decomposition digits of every value (see CrtDigits in kernels.h); returns
+// hipErrorNotSupported when the digits do not have the 16-bit fast form
 hipError_t launch_crt_to_u64_jobs(ConstHatView src, size_t src_js, const JobPtrs& coeffs, size_t count, const CrtTable* crt,
-                                  int nlimbs, size_t njobs, hipStream_t s) {
+                                  int nlimbs, size_t njobs, hipStream_t s, const CrtDigits* dg) {
   if (count == 0 || njobs == 0) return hipSuccess;
-  if ((src.plane_stride | src_js) & 1) return hipErrorInvalidValue;
-  size_t nwords = count * D;
-  unsigned blocks = (unsigned)((nwords / 2 + 255) / 256);
+  if ((src.plane_stride | src_js) & 3) return hipErrorInvalidValue;
+  if (dg && (dg->base >= 65536 || dg->base < 2 || (uint64_t)dg->base > dg->q || dg->q >= (1ull << 40) || dg->group == 0 || dg->exp <= 0 ||
+             count >> 32 || dg->group >> 32))
+    return hipErrorNotSupported;
+  const size_t nquads = count * D / 4;
+  unsigned blocks = (unsigned)((nquads + 255) / 256);
   if (blocks > 16384) blocks = 16384;
   const dim3 g(blocks, (unsigned)njobs);
-#define LAB_CRT_CASE(LL) \
-  case LL: hipLaunchKernelGGL(k_crt_to_u64<LL>, g, dim3(256), 0, s, src.base, src.plane_stride, coeffs, nwords, crt, src_js); break;
+  CrtDigits none{};
+#define LAB_CRT_CASE(LL)                                                                                                             \
+  case LL:                                                                                                                           \
+    if (dg) hipLaunchKernelGGL((k_crt_to_u64<LL, true>), g, dim3(256), 0, s, src.base, src.plane_stride, coeffs, nquads, crt, src_js, *dg); \
+    else hipLaunchKernelGGL((k_crt_to_u64<LL, false>), g, dim3(256), 0, s, src.base, src.plane_stride, coeffs, nquads, crt, src_js, none); \
+    break;
   switch (nlimbs) {
     LAB_CRT_CASE(1) LAB_CRT_CASE(2) LAB_CRT_CASE(3) LAB_CRT_CASE(4)
     default: return hipErrorInvalidValue;
@@ -422,7 +458,7 @@ hipError_t launch_crt_to_u64_jobs(ConstHatView src, size_t src_js, const JobPtrs
 hipError_t launch_crt_to_u64(ConstHatView src, uint64_t* coeffs, size_t count, const CrtTable* crt, int nlimbs, hipStream_t s) {
   JobPtrs t;
   t.p[0] = coeffs;
-  return launch_crt_to_u64_jobs(src, 0, t, count, crt, nlimbs, 1, s);
+  return launch_crt_to_u64_jobs(src, 0, t, count, crt, nlimbs, 1, s, nullptr);
 }
 
 __global__ void __launch_bounds__(256)

@@ -14,31 +14,12 @@ __device__ __forceinline__ uint64_t mulmod40(uint64_t a, uint64_t b, uint64_t q)
   t = (t << 20) % q;
   return (t + a * (b & 0xFFFFF)) % q;        // < 2^61
 }
-__device__ __forceinline__ uint64_t addmod(uint64_t a, uint64_t b, uint64_t q) { uint64_t s = a + b; return s >= q ? s - q : s; }
-__device__ __forceinline__ uint64_t submod(uint64_t a, uint64_t b, uint64_t q) { return a >= b ? a - b : a + q - b; }
-
 // ---- decompose_polynomial_vec, bug-compatible (src/util.rs:360-442):
 // per coefficient v: while v != 0 { r0 = v % b; r = r0 > b/2 ? (b - r0) % b : r0; push r; v = (v - r)/b }
 // digits are non-negative (the centred sign is lost), digits past `exp` dropped.
 // Output element (e, digit k) goes to index ((e/group)*exp + k)*group + e%group:
 // group = count gives the reference's [exp][count] layout, group = 1 gives
 // [count][exp], group = kappa gives [i][k][rho] for the t_i decomposition.
-// x = hi*2^32 + lo < 2^40 divided by b < 2^16 in 32-bit arithmetic: two steps of long division in base 2^16, each a
-// multiply-high by m = floor(2^32 / b) (underestimates the quotient by at most 2) and two conditional corrections.
-// Returns the remainder; *quot = floor(x / b).
-__device__ __forceinline__ uint32_t divmod_u40_u16(uint32_t hi, uint32_t lo, uint32_t b, uint32_t m, uint64_t* quot) {
-  const uint32_t t1 = (hi << 16) | (lo >> 16);            // < 2^24
-  uint32_t q1 = __umulhi(t1, m), r1 = t1 - q1 * b;
-  { const bool f = r1 >= b; r1 -= f ? b : 0; q1 += f; }
-  { const bool f = r1 >= b; r1 -= f ? b : 0; q1 += f; }
-  const uint32_t t2 = (r1 << 16) | (lo & 0xFFFFu);        // < b * 2^16 <= 2^32
-  uint32_t q2 = __umulhi(t2, m), r2 = t2 - q2 * b;
-  { const bool f = r2 >= b; r2 -= f ? b : 0; q2 += f; }
-  { const bool f = r2 >= b; r2 -= f ? b : 0; q2 += f; }
-  *quot = ((uint64_t)q1 << 16) + q2;
-  return r2;
-}
-
 // OT = uint16_t: digits (< base <= 2^16) stored as 16-bit words for consumers inside the library (to_hat of the digits)
 // FAST: base < 2^16 and base <= q — all quotients by `base` in 32-bit integer arithmetic (divmod_u40_u16)
 template <typename OT, bool FAST>
@@ -103,11 +84,12 @@ k_decompose_u16x4(const JobPtrs outp, const JobPtrs inp, size_t nquads, uint64_t
       uint32_t r[4];
 #pragma unroll
       for (int c = 0; c < 4; c++) {
+        // v = qq*b + r0.  The reference continues with (v - r) / b, r = r0 or b - r0: that is qq in both cases (r0 > b/2 gives
+        // (qq - 1)*b + 2*r0 with b < 2*r0 < 2b), and v - r never wraps mod q here (base <= q): one division per digit
         uint64_t qq;
         const uint32_t r0 = divmod_u40_u16((uint32_t)(v[c] >> 32), (uint32_t)v[c], b32, bm, &qq);
         r[c] = r0 > half ? b32 - r0 : r0;
-        const uint64_t w = submod(v[c], r[c], q);
-        (void)divmod_u40_u16((uint32_t)(w >> 32), (uint32_t)w, b32, bm, &v[c]);
+        v[c] = qq;
       }
       *reinterpret_cast<uint2*>(o + (size_t)k * g * D) = make_uint2(r[0] | (r[1] << 16), r[2] | (r[3] << 16));
     }

@@ -336,7 +336,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   // ================= step 1 (src/proofgen.rs:41-49): t_i = A s_i for every column of every proof; A is shared, so the
   // whole batch is one (kappa x n)(n x np*r) product (falls back to one launch per proof for shapes it does not take)
   uint64_t* norm_sums = host_stage + np * (256 + 256 + D);
-  bool t_in_dense = false, g_in_digit = false;
+  bool t_in_dense = false, g_in_digit = false, t_digits_done = false;
   if (a8d) {  // matrix cores, in the basis of B, C, D (see a8d above): S once more into that basis, its norm summed on the way
     LAB_HIP(c, hipMemsetAsync(norm_sums, 0, np * 8, s));
     // (coefficients above beta_bound are caught by the norm sum and the batch is redone: the transform may assume the bound)
@@ -372,7 +372,15 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   }
   if (t_in_dense) {   // the inverse transform already ran from the GEMM's staging array: only the CRT is left
     const int basis = a8d ? bdig : 0;
-    LAB_HIP(c, launch_crt_to_u64_jobs(HatView{dense_tmp, rk * D}, tmp_js, JP(&Job::cT), rk, basis_crt(c, basis), basis_nlimbs(c, basis), np, s));
+    // ... and the decomposition of t (its digits in [i][k][rho] order), in the same pass when they have the 16-bit form
+    CrtDigits dg{JP(&Job::cTdec), (uint32_t)in->b1, t1, kappa, q};
+    hipError_t e = dig16 ? launch_crt_to_u64_jobs(HatView{dense_tmp, rk * D}, tmp_js, JP(&Job::cT), rk, basis_crt(c, basis),
+                                                  basis_nlimbs(c, basis), np, s, &dg)
+                         : hipErrorNotSupported;
+    if (e == hipSuccess) t_digits_done = true;
+    else if (e == hipErrorNotSupported)
+      LAB_HIP(c, launch_crt_to_u64_jobs(HatView{dense_tmp, rk * D}, tmp_js, JP(&Job::cT), rk, basis_crt(c, basis), basis_nlimbs(c, basis), np, s));
+    else LAB_HIP(c, e);
   } else if ((rc = a8d ? from_hat_jobs(hTd, rk, JP(&Job::cT), true) : from_hat_jobs(hT, rk, JP(&Job::cT), false))) {
     return rc;
   }
@@ -385,7 +393,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     if ((rc = from_hat_jobs(hG, rr, JP(&Job::cG), false))) return rc;
   }
   // digits of t in [i][k][rho] order, into the basis of B
-  LAB_HIP(c, launch_decompose_jobs(JP(&Job::cTdec), JP(&Job::cT), rk, q, (uint64_t)in->b1, t1, kappa, np, s, dig16));
+  if (!t_digits_done) LAB_HIP(c, launch_decompose_jobs(JP(&Job::cTdec), JP(&Job::cT), rk, q, (uint64_t)in->b1, t1, kappa, np, s, dig16));
   if (!fuse_t && (rc = to_hat_jobs(JP(&Job::cTdec), hTdec, rk * t1, true, (uint64_t)in->b1, dig16))) return rc;
 
   // ================= step 3 (:101-132) for the whole batch: lhs_j = sum_{i,k} B_ik t_{j,i}^(k); B streamed once per group

@@ -389,4 +389,26 @@ __device__ __forceinline__ uint32_t reduce_small16(uint32_t hi8, uint32_t lo, ui
   return csub(csub(s, 2 * p), p);
 }
 
+// ---- mod-q helpers of the coefficient-domain kernels (q < 2^40)
+__device__ __forceinline__ uint64_t addmod(uint64_t a, uint64_t b, uint64_t q) { uint64_t s = a + b; return s >= q ? s - q : s; }
+__device__ __forceinline__ uint64_t submod(uint64_t a, uint64_t b, uint64_t q) { return a >= b ? a - b : a + q - b; }
+
+
+// x = hi*2^32 + lo < 2^40 divided by b < 2^16 in 32-bit arithmetic: two steps of long division in base 2^16, each a
+// multiply-high by m = floor(2^32 / b) (underestimates the quotient by at most 2) and two conditional corrections.
+// Returns the remainder; *quot = floor(x / b).
+__device__ __forceinline__ uint32_t divmod_u40_u16(uint32_t hi, uint32_t lo, uint32_t b, uint32_t m, uint64_t* quot) {
+  const uint32_t t1 = (hi << 16) | (lo >> 16);            // < 2^24
+  uint32_t q1 = __umulhi(t1, m), r1 = t1 - q1 * b;
+  { const bool f = r1 >= b; r1 -= f ? b : 0; q1 += f; }
+  { const bool f = r1 >= b; r1 -= f ? b : 0; q1 += f; }
+  const uint32_t t2 = (r1 << 16) | (lo & 0xFFFFu);        // < b * 2^16 <= 2^32
+  uint32_t q2 = __umulhi(t2, m), r2 = t2 - q2 * b;
+  { const bool f = r2 >= b; r2 -= f ? b : 0; q2 += f; }
+  { const bool f = r2 >= b; r2 -= f ? b : 0; q2 += f; }
+  *quot = ((uint64_t)q1 << 16) + q2;
+  return r2;
+}
+
+
 }  // namespace lab
