@@ -22,57 +22,89 @@ struct CrsSeed {
   a += b; d ^= a; d = __builtin_rotateleft32(d, 8);               \
   c += d; b ^= c; b = __builtin_rotateleft32(b, 7);
 
-__global__ void __launch_bounds__(256)
+// One ChaCha20 block of the generator seeded with base + offset + i (block counter `counter`), and rand's draws from it:
+// candidate d = words 4d .. 4d+3.  Returns true (and the value) at the first accepted candidate.
+__device__ __forceinline__ bool crs_block_draw(const CrsSeed& base, uint64_t off_lo, uint64_t off_hi, uint64_t i, uint32_t counter, uint64_t q,
+                                               uint64_t zone_lo, uint64_t zone_hi, uint64_t* result) {
+  // seed = base + offset + i  (256-bit big-endian arithmetic, wraps at 2^256 like increment_seed)
+  const uint64_t add_lo = off_lo + i;
+  const uint64_t add_hi = off_hi + (add_lo < off_lo ? 1 : 0);
+  const uint32_t addw[4] = {(uint32_t)add_lo, (uint32_t)(add_lo >> 32), (uint32_t)add_hi, (uint32_t)(add_hi >> 32)};
+  uint32_t key[8];
+  uint32_t carry = 0;
+#pragma unroll
+  for (int w = 7; w >= 0; w--) {
+    const uint64_t s = (uint64_t)base.limb[w] + (w >= 4 ? addw[7 - w] : 0u) + carry;
+    carry = (uint32_t)(s >> 32);
+    // the seed BYTES are the big-endian integer; ChaCha's key words are little-endian words of those bytes
+    key[w] = __builtin_bswap32((uint32_t)s);
+  }
+  uint32_t x0 = 0x61707865u, x1 = 0x3320646eu, x2 = 0x79622d32u, x3 = 0x6b206574u;
+  uint32_t x4 = key[0], x5 = key[1], x6 = key[2], x7 = key[3], x8 = key[4], x9 = key[5], x10 = key[6], x11 = key[7];
+  uint32_t x12 = counter, x13 = 0, x14 = 0, x15 = 0;
+#pragma unroll
+  for (int rnd = 0; rnd < 10; rnd++) {
+    LAB_QR(x0, x4, x8, x12) LAB_QR(x1, x5, x9, x13) LAB_QR(x2, x6, x10, x14) LAB_QR(x3, x7, x11, x15)
+    LAB_QR(x0, x5, x10, x15) LAB_QR(x1, x6, x11, x12) LAB_QR(x2, x7, x8, x13) LAB_QR(x3, x4, x9, x14)
+  }
+  const uint32_t blk[16] = {x0 + 0x61707865u, x1 + 0x3320646eu, x2 + 0x79622d32u, x3 + 0x6b206574u,
+                            x4 + key[0], x5 + key[1], x6 + key[2], x7 + key[3],
+                            x8 + key[4], x9 + key[5], x10 + key[6], x11 + key[7],
+                            x12 + counter, x13, x14, x15};
+  bool done = false;
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    if (!done) {
+      const uint64_t x = (uint64_t)blk[4 * d] | ((uint64_t)blk[4 * d + 1] << 32);      // first next_u64()
+      const uint64_t y = (uint64_t)blk[4 * d + 2] | ((uint64_t)blk[4 * d + 3] << 32);  // second: high half
+      // (y*2^64 + x) * q as 256 bits; q < 2^40 (each 64 x 64 product once: its low and high words share the partial products)
+      const unsigned __int128 pa = (unsigned __int128)x * q, pb = (unsigned __int128)y * q;
+      const uint64_t a_lo = (uint64_t)pa, a_hi = (uint64_t)(pa >> 64), b_lo = (uint64_t)pb, b_hi = (uint64_t)(pb >> 64);
+      const uint64_t t = a_hi + b_lo;
+      const uint64_t c = t < a_hi ? 1 : 0;
+      const uint64_t lo_lo = a_lo, lo_hi = t, hi = b_hi + c;
+      const bool ok = (lo_hi < zone_hi) || (lo_hi == zone_hi && lo_lo <= zone_lo);
+      if (ok) { *result = hi; done = true; }
+    }
+  }
+  return done;
+}
+
+// Block = 1024 coefficients per pass.  Every thread computes the FIRST block of its generator; one block holds four candidates
+// and a candidate is rejected with probability up to 1/2 (the 33-bit q), so about one coefficient in 16 needs a second block —
+// i.e. nearly every 64-lane wave would have to run it.  The rejected coefficients of CRS_GROUP passes are therefore queued in
+// LDS and worked off together by as many threads as there are entries (further blocks of those generators only): ~6 %
+// extra block computations instead of ~100 %, and the queue phase keeps about half of the block's waves busy.
+constexpr int CRS_BLOCK = 1024, CRS_GROUP = 8;
+__global__ void __launch_bounds__(CRS_BLOCK)
 k_crs_expand(uint64_t* __restrict__ out, size_t nwords, CrsSeed base, uint64_t off_lo, uint64_t off_hi, uint64_t q,
              uint64_t zone_lo, uint64_t zone_hi) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < nwords; i += stride) {
-    // seed = base + offset + i  (256-bit big-endian arithmetic, wraps at 2^256 like increment_seed)
-    uint64_t add_lo = off_lo + (uint64_t)i;
-    uint64_t add_hi = off_hi + (add_lo < off_lo ? 1 : 0);
-    const uint32_t addw[4] = {(uint32_t)add_lo, (uint32_t)(add_lo >> 32), (uint32_t)add_hi, (uint32_t)(add_hi >> 32)};
-    uint32_t key[8];
-    uint32_t carry = 0;
-#pragma unroll
-    for (int w = 7; w >= 0; w--) {
-      const uint64_t s = (uint64_t)base.limb[w] + (w >= 4 ? addw[7 - w] : 0u) + carry;
-      carry = (uint32_t)(s >> 32);
-      // the seed BYTES are the big-endian integer; ChaCha's key words are little-endian words of those bytes
-      key[w] = __builtin_bswap32((uint32_t)s);
-    }
-    uint64_t result = 0;
-    bool done = false;
-    for (uint32_t counter = 0; !done; counter++) {
-      uint32_t x0 = 0x61707865u, x1 = 0x3320646eu, x2 = 0x79622d32u, x3 = 0x6b206574u;
-      uint32_t x4 = key[0], x5 = key[1], x6 = key[2], x7 = key[3], x8 = key[4], x9 = key[5], x10 = key[6], x11 = key[7];
-      uint32_t x12 = counter, x13 = 0, x14 = 0, x15 = 0;
-#pragma unroll
-      for (int rnd = 0; rnd < 10; rnd++) {
-        LAB_QR(x0, x4, x8, x12) LAB_QR(x1, x5, x9, x13) LAB_QR(x2, x6, x10, x14) LAB_QR(x3, x7, x11, x15)
-        LAB_QR(x0, x5, x10, x15) LAB_QR(x1, x6, x11, x12) LAB_QR(x2, x7, x8, x13) LAB_QR(x3, x4, x9, x14)
-      }
-      const uint32_t blk[16] = {x0 + 0x61707865u, x1 + 0x3320646eu, x2 + 0x79622d32u, x3 + 0x6b206574u,
-                                x4 + key[0], x5 + key[1], x6 + key[2], x7 + key[3],
-                                x8 + key[4], x9 + key[5], x10 + key[6], x11 + key[7],
-                                x12 + counter, x13, x14, x15};
-#pragma unroll
-      for (int d = 0; d < 4; d++) {
-        if (!done) {
-          const uint64_t x = (uint64_t)blk[4 * d] | ((uint64_t)blk[4 * d + 1] << 32);      // first next_u64()
-          const uint64_t y = (uint64_t)blk[4 * d + 2] | ((uint64_t)blk[4 * d + 3] << 32);  // second: high half
-          // (y*2^64 + x) * q as 256 bits; q < 2^40
-          const uint64_t a_lo = x * q, a_hi = __umul64hi(x, q);
-          const uint64_t b_lo = y * q, b_hi = __umul64hi(y, q);
-          const uint64_t t = a_hi + b_lo;
-          const uint64_t c = t < a_hi ? 1 : 0;
-          const uint64_t lo_lo = a_lo, lo_hi = t, hi = b_hi + c;
-          const bool ok = (lo_hi < zone_hi) || (lo_hi == zone_hi && lo_lo <= zone_lo);
-          if (ok) { result = hi; done = true; }
-        }
+  __shared__ uint32_t queue[CRS_GROUP * CRS_BLOCK];      // (pass of the group << 10) | thread: room for every coefficient
+  __shared__ uint32_t qlen;
+  const size_t pass_stride = (size_t)gridDim.x * CRS_BLOCK;
+  for (size_t g0 = (size_t)blockIdx.x * CRS_BLOCK; g0 < nwords; g0 += pass_stride * CRS_GROUP) {
+    if (threadIdx.x == 0) qlen = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int g = 0; g < CRS_GROUP; g++) {
+      const size_t i = g0 + g * pass_stride + threadIdx.x;
+      if (i < nwords) {
+        uint64_t r;
+        if (crs_block_draw(base, off_lo, off_hi, (uint64_t)i, 0, q, zone_lo, zone_hi, &r)) out[i] = r;
+        else queue[atomicAdd(&qlen, 1u)] = ((uint32_t)g << 10) | threadIdx.x;
       }
     }
-    out[i] = result;
+    __syncthreads();
+    const uint32_t m = qlen;
+    for (uint32_t e = threadIdx.x; e < m; e += CRS_BLOCK) {
+      const uint32_t ent = queue[e];
+      const size_t k = g0 + (size_t)(ent >> 10) * pass_stride + (ent & 1023u);
+      uint64_t r = 0;
+      for (uint32_t counter = 1;; counter++)
+        if (crs_block_draw(base, off_lo, off_hi, (uint64_t)k, counter, q, zone_lo, zone_hi, &r)) break;
+      out[k] = r;
+    }
+    __syncthreads();
   }
 }
 
@@ -88,9 +120,9 @@ hipError_t launch_crs_expand(uint64_t* coeffs, size_t count, const uint8_t base_
   int lz = 64 + __builtin_clzll(q);
   unsigned __int128 zone = (range << lz) - 1;
   size_t nwords = count * D;
-  unsigned blocks = (unsigned)((nwords + 255) / 256);
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(k_crs_expand, dim3(blocks), dim3(256), 0, s, coeffs, nwords, base, off_lo, off_hi, q,
+  unsigned blocks = (unsigned)((nwords + CRS_BLOCK - 1) / CRS_BLOCK);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_crs_expand, dim3(blocks), dim3(CRS_BLOCK), 0, s, coeffs, nwords, base, off_lo, off_hi, q,
                      (uint64_t)zone, (uint64_t)(zone >> 64));
   return hipGetLastError();
 }
