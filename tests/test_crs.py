@@ -120,6 +120,28 @@ def test_gpu_crs_expand_matches_oracle(contexts, q):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("q", [Q_REF33, Q_DEFAULT])
+def test_gpu_crs_expand_large_count_is_position_independent(contexts, q):
+    # k_crs_expand walks a long range in groups of 8 passes of 1024 coefficients per block and queues the coefficients whose first
+    # ChaCha20 block is rejected (one in 16 at the 33-bit q): a 6.3-million-polynomial range equals the same range fetched in
+    # pieces of odd sizes (other grids, other pass groups), and polynomials at group / pass / range boundaries equal the oracle
+    import labrador_snark_amd as lab
+    ctx = contexts(q)
+    base = bytes((5 * i + 1) % 256 for i in range(32))
+    k = lab.RuntimeConstants(q, 2, 2, 4, 3, 3)
+    crs = lab.CRS(ctx, k, base)
+    off0, count = (1 << 40) + 977, 6 * (1 << 20) + 37
+    whole = crs._fetch(off0, count)
+    pos = 0
+    for piece in (1, 15, 16, 17, 1023, 131072 + 5, 1 << 20, 3 * (1 << 20) + 11):
+        part = crs._fetch(off0 + pos * D, piece)
+        assert np.array_equal(part, whole[pos:pos + piece]), (pos, piece)
+        pos += piece
+    for poly in (0, 15, 16, 131071, 131072, 8 * 131072 - 1, 8 * 131072, count - 1):   # 8192 blocks x 1024 / 64 = 131072 polynomials per pass
+        assert np.array_equal(whole[poly], co.crs_fill(base, off0 + poly * D, D, q)), poly
+
+
+@pytest.mark.gpu
 def test_gpu_prove_on_seed_addressed_crs_matches_oracle(contexts):
     # the reference's own flow: CRS::new(seed) -> proof_gen fetches rows from the seed (src/main.rs:82-97)
     import labrador_snark_amd as lab
