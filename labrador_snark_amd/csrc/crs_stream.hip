@@ -17,6 +17,9 @@ typedef unsigned __int128 u128;
 namespace lab {
 int mat8_alloc(lab_ctx* c, int basis, size_t nmat_max, size_t rows, size_t cols, lab_mat8** out);
 int mat8_repack(lab_ctx* c, lab_mat8* m, const uint32_t* hat_planes, size_t plane_stride, size_t nmat, size_t rows_valid);
+bool mat8_can_fill_rows(const lab_mat8* m);
+int mat8_fill_begin(lab_ctx* c, lab_mat8* m, size_t nmat, size_t rows_valid);
+int mat8_fill_rows(lab_ctx* c, lab_mat8* m, const uint64_t* coefs, size_t m_idx, size_t row0, size_t nrows);
 
 struct CrsStream {
   lab_ctx* c = nullptr;
@@ -27,6 +30,7 @@ struct CrsStream {
   uint64_t* coefs = nullptr;      // [chunk][64]
   uint32_t* tmp = nullptr;        // [L][ns*R][64]
   size_t chunk = 0;
+  bool fused = false;             // slab tiles straight from the expanded coefficients (mat8_fill_rows)
   ~CrsStream() {
     if (m8) lab_mat8_destroy(m8);
     if (slab) (void)hipFree(slab);
@@ -60,7 +64,14 @@ int crs_stream_create(lab_ctx* c, int basis, size_t nmat, size_t rows, size_t co
   st->chunk = slab_elems < ((size_t)1 << 18) ? slab_elems : ((size_t)1 << 18);
   int rc = mat8_alloc(c, basis, st->MC, st->R, cols, &st->m8);
   if (rc) { delete st; return rc; }
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&st->slab), (size_t)L * slab_elems * D * 4);
+  st->fused = mat8_can_fill_rows(st->m8) && c->q < (1ull << 40);
+  hipError_t e = hipSuccess;
+  if (st->fused) {   // expansion chunks of whole rows; no slab of residues
+    const size_t rows_per = std::max<size_t>(1, (((size_t)1 << 18) / cols));
+    st->chunk = std::min(rows_per, st->R) * cols;
+  } else {
+    e = hipMalloc(reinterpret_cast<void**>(&st->slab), (size_t)L * slab_elems * D * 4);
+  }
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&st->coefs), st->chunk * D * 8);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&st->tmp), (size_t)L * ns * st->R * D * 4);
   if (e != hipSuccess) { delete st; return fail(c, LAB_ERR_HIP, "streamed commitment: hipMalloc of the slab: %s", hipGetErrorString(e)); }
@@ -74,6 +85,22 @@ static int fill_slab(CrsStream* st, const uint8_t seed[32], const uint64_t* mat_
   lab_ctx* c = st->c;
   const int L = basis_nlimbs(c, st->basis);
   const size_t cols = st->cols, slab_elems = st->MC * st->R * cols;
+  if (st->fused) {
+    // coefficients -> tiles in one pass (k_coefs_to_a8): whole rows per expansion chunk, no transform-domain slab
+    int rc = mat8_fill_begin(c, st->m8, mc, nr);
+    if (rc) return rc;
+    const size_t rows_per = st->chunk / cols;
+    for (size_t m = 0; m < mc; m++) {
+      const u128 base = (((u128)mat_offsets[2 * (m0 + m) + 1] << 64) | mat_offsets[2 * (m0 + m)]) + (u128)rho0 * cols * D;
+      for (size_t r0 = 0; r0 < nr; r0 += rows_per) {
+        const size_t rows = nr - r0 < rows_per ? nr - r0 : rows_per;
+        const u128 off = base + (u128)r0 * cols * D;
+        LAB_HIP(c, launch_crs_expand(st->coefs, rows * cols, seed, (uint64_t)off, (uint64_t)(off >> 64), c->q, c->stream));
+        if ((rc = mat8_fill_rows(c, st->m8, st->coefs, m, r0, rows))) return rc;
+      }
+    }
+    return LAB_OK;
+  }
   if (nr < st->R)   // ragged last slab: rows past the end read as zero
     LAB_HIP(c, hipMemsetAsync(st->slab, 0, (size_t)L * slab_elems * D * 4, c->stream));
   for (size_t m = 0; m < mc; m++) {

@@ -180,6 +180,9 @@ hipError_t launch_digits_to_v8(const JobPtrs& src16, size_t ktotal, int8_t* dst,
 // (limb primes below 2^23), ns / 32 proofs per job
 hipError_t launch_coefs_to_v8(const JobPtrs& src64, size_t n, size_t r, int8_t* dst, size_t limb_stride, size_t job_stride, size_t kt_count,
                               int ns, size_t njobs, int nlimbs, const LimbTable* tabs, const int* planes, const size_t* nt, hipStream_t s);
+// rows of a coefficient matrix (64-bit words below q) -> A-operand tiles of every limb (3-plane limbs), see k_coefs_to_a8
+hipError_t launch_coefs_to_a8(const uint64_t* coefs, size_t nrows, size_t cols, size_t row_base, size_t kbase, int8_t* const* dst,
+                              size_t rt_count, size_t kt_count, int nlimbs, const LimbTable* tabs, hipStream_t s);
 // tiled Gram: partial[chunk][i][k], gram_chunks(..) <= gram_num_chunks(n) chunks, to be summed with launch_sum_terms(rows = r*r)
 size_t gram_num_chunks(size_t n);
 size_t gram_chunks(size_t n, size_t r, int nlimbs, size_t njobs);

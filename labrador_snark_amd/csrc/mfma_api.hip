@@ -17,6 +17,7 @@ struct lab_mat8 {
   int planes[MAX_LIMBS] = {0, 0, 0, 0};   // signed base-256 digit planes per limb
   int8_t* d[MAX_LIMBS] = {nullptr, nullptr, nullptr, nullptr};
   size_t bytes = 0;
+  bool filled = false;                    // mat8_fill_begin has cleared the tiles once
 };
 
 namespace lab {
@@ -305,6 +306,32 @@ int mat8_repack(lab_ctx* c, lab_mat8* m, const uint32_t* hat_planes, size_t plan
   for (int l = 0; l < m->nlimbs; l++)
     LAB_HIP(c, launch_pack_matrix_i8(m->d[l], hat_planes + (size_t)l * plane_stride, false, nmat, m->rows_alloc, m->cols, m->rt_count,
                                      m->kt_count, m->planes[l], c->stream));
+  return LAB_OK;
+}
+// The same contents written straight from coefficient rows (k_coefs_to_a8: reduce + transform + byte planes in one pass):
+// mat8_fill_begin declares the shape of the next contents (clearing the tiles when it shrinks, so that padding reads as
+// zero), mat8_fill_rows writes rows [row0, row0 + nrows) of matrix m_idx from `coefs` ([nrows][cols][64] 64-bit words).
+bool mat8_can_fill_rows(const lab_mat8* m) {
+  if (m->cols % 64) return false;
+  for (int l = 0; l < m->nlimbs; l++)
+    if (m->planes[l] != 3) return false;
+  return true;
+}
+int mat8_fill_begin(lab_ctx* c, lab_mat8* m, size_t nmat, size_t rows_valid) {
+  if (nmat == 0 || ((nmat * m->cols + 31) / 32) > m->kt_count || rows_valid == 0 || rows_valid > m->rows_alloc)
+    return fail(c, LAB_ERR_ARG, "mat8_fill_begin: shape exceeds the allocation");
+  if (nmat < m->nmat || rows_valid < m->rows || !m->filled)
+    for (int l = 0; l < m->nlimbs; l++)
+      LAB_HIP(c, hipMemsetAsync(m->d[l], 0, (size_t)D * m->planes[l] * m->rt_count * m->kt_count * 1024, c->stream));
+  m->nmat = nmat;
+  m->rows = rows_valid;
+  m->filled = true;
+  return LAB_OK;
+}
+int mat8_fill_rows(lab_ctx* c, lab_mat8* m, const uint64_t* coefs, size_t m_idx, size_t row0, size_t nrows) {
+  if (m_idx >= m->nmat || row0 + nrows > m->rows_alloc) return fail(c, LAB_ERR_ARG, "mat8_fill_rows: outside the declared shape");
+  const LimbTable* tabs = m->basis ? c->dg_tabs : c->d_tabs;
+  LAB_HIP(c, launch_coefs_to_a8(coefs, nrows, m->cols, row0, m_idx * m->cols, m->d, m->rt_count, m->kt_count, m->nlimbs, tabs, c->stream));
   return LAB_OK;
 }
 }  // namespace lab

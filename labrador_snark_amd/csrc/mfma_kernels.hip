@@ -376,6 +376,121 @@ hipError_t launch_coefs_to_v8(const JobPtrs& src64, size_t n, size_t r, int8_t* 
   return hipGetLastError();
 }
 
+// ---- rows of a coefficient matrix (64-bit words below q < 2^40, e.g. a chunk of a CRS matrix fresh from k_crs_expand) ->
+// reduce -> transform of every limb -> A-operand tiles of a lab_mat8 (3-plane limbs: primes below 2^23), in one pass: the
+// streamed outer commitment's slab never exists as transform-domain residues.  Same structure as k_digits_to_v8<true, 4>
+// with the roles of rows and columns exchanged: block = 4 waves = 4 matrix rows x 64 consecutive columns; thread = one
+// polynomial; a tile lane is (k half, row & 31), so the 4 rows of a block are 4 neighbouring lanes (64-byte runs).
+// cols % 64 == 0 and kbase % 32 == 0 (the caller's business): a block's 64 columns are exactly two k tiles.
+struct A8Dst { int8_t* d[MAX_LIMBS]; };
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_coefs_to_a8(const uint64_t* __restrict__ coefs, unsigned nrows, unsigned cols, unsigned row_base, unsigned kbase, const A8Dst dst,
+              unsigned rt_count, unsigned kt_count, int nlimbs, const LimbTable* __restrict__ tabs) {
+  constexpr int NSETS = 4, ROW = DV_ROW<NSETS>, SB = 2;
+  constexpr int LDSW = 64 * NSETS * 36 > 16 * ROW ? 64 * NSETS * 36 : 16 * ROW;
+  __shared__ __attribute__((aligned(16))) uint32_t ex[LDSW];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const unsigned c0 = blockIdx.x * D, row0 = blockIdx.y * NSETS;
+  uint32_t clo[D], chi[D / 4];
+  {
+    // piece id = it * 256 + t -> polynomial id >> 3 (row poly / 64 of the block, column poly % 64), 16-byte piece id & 7 of the
+    // 128 bytes of this pass: eight lanes fetch one full line; parked at row (row * 64 + column) of the tile
+    auto fetch = [&](int q, u32x4_t (&v)[8]) {
+#pragma unroll
+      for (int it = 0; it < 8; it++) {
+        const unsigned id = it * 256 + t, poly = id >> 3, piece = id & 7, r = poly >> 6, x = poly & 63;
+        const u32x4_t z = {0, 0, 0, 0};
+        v[it] = (row0 + r < nrows && c0 + x < cols)
+                    ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(coefs + ((size_t)(row0 + r) * cols + c0 + x) * D + q * 16) + piece)
+                    : z;
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < D / 4; i++) chi[i] = 0;
+    u32x4_t cur[8], nxt[8];
+    fetch(0, cur);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (q < 3) fetch(q + 1, nxt);
+#pragma unroll
+      for (int it = 0; it < 8; it++) {
+        const unsigned id = it * 256 + t, poly = id >> 3, piece = id & 7;
+        *reinterpret_cast<u32x4_t*>(&ex[poly * 36 + piece * 4]) = cur[it];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int piece = 0; piece < 8; piece++) {
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&ex[(w * 64 + lane) * 36 + piece * 4]);
+        const int k = q * 16 + piece * 2;
+        clo[k] = v.x; clo[k + 1] = v.z;
+        chi[k / 4] |= ((v.y & 0xFFu) << (8 * (k & 3))) | ((v.w & 0xFFu) << (8 * ((k + 1) & 3)));
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 8; it++) cur[it] = nxt[it];
+    }
+  }
+  // gather role: row (fastest: neighbouring lanes of the A tile), k block of 16, slot inside the pass
+  const unsigned g_set = t & (NSETS - 1), g_kb = (t >> SB) & 3, g_jl = t >> (SB + 2);
+  const unsigned g_row = row_base + row0 + g_set;
+  const unsigned rt = g_row / 32, ln = ((g_kb & 1) << 5) | (g_row & 31);
+  const size_t kt = (size_t)(kbase + c0) / 32 + g_kb / 2;
+#pragma unroll 1
+  for (int l = 0; l < nlimbs; l++) {
+    uint32_t x[D];
+    {
+      const LimbTable* tab = tabs + l;
+      const uint32_t p = tab->p, m = (uint32_t)(4294967296.0 * tab->inv_p) - 1, r1 = tab->r1;
+#pragma unroll
+      for (int k = 0; k < D; k++) x[k] = reduce_small16((chi[k / 4] >> (8 * (k & 3))) & 0xFFu, clo[k], p, m, r1);
+    }
+    ntt64_forward(x, tabs + l);
+    const uint32_t offs = digit_offsets(3);
+    int8_t* dl = dst.d[l];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) ex[c * ROW + w * D + lane] = signed_digit_word(x[16 * q + c], offs);
+      __syncthreads();
+      uint32_t wd[16];
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&ex[g_jl * ROW + g_set * D + g_kb * 16 + 4 * b]);
+        wd[4 * b] = v.x; wd[4 * b + 1] = v.y; wd[4 * b + 2] = v.z; wd[4 * b + 3] = v.w;
+      }
+      const unsigned j = 16 * q + g_jl;
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        u32x4_t o;
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) {
+          const uint32_t sel = 0x04000400u + 0x01010101u * i;
+          const uint32_t lo = __builtin_amdgcn_perm(wd[4 * qq + 1], wd[4 * qq], sel);
+          const uint32_t hi = __builtin_amdgcn_perm(wd[4 * qq + 3], wd[4 * qq + 2], sel);
+          o[qq] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+        }
+        if (kt < kt_count && rt < rt_count)
+          *reinterpret_cast<u32x4_t*>(dl + ((((size_t)j * 3 + i) * rt_count + rt) * kt_count + kt) * 1024 + ln * 16) = o;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// nrows x cols polynomials (row-major, 64-bit coefficients below q) -> rows row_base.. and k positions kbase.. of the tiles dst[l]
+// ([64 slots][3 planes][rt_count][kt_count] KiB per limb).  cols % 64 == 0, kbase % 32 == 0, every limb prime below 2^23.
+hipError_t launch_coefs_to_a8(const uint64_t* coefs, size_t nrows, size_t cols, size_t row_base, size_t kbase, int8_t* const* dst,
+                              size_t rt_count, size_t kt_count, int nlimbs, const LimbTable* tabs, hipStream_t s) {
+  if (nrows == 0 || cols == 0) return hipSuccess;
+  if ((cols % 64) || (kbase % 32) || nlimbs > MAX_LIMBS || (nrows + 3) / 4 > 65535) return hipErrorInvalidValue;
+  A8Dst d;
+  for (int l = 0; l < MAX_LIMBS; l++) d.d[l] = l < nlimbs ? dst[l] : nullptr;
+  hipLaunchKernelGGL(k_coefs_to_a8, dim3((unsigned)(cols / 64), (unsigned)((nrows + 3) / 4)), dim3(256), 0, s, coefs, (unsigned)nrows,
+                     (unsigned)cols, (unsigned)row_base, (unsigned)kbase, d, (unsigned)rt_count, (unsigned)kt_count, nlimbs, tabs);
+  return hipGetLastError();
+}
+
 // ---- X = P^T S of one proof (G = S^T S when P is S) from B-operand tiles: the witness columns packed for step 1, and
 // the columns of phi' / W packed the same way (3-plane limbs).
 // A B-operand tile (lane l: column l & 31, 16 consecutive k of half l >> 5) is byte for byte an A-operand tile with the
