@@ -3,6 +3,7 @@
 import ctypes
 import os
 import re
+import sys
 
 import pytest
 
@@ -120,3 +121,11 @@ def test_integration_doc_carries_the_generated_rust_binding():
     by_name = dict(structs)
     assert [f for f, _ in by_name["lab_prove_input"]] == [f for f, _ in _lib.lab_prove_input._fields_]
     assert [f for f, _ in by_name["lab_transcript"]] == [f for f, _ in _lib.lab_transcript._fields_]
+
+
+def test_generated_gemm_loop_is_what_the_generator_emits():
+    """labrador_snark_amd/csrc/gemm_w3_asm.inc (the assembly K loop of the dominant GEMM) is exactly the output of
+    tools/gen_gemm_w3_asm.py: the committed include was not edited by hand and the generator has not drifted from it."""
+    import subprocess
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "gen_gemm_w3_asm.py")]).decode()
+    assert out == open(os.path.join(ROOT, "labrador_snark_amd", "csrc", "gemm_w3_asm.inc")).read()
