@@ -232,10 +232,10 @@ struct PlaneCounts { int n[MAX_LIMBS]; unsigned nt[MAX_LIMBS]; };   // digit pla
 // prime below 2^29 (reduce_small16).  blockIdx.z = job, its tiles at + job * job_stride of every limb.
 // NSETS = 8 or 4 sets (waves) per block: with 4, two blocks share a CU and one loads while the other transforms.
 template <bool MATRIX64, int NSETS>
-__global__ void __launch_bounds__(64 * NSETS) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_digits_to_v8(const JobPtrs src, size_t ktotal, int8_t* __restrict__ dst, size_t limb_stride, unsigned kt_count, unsigned ns,
-               unsigned ns_valid, int nlimbs, const LimbTable* __restrict__ tabs, const PlaneCounts planes, unsigned r, unsigned nsub,
-               size_t job_stride) {
+__device__ __forceinline__ void digits_to_v8_body(const JobPtrs& src, size_t ktotal, int8_t* __restrict__ dst, size_t limb_stride,
+                                                  unsigned kt_count, unsigned ns, unsigned ns_valid, int nlimbs,
+                                                  const LimbTable* __restrict__ tabs, const PlaneCounts& planes, unsigned r, unsigned nsub,
+                                                  size_t job_stride) {
   constexpr int ROW = DV_ROW<NSETS>, SB = NSETS == 8 ? 3 : 2;          // log2(NSETS)
   static_assert(NSETS == 8 || NSETS == 4, "8 or 4 sets per block");
   // [slot of the pass][set][k]: writes and reads conflict-free; MATRIX64: first the load tile [set][x][16 coefficients], pitch 36 words
@@ -244,7 +244,9 @@ k_digits_to_v8(const JobPtrs src, size_t ktotal, int8_t* __restrict__ dst, size_
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const size_t k0 = (size_t)blockIdx.x * D;
   const unsigned s_mine = blockIdx.y * NSETS + w;
-  uint32_t clo[D];
+  // MATRIX64: low words and packed high bytes of the 64 coefficients; digits: two 16-bit digits per register (64 fewer registers
+  // than one each)
+  uint32_t clo[MATRIX64 ? D : D / 2];
   uint32_t chi[MATRIX64 ? D / 4 : 1];
   if constexpr (MATRIX64) {
     dst += (size_t)blockIdx.z * job_stride;
@@ -296,8 +298,7 @@ k_digits_to_v8(const JobPtrs src, size_t ktotal, int8_t* __restrict__ dst, size_
     for (int i = 0; i < 8; i++) {
       u32x4_t v = {0, 0, 0, 0};
       if (have) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p) + i);
-      clo[8 * i] = v.x & 0xFFFFu; clo[8 * i + 1] = v.x >> 16; clo[8 * i + 2] = v.y & 0xFFFFu; clo[8 * i + 3] = v.y >> 16;
-      clo[8 * i + 4] = v.z & 0xFFFFu; clo[8 * i + 5] = v.z >> 16; clo[8 * i + 6] = v.w & 0xFFFFu; clo[8 * i + 7] = v.w >> 16;
+      clo[4 * i] = v.x; clo[4 * i + 1] = v.y; clo[4 * i + 2] = v.z; clo[4 * i + 3] = v.w;
     }
   }
   // gather role: set (fastest: neighbouring lanes of the B tile), k block, slot inside the pass
@@ -313,7 +314,7 @@ k_digits_to_v8(const JobPtrs src, size_t ktotal, int8_t* __restrict__ dst, size_
       for (int k = 0; k < D; k++) x[k] = reduce_small16((chi[k / 4] >> (8 * (k & 3))) & 0xFFu, clo[k], p, m, r1);
     } else {
 #pragma unroll
-      for (int k = 0; k < D; k++) x[k] = clo[k];
+      for (int k = 0; k < D / 2; k++) { x[2 * k] = clo[k] & 0xFFFFu; x[2 * k + 1] = clo[k] >> 16; }
     }
     ntt64_forward(x, tabs + l);
     const int pl = planes.n[l];
@@ -352,6 +353,26 @@ k_digits_to_v8(const JobPtrs src, size_t ktotal, int8_t* __restrict__ dst, size_
   }
 }
 
+// the two instantiations as kernels of their own: the occupancy hint is per kernel.  Digits: 4 sets per block, <= 168 registers,
+// three waves per SIMD (the kernel waits on LDS and store latency a third of the time at two; at 128 registers it spills);
+// matrices: 256 registers, two.
+template <bool MATRIX64, int NSETS> __global__ void k_digits_to_v8(const JobPtrs, size_t, int8_t*, size_t, unsigned, unsigned, unsigned, int,
+                                                                   const LimbTable*, const PlaneCounts, unsigned, unsigned, size_t);
+template <>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_digits_to_v8<false, 4>(const JobPtrs src, size_t ktotal, int8_t* __restrict__ dst, size_t limb_stride, unsigned kt_count, unsigned ns,
+                         unsigned ns_valid, int nlimbs, const LimbTable* __restrict__ tabs, const PlaneCounts planes, unsigned r,
+                         unsigned nsub, size_t job_stride) {
+  digits_to_v8_body<false, 4>(src, ktotal, dst, limb_stride, kt_count, ns, ns_valid, nlimbs, tabs, planes, r, nsub, job_stride);
+}
+template <>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_digits_to_v8<true, 4>(const JobPtrs src, size_t ktotal, int8_t* __restrict__ dst, size_t limb_stride, unsigned kt_count, unsigned ns,
+                        unsigned ns_valid, int nlimbs, const LimbTable* __restrict__ tabs, const PlaneCounts planes, unsigned r,
+                        unsigned nsub, size_t job_stride) {
+  digits_to_v8_body<true, 4>(src, ktotal, dst, limb_stride, kt_count, ns, ns_valid, nlimbs, tabs, planes, r, nsub, job_stride);
+}
+
 // one launch for every limb; sets past ns_valid and polynomials past ktotal come out as zero columns / rows.  K tiles past
 // ceil(ktotal / 64) * 2 (kt_count padding) are NOT written: the caller clears the buffer once.
 hipError_t launch_digits_to_v8(const JobPtrs& src16, size_t ktotal, int8_t* dst, size_t limb_stride, size_t kt_count, int ns,
@@ -359,7 +380,7 @@ hipError_t launch_digits_to_v8(const JobPtrs& src16, size_t ktotal, int8_t* dst,
   if (ns % 8 || ns > 64 || nlimbs > MAX_LIMBS) return hipErrorInvalidValue;
   PlaneCounts pc;
   for (int l = 0; l < MAX_LIMBS; l++) { pc.n[l] = l < nlimbs ? planes[l] : 0; pc.nt[l] = l < nlimbs ? (unsigned)nt[l] : 0; }
-  hipLaunchKernelGGL((k_digits_to_v8<false, 8>), dim3((unsigned)((ktotal + D - 1) / D), (unsigned)(ns / 8)), dim3(512), 0, s, src16, ktotal, dst,
+  hipLaunchKernelGGL((k_digits_to_v8<false, 4>), dim3((unsigned)((ktotal + D - 1) / D), (unsigned)(ns / 4)), dim3(256), 0, s, src16, ktotal, dst,
                      limb_stride, (unsigned)kt_count, (unsigned)ns, (unsigned)ns_valid, nlimbs, tabs, pc, 0u, 1u, (size_t)0);
   return hipGetLastError();
 }
