@@ -618,6 +618,15 @@ def both_paths_q32(lab, dev, q=4294966657, kappa=1024):
                                "step3_kernel": ctx.profile_kernel(), "step3_launch_ms": ms / max(launches, 1),
                                "step3_algorithmic_GBps": alg / max(launches, 1) / (ms / max(launches, 1) / 1e3) / 1e9 if launches else None}
         crs.close()
+        if not rns:
+            # 64 proofs per call at this q: the main basis is the single limb, B, C, D, A go to the matrix cores in the 23-bit
+            # digit basis exactly as at the headline q
+            dSs, sts, dtapes, crs = build_workload(lab, ctx, k, q, dev, 64, 50, 1000, use_mfma=True, basis23=True, compact=True)
+            plan = lab.BatchPlan(ctx, k, dSs, sts, crs, dtapes, device_outputs=True)
+            t = _time(plan.run, 3, warm=1)
+            rec["batch64"] = {"proofs_per_s": 64.0 / t, "ms_per_step": t * 1e3}
+            del plan
+            crs.close()
         ctx.close()
         torch.cuda.synchronize()
         res[name] = rec
