@@ -6,13 +6,13 @@ import labrador_snark_amd as lab
 from oracle import coracle as co
 D = 64
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-qs = [8191, (1 << 32) + 15, 1073738753]
+qs = [8191, (1 << 32) + 15, 1073738753, 4294966657, 2147483777]    # the last two: single-limb strict-32 path (k_wide_dot)
 ctxs = {q: lab.Context(q, 0) for q in qs}
 def rp(q, *shape): return rng.integers(0, q, size=shape + (D,), dtype=np.uint64)
 bad = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 120):
-    q = qs[it % 3]; ctx = ctxs[q]
-    kind = it % 5
+    q = qs[it % len(qs)]; ctx = ctxs[q]
+    kind = (it // len(qs)) % 5
     if kind == 0:
         nmat, rows, cols = int(rng.integers(1, 5)), int(rng.integers(1, 19)), int(rng.integers(1, 300))
         M, V = rp(q, nmat, rows, cols), rp(q, nmat, cols)
