@@ -180,6 +180,9 @@ static void build_crt_table(uint64_t q, int nlimbs, const uint32_t* primes, CrtT
     t->half_digits[a] = (uint32_t)(h % primes[a]);
     h /= primes[a];
   }
+  u128 worst = primes[0];
+  for (int a = 1; a < nlimbs; a++) worst += (u128)(primes[a] - 1) * (q - 1);
+  t->lazy_sum = worst < ((u128)1 << 63) ? 1u : 0u;
 }
 
 // ------------------------------------------------------------- context

@@ -46,6 +46,8 @@ struct CrtTable {
   // reciprocals for the division-free reductions (mod_u64)
   double inv_q;
   double inv_p[MAX_LIMBS];
+  // sum_a (p_a - 1) * (q - 1) + max p < 2^63: the mixed-radix digits times the prefixes can be summed in 64 bits before the one mod q
+  uint32_t lazy_sum;
 };
 
 // ---- ntt_kernels.hip

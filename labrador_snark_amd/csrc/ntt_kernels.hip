@@ -365,11 +365,19 @@ __device__ __forceinline__ uint64_t crt_one(const uint32_t (&r)[L], const CrtTab
     const uint32_t hd = crt->half_digits[a];
     if (!decided && d[a] != hd) { neg = d[a] > hd; decided = true; }
   }
-  uint64_t acc = d[0] < q ? d[0] : mod_u64_near(d[0], q, inv_q);
+  uint64_t acc;
+  if (crt->lazy_sum) {   // sum_a (p_a - 1)(q - 1) < 2^63 (e.g. 23-bit limbs, q below 2^34): the mixed-radix sum first, one reduction
+    acc = d[0];
 #pragma unroll
-  for (int a = 1; a < L; a++) {
-    acc += mulmod_q(d[a], crt->prefix_mod_q[a], q, inv_q);
-    acc -= acc >= q ? q : 0;
+    for (int a = 1; a < L; a++) acc += (uint64_t)d[a] * crt->prefix_mod_q[a];
+    acc = mod_u64_near(acc, q, inv_q);                     // quotient below sum_a p_a < 2^32
+  } else {
+    acc = d[0] < q ? d[0] : mod_u64_near(d[0], q, inv_q);
+#pragma unroll
+    for (int a = 1; a < L; a++) {
+      acc += mulmod_q(d[a], crt->prefix_mod_q[a], q, inv_q);
+      acc -= acc >= q ? q : 0;
+    }
   }
   const uint64_t mm = crt->m_mod_q;
   if (neg) acc = acc >= mm ? acc - mm : acc + q - mm;
