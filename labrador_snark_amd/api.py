@@ -65,6 +65,9 @@ class Context:
         self.primes = [int(info.primes[i]) for i in range(self.nlimbs)]
         self.max_len = int(info.max_len)
         self.device = int(info.device)
+        # q is its own NTT prime in [2^30, 2^32): the strict-32 kernels (csrc/zq_device.h Zp<true>); its main basis has no
+        # matrix-core form (lab_mat8_pack refuses it), the 23-bit digit basis serves that q
+        self.wide = self.nlimbs == 1 and self.primes[0] == self.q and self.q >= (1 << 30)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -243,10 +243,16 @@ extern "C" int lab_mat8_pack(lab_ctx* c, const lab_vec* M, size_t m_off, size_t 
   m->rt_count = (rows + 31) / 32;
   m->kt_count = ((nmat * cols + 31) / 32 + 11) / 12 * 12;   // the GEMM walks K in stages of 4 k-tiles, 3 stages per loop trip
   const uint32_t* primes = M->basis ? c->dg_primes : c->primes;
+  // the recombination epilogue of the GEMM is the lazy arithmetic of limb primes below 2^30 (acc_fold_lazy, redc64): the main basis of
+  // a strict-32 context (its single prime in [2^30, 2^32), LimbTable.wide) is refused whether or not the prime fits four planes
+  if (M->basis == 0 && c->wide) {
+    delete m;
+    return fail(c, LAB_ERR_RANGE, "lab_mat8_pack: the main basis of a single-limb context with q >= 2^30 has no matrix-core form (use the digit basis)");
+  }
   for (int l = 0; l < m->nlimbs; l++)
-    if (mfma_planes(primes[l]) > 4) {
+    if (mfma_planes(primes[l]) > 4 || primes[l] >= (1u << 30)) {
       delete m;
-      return fail(c, LAB_ERR_RANGE, "lab_mat8_pack: limb prime %u does not fit four signed byte planes", primes[l]);
+      return fail(c, LAB_ERR_RANGE, "lab_mat8_pack: limb prime %u does not fit four signed byte planes below 2^30", primes[l]);
     }
   const int nfull = M->planes32();
   for (int l = 0; l < m->nlimbs; l++) {
@@ -278,6 +284,7 @@ namespace lab {
 // streamed outer commitment, crs_stream.hip)
 int mat8_alloc(lab_ctx* c, int basis, size_t nmat_max, size_t rows, size_t cols, lab_mat8** out) {
   if (nmat_max * cols >= (1u << 17) - 1) return fail(c, LAB_ERR_RANGE, "mat8_alloc: %zu products per sum exceed the int32 exactness bound", nmat_max * cols);
+  if (basis == 0 && c->wide) return fail(c, LAB_ERR_RANGE, "mat8_alloc: the main basis of a single-limb context with q >= 2^30 has no matrix-core form");
   lab_mat8* m = new lab_mat8();
   m->ctx = c; m->basis = basis; m->nlimbs = basis_nlimbs(c, basis);
   m->nmat = nmat_max; m->rows = rows; m->rows_alloc = rows; m->cols = cols;

@@ -62,9 +62,10 @@ struct Job {  // device pointers of one proof of the batch
 
 }  // namespace
 
-// Prover::proof_gen for `np` independent proofs that share one common reference string.  Per-proof work is issued
-// proof by proof; the outer commitment (step 3), whose cost is streaming the CRS matrices B_ik from HBM, is issued
-// once per group of up to 8 proofs with the multi-set mat-vec, so B is read once per group instead of once per proof.
+// Prover::proof_gen for `np` independent proofs that share one common reference string.  The per-proof kernels take all
+// proofs of the call as jobs of one launch; the outer commitment (step 3), whose cost is streaming the CRS matrices B_ik, is
+// issued once per group of proofs — up to 64 per pass over B on the matrix cores (B8 or B regenerated from crs_seed), up to 8
+// with the multi-set multiply-add kernel — so B is read (or expanded) once per group instead of once per proof.
 static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const* ins, lab_transcript* const* outs, int* status,
                             bool allow_digit_ajtai = true) {
   if (!c) return LAB_ERR_ARG;
@@ -135,7 +136,8 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if (a8d) {
     long double M = 1.0L;
     for (int l = 0; l < c->dg_nlimbs; l++) M *= (long double)c->dg_primes[l];
-    const long double need = sqrtl((long double)n * D) * (long double)(c->q - 1) * (long double)in->beta_bound * 1.0001L;
+    // (z = sum_{i<r} c_i s_i of step 10 runs in that basis too under sd_only: its Cauchy-Schwarz bound has r in place of n)
+    const long double need = sqrtl((long double)(n > r ? n : r) * D) * (long double)(c->q - 1) * (long double)in->beta_bound * 1.0001L;
     const size_t blocks = (nr + 63) / 64 + 1;
     if (in->beta_bound <= 0 || in->beta_bound >= (int64_t)1 << 24 || need >= M / 2 ||
         (u128)blocks * ((u128)in->beta_bound * in->beta_bound + 1) >= ((u128)1 << 64))

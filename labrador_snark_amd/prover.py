@@ -96,9 +96,9 @@ class ResidentCRS:
         from .api import Mat8
         k = self.constants
         self.B8 = Mat8(self.ctx, self.B, k.R * k.T_1, k.KAPPA_1, k.KAPPA) if self.B is not None else None
-        # (the single-limb strict-32 prime does not fit four signed byte planes: step 1 then has the digit-basis A8d or the
-        # multiply-add kernel)
-        self.A8 = Mat8(self.ctx, self.A, 1, k.KAPPA, k.N) if max(self.ctx.primes) - 1 <= 2139127679 else None
+        # (a single-limb strict-32 context — q its own NTT prime in [2^30, 2^32) — has no main-basis matrix-core form: step 1
+        # then has the digit-basis A8d or the multiply-add kernel)
+        self.A8 = Mat8(self.ctx, self.A, 1, k.KAPPA, k.N) if not self.ctx.wide else None
         pairs = k.R * (k.R + 1) // 2
         self.C8 = Mat8(self.ctx, self.C, pairs * k.T_2, k.KAPPA_2, 1)      # element (rho, m) = C[m][rho]
         self.D8 = Mat8(self.ctx, self.Dm, pairs * k.T_1, k.KAPPA_2, 1)

@@ -15,6 +15,9 @@ Q_DIRECT = 1073738753
 # the largest prime below 2^32 with q == 1 (mod 128): SURVEY §7's "NTT-friendly 32-bit q" (path (b)): one limb, 4 bytes per
 # coefficient, on the strict-32 kernels (csrc/zq_device.h Zp<true>, csrc/wide_kernels.hip)
 Q_NTT32 = 4294966657
+# the smallest NTT-friendly prime above 2^30: single-limb strict-32 too, but it would FIT four signed byte planes (below 2139127680),
+# so nothing but the context's `wide` flag keeps it off the lazy matrix-core epilogue
+Q_WIDE31 = 1073741953
 
 
 class RnsOnly(int):
@@ -25,7 +28,7 @@ class RnsOnly(int):
 Q_NTT32_RNS = RnsOnly(Q_NTT32)
 # Q_NTT32 runs single-limb on the strict-32 kernels (SURVEY section 7 path (b)); Q_NTT32_RNS is the same modulus on three RNS
 # limbs (path (a)): every test parametrised over ALL_Q compares both with the oracle
-ALL_Q = [Q_DEFAULT, Q_REF33, Q_DIRECT, Q_NTT32, Q_NTT32_RNS]
+ALL_Q = [Q_DEFAULT, Q_REF33, Q_DIRECT, Q_NTT32, Q_NTT32_RNS, Q_WIDE31]
 
 
 def ctx_kw(q):

@@ -262,3 +262,110 @@ def test_prover_with_B_streamed_from_the_seed(nproofs):
     assert np.array_equal(T.u_1, np.stack(acc))
     full.close(); streamed.close()
     ctx.close()
+
+
+# ------------------------------------------------------------------ the regime kappa = 2^14 runs in
+def _digit_basis(ctx, which, terms):
+    """'mfma23': primes below 2^23 sized for `terms`; 'mfma23x4': the same with 2^21 terms (what r*t1*kappa at kappa = 2^14 asks
+    for: FOUR primes); 'u16': the compact basis (30-bit prefix + a prime below 2^16: 4- and 2-plane limbs, slab path)"""
+    if which == "u16":
+        primes, small, _ = ctx.enable_digit_basis(terms, 1625)
+        assert small
+        return primes
+    primes, small, _ = ctx.enable_digit_basis((1 << 21) if which == "mfma23x4" else terms, 1625, mfma=True)
+    assert not small and all(p < 8355712 for p in primes)
+    assert len(primes) == (4 if which == "mfma23x4" else 3), primes
+    return primes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("basis", ["mfma23", "mfma23x4", "u16"])
+# more matrices than fit one K chunk of the int8 GEMM (MC = floor((2^17 - 2) / cols) matrices per chunk): chunks after the first
+# land in the side buffer and are added mod every limb prime — 4096 columns: MC = 31 -> 40 = 31 + 9 and 70 = 31 + 31 + 8;
+# 16384 columns (kappa = 2^14's own shape): MC = 7 -> 9 = 7 + 2, 130 rows = a full slab + a ragged one of 2 rows;
+# 32768 columns: MC = 3 -> 5 = 3 + 2.  The last chunk is always shorter than MC (the tiles past it must read as zero).
+@pytest.mark.parametrize("nmat,rows,cols,ns", [(40, 8, 4096, 8), (70, 33, 4096, 64), (9, 130, 16384, 32), (5, 40, 32768, 16)])
+def test_streamed_crs_matvec_with_k_chunks(basis, nmat, rows, cols, ns):
+    # lab_crs_matvec_mfma where nmat * cols exceeds the int32 bound of one GEMM: == lab_crs_expand of the whole matrices + the
+    # multiply-add kernel (lab_matvec_sum, one set at a time; the resident int8 GEMM refuses these lengths), bit for bit, and
+    # == the oracle's CRS restatement + schoolbook products on sample (set, row) pairs
+    import labrador_snark_amd as lab
+    q = Q_REF33
+    assert nmat * cols > (1 << 17) - 2 and nmat % (((1 << 17) - 2) // cols) != 0
+    ctx = lab.Context(q, 0, **ctx_kw(q))
+    _digit_basis(ctx, basis, nmat * cols)
+    base = bytes((i * 31 + 9) % 256 for i in range(32))
+    offs = [555 + m * (rows * cols * D + 13) + ((1 << 65) if m == 2 else 0) for m in range(nmat)]
+    hV = ctx.vec(ns * nmat * cols, digit=True).fill_synthetic(91, bound=1625)
+    got = lab.crs_matvec_mfma(ctx, base, offs, rows, cols, hV, ns).store().reshape(ns, rows, D)
+    M = ctx.vec(nmat * rows * cols, digit=True)
+    for m in range(nmat):
+        ctx._check(ctx._lib.lab_crs_expand(ctx._h, M._h, m * rows * cols, rows * cols, base, offs[m] & ((1 << 64) - 1), offs[m] >> 64))
+    for s in sorted({0, 1, ns // 2, ns - 1}):
+        want = lab.matvec_sum(ctx, M, hV, nmat, rows, cols, v_off=s * nmat * cols).store()
+        assert np.array_equal(got[s], want), (s,)
+    K = nmat * cols
+    for s, rho in ((ns - 1, rows - 1), (2, 0)):
+        v = co.synth_fill(91, s * K * D, K * D, 1625).reshape(nmat, cols, D)
+        acc = np.zeros(D, np.uint64)
+        for m in range(nmat):
+            row = co.crs_fill(base, offs[m] + rho * cols * D, cols * D, q).reshape(cols, D)
+            acc = co.poly_add(q, acc, co.inner_product(q, row, v[m]))
+        assert np.array_equal(got[s, rho], acc), (s, rho)
+    M.close(); hV.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproofs", [2, 9])
+def test_prover_streamed_with_k_chunks_and_four_digit_primes(nproofs):
+    # the streamed prover in the configuration of the kappa = 2^14 bench run, scaled down in kappa1 only: kappa = 16384 columns
+    # per B_ik (MC = 7 matrices per K chunk, r*t1 = 9 matrices -> two chunks), digit basis sized for 2^21 terms (four primes
+    # below 2^23), A8d in that basis.  == the resident CRS on the multiply-add kernels (B as residues), field by field; u_1 row 0
+    # of proof 0 == the oracle on its own CRS expansion at the reference's literal offsets (src/structs.rs:78-82)
+    import labrador_snark_amd as lab
+    import cases
+    q, n, r, kappa, kappa1 = Q_REF33, 2, 3, 16384, 3
+    ctx = lab.Context(q, 0, **ctx_kw(q))
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, kappa1)
+    assert k.T_1 == 3 and r * k.T_1 * kappa > (1 << 17)
+    primes, _, _ = ctx.enable_digit_basis(1 << 21, max(k.B_1, k.B_2), mfma=True)
+    assert len(primes) == 4
+    base = bytes((i * 41 + 3) % 256 for i in range(32))
+    crs = lab.CRS(ctx, k, base)
+    full = crs.materialize(mfma_basis=True)                     # B resident as residues: the multiply-add kernels
+    streamed = crs.materialize(mfma_basis=True, stream_B=True)
+    streamed.pack_mfma()                                        # A8d, C8, D8 in the four-prime basis; B stays a seed
+    assert streamed.B is None and getattr(streamed, "B8", None) is None and streamed.A8d.nbytes > 0
+    ws, sts, tapes = [], [], []
+    for j in range(nproofs):
+        S, phi, a, tape = cases.make_inputs(p, seed=61 + j)
+        ws.append(S); tapes.append(tape)
+        sts.append(lab.State(phi, a, int(lab.gen_f_b(ctx, S, phi, a, n, r)[0])))
+    want, c1 = lab.prove_core_batch(ctx, k, ws, sts, full, tapes, raise_on_reject=False)
+    got, c2 = lab.prove_core_batch(ctx, k, ws, sts, streamed, tapes, raise_on_reject=False)
+    assert c1 == c2 and ctx.prove_flags() == 1                  # step 1 ran in the digit basis (A8d), no fallback
+    for j in range(nproofs):
+        for f in ("u_1", "u_2", "t_i_all", "g_mat", "h_mat", "z", "b_prime_prime", "projection_int"):
+            assert np.array_equal(getattr(got[j], f), getattr(want[j], f)), (j, f)
+    off = lambda which, **kw: co.crs_offset(which, n, r, kappa, kappa1, kappa1, p.t1, **kw)
+    T, rho = got[0], 0
+    acc = np.zeros(D, np.uint64)
+    for i in range(r):
+        # t itself against the oracle's A rows on a few entries, then its digits through the oracle's decomposition
+        dec = co.decompose_vec(q, T.t_i_all[i], k.B_1, k.T_1)
+        for kk in range(k.T_1):
+            b_row = co.crs_fill(base, off("B", i=i, k=kk, row=rho), kappa * D, q).reshape(kappa, D)
+            acc = co.poly_add(q, acc, co.inner_product(q, b_row, dec[kk]))
+    for (i, j) in [(i, j) for i in range(r) for j in range(i, r)]:
+        gdec = co.decompose(q, T.g_mat[i, j], k.B_2, k.T_2)
+        for kk in range(k.T_2):
+            c_vec = co.crs_fill(base, off("C", i=i, j=j, k=kk), kappa1 * D, q).reshape(kappa1, D)
+            acc = co.poly_add(q, acc, co.polymul(q, gdec[kk], c_vec[rho]))
+    assert np.array_equal(T.u_1[rho], acc)
+    for (i, row) in ((0, 0), (r - 1, kappa - 1), (1, 7777)):
+        a_row = co.crs_fill(base, off("A", row=row), n * D, q).reshape(n, D)
+        assert np.array_equal(T.t_i_all[i, row], co.inner_product(q, a_row, ws[0][:, i]))
+    full.close(); streamed.close()
+    ctx.close()

@@ -560,3 +560,76 @@ def test_state_gen_f_and_transcript_bytes_from_a_gpu_proof(q):
     assert rd.o == len(data)
     crs.close()
     ctx.close()
+
+
+# ------------------------------------------------------------------ four 23-bit digit primes (what kappa = 2^14 selects)
+def test_four_prime_digit_basis_matvec_on_matrix_cores():
+    # lab_ctx_enable_digit_basis_mfma(2^21 terms): r*t1*kappa at kappa = 2^14 is 1.5 * 2^20 — FOUR primes below 8355712.  The int8 GEMM,
+    # its 4-limb CRT (k_crt_to_u64<4>) and the fused digits -> tiles pass in that basis against the multiply-add kernel and the oracle
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    q = Q_REF33
+    ctx = lab.Context(q, 0)
+    primes, small, _ = ctx.enable_digit_basis(1 << 21, 1625, mfma=True)
+    assert len(primes) == 4 and not small and all(pr < 8355712 and pr % 128 == 1 for pr in primes) and len(set(primes)) == 4
+    rng = np.random.default_rng(44)
+    for ns, nmat, rows, cols in ((8, 3, 40, 70), (64, 2, 130, 256), (32, 5, 128, 100)):
+        M = rng.integers(0, q, size=(nmat, rows, cols, D), dtype=np.uint64)
+        V = rng.integers(0, 1625, size=(ns, nmat, cols, D), dtype=np.uint64)
+        M[0, :2] = q - 1
+        V[ns - 1] = 1624
+        hM = ctx.vec(nmat * rows * cols, digit=True).load(M)
+        hV = ctx.vec(ns * nmat * cols, digit=True).load(V)
+        M8 = lab.Mat8(ctx, hM, nmat, rows, cols)
+        got = lab.matvec_sum_mfma(ctx, M8, hV, ns).store().reshape(ns, rows, D)
+        for b in sorted({0, 3, ns - 1}):
+            assert np.array_equal(got[b], lab.matvec_sum(ctx, hM, hV, nmat, rows, cols, v_off=b * nmat * cols).store()), (ns, b)
+        for b, r_ in ((0, 0), (ns - 1, rows - 1), (ns - 1, 1)):
+            want = np.zeros(D, np.uint64)
+            for m in range(nmat):
+                want = co.poly_add(q, want, co.inner_product(q, M[m, r_], V[b, m]))
+            assert np.array_equal(got[b, r_], want), (ns, b, r_)
+        M8.close(); hM.close(); hV.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("nb", [3, 4, 9])
+def test_prove_core_batch_in_the_four_prime_digit_basis(nb):
+    # lab_prove_core_batch with B8, C8, D8 and A8d in the four-prime basis, r = 32 (the witness products of steps 1, 2, 6-8, 10 all in
+    # that basis; nb = 4: two proofs per 64-set Ajtai job, 3 and 9: one per job): every field == the multiply-add path in the main
+    # basis == the oracle
+    import labrador_snark_amd as lab
+    q, n, r, kappa, kappa1 = Q_REF33, 6, 32, 40, 36
+    ctx = lab.Context(q, 0)
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
+    plain = lab.ResidentCRS(ctx, k).fill_synthetic(1000)            # main basis, multiply-add kernels
+    primes, _, _ = ctx.enable_digit_basis(1 << 21, max(k.B_1, k.B_2), mfma=True)
+    assert len(primes) == 4
+    crs = lab.ResidentCRS(ctx, k, mfma_basis=True).fill_synthetic(1000)
+    crs.pack_mfma(drop_B=True)
+    assert crs.A8d.nbytes > 0 and crs.B is None
+    ws, sts, tapes, wants = [], [], [], []
+    for j in range(nb):
+        case, (S, phi, a, tape) = cases.oracle_case(p, seed=1300 + j)
+        ws.append(S); sts.append(lab.State(phi, a, case.b_prime)); tapes.append(tape)
+        wants.append(case.prove() if j in (0, nb - 1) else None)
+    ref = lab.prove_core_batch(ctx, k, ws, sts, plain, tapes)
+    assert ctx.prove_flags() == 0
+    got = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes)
+    assert ctx.prove_flags() == 1                                   # digit-basis step 1, no fallback
+    for j in range(nb):
+        for f in ("t_i_all", "g_mat", "h_mat", "u_1", "u_2", "z", "b_prime_prime", "projection_int", "projection"):
+            assert np.array_equal(getattr(got[j], f), getattr(ref[j], f)), (j, f)
+        w = wants[j]
+        if w is not None:
+            for f, o in (("t_i_all", "t"), ("g_mat", "G"), ("h_mat", "H"), ("u_1", "u1"), ("u_2", "u2"), ("z", "z"), ("b_prime_prime", "bpp")):
+                assert np.array_equal(getattr(got[j], f), w[o]), (j, f)
+    # Pi at 2 bits per entry on the same path (the bench's form)
+    tapes2 = [dict(t, Pi2=lab.pack_pi_host(t["Pi"])) for t in tapes]
+    got2 = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes2)
+    for j in range(nb):
+        for f in ("h_mat", "u_2", "b_prime_prime", "projection_int"):
+            assert np.array_equal(getattr(got2[j], f), getattr(ref[j], f)), (j, f)
+    crs.close(); plain.close()
+    ctx.close()
