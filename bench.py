@@ -238,7 +238,8 @@ def build_workload(lab, ctx, k, q, dev, nbatch, seed0, crs_seed, use_mfma=True, 
         # inside every step (lab_prove_input.crs_seed) — B is never materialised, so its expansion IS in the timed region
         seed = bytes((crs_seed * 7 + 13 * i) % 256 for i in range(32))
         crs = lab.CRS(ctx, k, seed).materialize(mfma_basis=True, stream_B=True)
-        crs.pack_mfma()
+        # (no main-basis A8: step 1 runs from A8d; a witness above its norm bound would fall back to the multiply-add kernel)
+        crs.pack_mfma(main_basis_A=False)
         torch.cuda.synchronize()
         return dSs, sts, dtapes, crs
     # B, C, D are only ever multiplied by decomposition digits: keep them in the digit basis
@@ -247,6 +248,50 @@ def build_workload(lab, ctx, k, q, dev, nbatch, seed0, crs_seed, use_mfma=True, 
         crs.pack_mfma(drop_B=True)     # one-time, like the CRS expansion: outside every timed region
     torch.cuda.synchronize()
     return dSs, sts, dtapes, crs
+
+
+VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12   # MI355X_MICROARCH.md: 256 CUs x 4 SIMD16 at 2.4 GHz = 39.3e12 32-bit lane operations per second
+
+
+def expand_valu_per_coefficient():
+    """Vector instructions k_crs_expand issues per 64 coefficients (one wave instruction = 64 lane operations), from the committed
+    rocprofv3 --pmc SQ_INSTS_VALU pass (profiles/*_crs_expand_valu.json); None when no such record is tracked."""
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []:
+        if name.endswith("_crs_expand_valu.json"):
+            try:
+                rec = json.load(open(os.path.join(pdir, name)))
+                return float(rec["valu_instructions_per_coefficient_lane"]), "profiles/" + name
+            except Exception:
+                pass
+    return None, None
+
+
+def streamed_roofline(phases, elapsed, steps):
+    """The roofline object of a --crs streamed run: the dominant kernel is the CRS expansion (k_crs_expand, ChaCha20 on the
+    vector ALUs), timed live with HIP events around a uniform sample of its launches (lab_ctx_profile_phase); its bound is the
+    32-bit integer issue rate, not HBM or the matrix cores.  achieved = coefficients/s of the sampled launches x the vector
+    instructions per coefficient of the committed SQ_INSTS_VALU pass."""
+    ex = phases["crs_expand"]
+    per, src = expand_valu_per_coefficient()
+    rate = ex["sampled_units"] / (ex["sampled_ms"] / 1e3) if ex["sampled_ms"] > 0 else 0.0
+    out = {"bound": "valu", "kernel": "lab::k_crs_expand — CRS::fetch_B_ik_row's coefficients (src/structs.rs:147-171) regenerated inside step 3: one ChaCha20 "
+                                        "block + rand's gen_range per coefficient",
+           "unit": "TOP/s (32-bit integer lane operations)", "peak": VALU_PEAK_TOPS,
+           "coefficients_per_s": rate, "valu_instructions_per_coefficient": per, "valu_count_source": src,
+           "achieved": rate * per / 1e12 if per else None, "frac": rate * per / 1e12 / VALU_PEAK_TOPS if per else None,
+           "traffic": None, "launches": ex["launches"], "sampled_launches": ex["sampled_launches"],
+           "avg_launch_ms": ex["sampled_ms"] / max(ex["sampled_launches"], 1)}
+    # where the step goes: phase time = sampled time scaled to all launches of the phase (launches are of equal size)
+    shares = {}
+    for name, ph in phases.items():
+        if ph["sampled_launches"]:
+            total_ms = ph["sampled_ms"] * (ph["units"] / ph["sampled_units"] if ph["sampled_units"] else ph["launches"] / ph["sampled_launches"])
+            shares[name] = {"ms_per_step": total_ms / steps, "share_of_step": total_ms / 1e3 / elapsed, "launches_per_step": ph["launches"] / steps,
+                            "units_per_s_inside_phase": ph["sampled_units"] / (ph["sampled_ms"] / 1e3) if ph["sampled_ms"] > 0 else None}
+    out["phases"] = shares
+    out["end_to_end_over_expand_alone"] = (phases["crs_expand"]["units"] / elapsed) / rate if rate else None
+    return out
 
 
 def launch_ranks(n_gpus, argv):
@@ -379,6 +424,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms, launches, alg_bytes = ctx.profile_end()
     step3_kernel = ctx.profile_kernel()
+    phases = ctx.profile_phases() if args.crs == "streamed" else None
 
     # aggregate of the commitments across instances: one RCCL all-reduce of a checksum (outside the timed steps)
     chk = checksum_u64(T.u_1) + checksum_u64(T.u_2)
@@ -487,6 +533,7 @@ def main():
         result["crs_expansion"] = {"B_coefficients_regenerated_per_step": coefs, "coefficients_per_s": coefs / (elapsed / args.steps),
                                    "note": "every coefficient = one ChaCha20 key set-up + block + gen_range on i128 (src/structs.rs:167-171): "
                                            "the step is bound by that VALU work (k_crs_expand), not by HBM or the matrix cores"}
+        result["roofline"] = streamed_roofline(phases, elapsed, args.steps)
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:
         # release the big CRS before the side measurements

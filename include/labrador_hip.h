@@ -106,6 +106,14 @@ int lab_ctx_synchronize(lab_ctx *ctx);
  * bytes those launches moved (matrix + vector + output, all limbs). */
 int lab_ctx_profile_begin(lab_ctx *ctx);
 int lab_ctx_profile_end(lab_ctx *ctx, double *kernel_ms, uint64_t *launches, double *algorithmic_bytes);
+/* The same hook for the STREAMED outer commitment (lab_prove_input.crs_seed / lab_crs_matvec_mfma), whose time is not one
+ * kernel's: between begin and end a bounded uniform sample (at most 1024 launches per phase) of the launches of phase
+ * 0 = CRS expansion (k_crs_expand; units: coefficients), 1 = coefficients -> matrix-core tiles (units: coefficients),
+ * 2 = the int8 GEMMs over a slab (units: algorithmic bytes), 3 = decomposition digits -> tiles (units: digits) is bracketed by
+ * HIP events on the context's stream.  Returns the sampled time / launches / units and the totals over every launch of the
+ * phase since begin (call before lab_ctx_profile_end or after: the sample is kept until the next begin). */
+int lab_ctx_profile_phase(lab_ctx *ctx, int phase, double *sampled_ms, uint64_t *sampled_launches, double *sampled_units,
+                          uint64_t *launches, double *units);
 /* name (template arguments included) of the kernel the most recent launch timed by the hook was dispatched to */
 const char *lab_ctx_profile_kernel(const lab_ctx *ctx);
 /* Diagnostic variants of that kernel (tools/gemm_ablation.py; the matrix-core outer commitment at 64 sets only, otherwise

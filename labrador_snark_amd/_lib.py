@@ -82,6 +82,8 @@ SIGNATURES = {
     "lab_ctx_profile_begin": (C.c_int, [C.c_void_p]),
     "lab_ctx_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
                                       C.POINTER(C.c_double)]),
+    "lab_ctx_profile_phase": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double),
+                                        C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "lab_ctx_profile_kernel": (C.c_char_p, [C.c_void_p]),
     "lab_ctx_gemm_diag": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "lab_ctx_enable_digit_basis": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),

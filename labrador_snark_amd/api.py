@@ -122,6 +122,18 @@ class Context:
         self._check(self._lib.lab_ctx_profile_end(self._h, C.byref(ms), C.byref(n), C.byref(b)))
         return ms.value, int(n.value), b.value
 
+    PHASES = ("crs_expand", "coefs_to_tiles", "gemm", "digits_to_tiles")
+
+    def profile_phases(self):
+        """The streamed outer commitment's phases as sampled by the hook since profile_begin (lab_ctx_profile_phase):
+        {name: dict(sampled_ms, sampled_launches, sampled_units, launches, units)}."""
+        out = {}
+        for i, name in enumerate(self.PHASES):
+            ms, sl, su, n, u = C.c_double(), C.c_uint64(), C.c_double(), C.c_uint64(), C.c_double()
+            self._check(self._lib.lab_ctx_profile_phase(self._h, i, C.byref(ms), C.byref(sl), C.byref(su), C.byref(n), C.byref(u)))
+            out[name] = dict(sampled_ms=ms.value, sampled_launches=int(sl.value), sampled_units=su.value, launches=int(n.value), units=u.value)
+        return out
+
     def gemm_diag(self, mode, ticks=None):
         """Diagnostic variant of the timed GEMM (include/labrador_hip.h: lab_ctx_gemm_diag); ticks: uint64 device tensor."""
         ptr, words = (ticks.data_ptr(), ticks.numel()) if ticks is not None else (None, 0)

@@ -253,6 +253,8 @@ extern "C" void lab_ctx_destroy(lab_ctx* c) {
   if (c->d_tabs) limb_tables_register(c->d_tabs, false);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& ev : c->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  for (auto& ph : c->prof_phase)
+    for (auto& sm : ph.ev) { (void)hipEventDestroy(sm.a); (void)hipEventDestroy(sm.b); }
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->d_tabs) (void)hipFree(c->d_tabs);
@@ -394,6 +396,28 @@ extern "C" int lab_ctx_profile_begin(lab_ctx* c) {
   c->prof_on = true;
   c->prof_used = 0;
   c->prof_bytes = 0.0;
+  for (auto& ph : c->prof_phase) { ph.used = 0; ph.launches = 0; ph.stride = 1; ph.units = 0.0; }
+  return LAB_OK;
+}
+
+extern "C" int lab_ctx_profile_phase(lab_ctx* c, int phase, double* sampled_ms, uint64_t* sampled_launches, double* sampled_units,
+                                     uint64_t* launches, double* units) {
+  if (!c) return LAB_ERR_ARG;
+  if (phase < 0 || phase >= PH_COUNT) return fail(c, LAB_ERR_ARG, "lab_ctx_profile_phase: phase %d (0..%d)", phase, PH_COUNT - 1);
+  LAB_HIP(c, hipStreamSynchronize(c->stream));
+  const ProfPhase& P = c->prof_phase[phase];
+  double ms = 0.0, u = 0.0;
+  for (size_t i = 0; i < P.used; i++) {
+    float t = 0.f;
+    LAB_HIP(c, hipEventElapsedTime(&t, P.ev[i].a, P.ev[i].b));
+    ms += t;
+    u += P.ev[i].units;
+  }
+  if (sampled_ms) *sampled_ms = ms;
+  if (sampled_launches) *sampled_launches = P.used;
+  if (sampled_units) *sampled_units = u;
+  if (launches) *launches = P.launches;
+  if (units) *units = P.units;
   return LAB_OK;
 }
 

@@ -12,6 +12,21 @@
 
 struct lab_mat8;
 
+namespace lab {
+// Phases of the streamed outer commitment (crs_stream.hip) the measurement hook samples: HIP events around a bounded sample of
+// the launches of each phase (a kappa = 2^14 step has ~10^5 expansion launches), the totals counted for every launch.
+enum ProfPhaseId { PH_EXPAND = 0 /* k_crs_expand: units = coefficients */, PH_TILES = 1 /* k_coefs_to_a8 / transform + pack: coefficients */,
+                   PH_GEMM = 2 /* k_gemm_i8*: units = algorithmic bytes */, PH_DIGITS = 3 /* k_digits_to_v8: digits */, PH_COUNT = 4 };
+struct ProfPhase {
+  struct Sample { hipEvent_t a, b; double units; };
+  std::vector<Sample> ev;      // [0, used): recorded samples; the rest: created events waiting for reuse
+  size_t used = 0;
+  uint64_t launches = 0, stride = 1;
+  double units = 0.0;          // over ALL launches
+};
+constexpr size_t PROF_PHASE_CAP = 1024;
+}  // namespace lab
+
 struct lab_ctx {
   uint64_t q = 0;
   int device = 0;
@@ -52,6 +67,7 @@ struct lab_ctx {
   uint64_t* gemm_diag_buf = nullptr;
   size_t gemm_diag_words = 0;
   std::string prof_kernel;        // kernel the last profiled mat-vec launch was dispatched to
+  lab::ProfPhase prof_phase[lab::PH_COUNT];
   int prove_flags = 0;            // last lab_prove_core[_batch]: 1 = step 1 ran in the digit basis, 2 = tried and redone in the main basis
 };
 
@@ -87,6 +103,36 @@ struct PtrCacheScope {
     hipError_t _e = (expr);                                                                        \
     if (_e != hipSuccess) return lab::fail(ctx, LAB_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
   } while (0)
+
+// Brackets the launches issued during its lifetime on c->stream as one sample of phase `ph` (when the hook is on and the
+// phase's sampling stride selects this launch); `units` are counted either way.
+struct PhaseSample {
+  lab_ctx* c;
+  ProfPhase* p = nullptr;
+  PhaseSample(lab_ctx* ctx, int ph, double units) : c(ctx) {
+    if (!c->prof_on) return;
+    ProfPhase& P = c->prof_phase[ph];
+    P.units += units;
+    const bool take = (P.launches++ % P.stride) == 0;
+    if (!take) return;
+    if (P.used == PROF_PHASE_CAP) {   // keep every other sample, double the stride: a uniform sample of a run of any length
+      for (size_t i = 1; 2 * i < P.used; i++) std::swap(P.ev[i], P.ev[2 * i]);
+      P.used = (P.used + 1) / 2;
+      P.stride *= 2;
+      if ((P.launches - 1) % P.stride) return;
+    }
+    if (P.used == P.ev.size()) {
+      ProfPhase::Sample sm{nullptr, nullptr, 0.0};
+      if (hipEventCreate(&sm.a) != hipSuccess || hipEventCreate(&sm.b) != hipSuccess) return;
+      P.ev.push_back(sm);
+    }
+    P.ev[P.used].units = units;
+    if (hipEventRecord(P.ev[P.used].a, c->stream) == hipSuccess) p = &P;
+  }
+  ~PhaseSample() {
+    if (p && hipEventRecord(p->ev[p->used].b, c->stream) == hipSuccess) p->used++;
+  }
+};
 
 // carve helper: sequential 256-byte aligned sub-allocations out of ctx->scratch
 struct Carver {
@@ -146,6 +192,9 @@ int gram_impl(lab_ctx* c, HatView out, ConstHatView P, ConstHatView S, size_t n,
 int check_range(lab_ctx* c, const lab_vec* v, size_t off, size_t n, const char* what);
 // int8-MFMA outer commitment (mfma_api.hip)
 size_t mfma_scratch_bytes(const lab_mat8* m, int ns, size_t njobs);
+// algorithmic bytes of the GEMM launches of all limbs of `m` against ns sets: digit planes of the k-tiles that hold terms, the
+// B-operand tiles once, the results
+double mfma_gemm_bytes(const lab_mat8* m, int ns, int ns_valid);
 // `coef`: the caller only wants the results as coefficients — when the launch goes through the slot-major staging array
 // (several jobs) the inverse transform reads it directly and writes plane l of the dense array `coef->dense`
 // ([limb][count][64] words, job stride coef->job_stride, set s -> polynomial s * coef->set_stride + row) instead of `out`;
@@ -173,8 +222,13 @@ int digits_to_v8_impl(lab_ctx* c, const lab_mat8* m, const JobPtrs& src16, int n
 uint32_t mat8_min_prime(const lab_ctx* c, const lab_mat8* m);
 // the outer commitment with the matrices streamed from the CRS seed (crs_stream.hip)
 struct CrsStream;
-size_t crs_stream_scratch_bytes(lab_ctx* c, int basis, size_t nmat, size_t rows, size_t cols, int ns);
-int crs_stream_create(lab_ctx* c, int basis, size_t nmat, size_t rows, size_t cols, int ns, CrsStream** out);
+// extra_terms: terms the caller adds to the result in the transform domain (the prover's rhs of u_1) — they count against the
+// exactness bound of the basis together with the streamed sum
+size_t crs_stream_scratch_bytes(lab_ctx* c, int basis, size_t nmat, size_t rows, size_t cols, int ns, uint64_t extra_terms = 0);
+// matrices per K chunk of the streamed sum and whether the chunks are added mod q in the coefficient domain (the whole sum exceeds
+// the exactness bound of the basis, one chunk does not); false: not even one matrix row fits
+bool crs_stream_plan(const lab_ctx* c, int basis, size_t nmat, size_t cols, uint64_t extra_terms, size_t* mc, bool* reduce);
+int crs_stream_create(lab_ctx* c, int basis, size_t nmat, size_t rows, size_t cols, int ns, CrsStream** out, uint64_t extra_terms = 0);
 void crs_stream_destroy(CrsStream* st);
 int crs_stream_run(CrsStream* st, const uint8_t seed[32], const uint64_t* mat_offsets, size_t nmat, HatView out, size_t out_set_stride,
                    const ConstHatView* V, size_t v_set_stride, const JobPtrs* dig, int ns, int ns_valid, void* scratch);

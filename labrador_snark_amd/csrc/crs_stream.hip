@@ -6,7 +6,11 @@
 // matrix rows x MC matrices (MC * cols below the int32 bound of the int8 GEMM): a slab is expanded on the device
 // (k_crs_expand), transformed into the basis of the vectors, packed as signed byte planes in MFMA operand order and
 // multiplied with every vector set on the matrix cores (k_gemm_i8*); the partial results of the MC-chunks are added
-// mod each limb prime.  Only the slab (a fixed working set, independent of the matrix size) ever exists in HBM.
+// mod each limb prime — or, when the whole sum of nmat * cols terms exceeds the exactness bound of the basis but one chunk does
+// not, every chunk's result is brought back to coefficients mod q (INTT + CRT of ns * 128 polynomials: nothing) and the
+// chunks are added mod q: the basis then only has to hold ONE chunk's sum (three 23-bit primes instead of four at kappa = 2^14:
+// a quarter less transform, packing and matrix-core work per regenerated coefficient).
+// Only the slab (a fixed working set, independent of the matrix size) ever exists in HBM.
 // The expansion is ~1100 integer operations per coefficient (x ~2 at the 33-bit modulus: half the candidates are
 // rejected) against 27 byte products in the GEMM: this path is bound by the ChaCha20/VALU rate, not by HBM or MFMA.
 #include "context.h"
@@ -21,6 +25,11 @@ bool mat8_can_fill_rows(const lab_mat8* m);
 int mat8_fill_begin(lab_ctx* c, lab_mat8* m, size_t nmat, size_t rows_valid);
 int mat8_fill_rows(lab_ctx* c, lab_mat8* m, const uint64_t* coefs, size_t m_idx, size_t row0, size_t nrows);
 
+// polynomials per expansion launch: 2^20 x 64 coefficients = 8192 blocks x 8 passes of k_crs_expand — every block then works off
+// its rejected coefficients once per EIGHT passes (launches of 2^18 polynomials gave each block two passes per queue phase and
+// ran 19 % below the kernel's stand-alone rate)
+constexpr size_t CRS_CHUNK_POLYS = (size_t)1 << 20;
+
 struct CrsStream {
   lab_ctx* c = nullptr;
   int basis = 0;
@@ -28,52 +37,75 @@ struct CrsStream {
   lab_mat8* m8 = nullptr;
   uint32_t* slab = nullptr;       // [L][MC*R*cols][64]
   uint64_t* coefs = nullptr;      // [chunk][64]
-  uint32_t* tmp = nullptr;        // [L][ns*R][64]
+  uint32_t* tmp = nullptr;        // [L][ns*R][64] (twice that with `reduce`: the inverse transform's scratch behind it)
+  uint64_t* acc = nullptr;        // reduce: [ns][rows][64] coefficients mod q — the running sum over the K chunks
+  uint64_t* cur = nullptr;        // reduce: [ns*R][64] the current (chunk, slab)'s sums mod q
   size_t chunk = 0;
   bool fused = false;             // slab tiles straight from the expanded coefficients (mat8_fill_rows)
+  bool reduce = false;            // chunk results are added mod q in the coefficient domain (see the header)
   ~CrsStream() {
     if (m8) lab_mat8_destroy(m8);
     if (slab) (void)hipFree(slab);
     if (coefs) (void)hipFree(coefs);
     if (tmp) (void)hipFree(tmp);
+    if (acc) (void)hipFree(acc);
+    if (cur) (void)hipFree(cur);
   }
 };
 
 // rows per slab / matrices per chunk the engine will use
 size_t crs_stream_rows(size_t rows) { return rows < 128 ? rows : 128; }
-size_t crs_stream_mats(size_t nmat, size_t cols) {
-  size_t mc = cols ? ((1u << 17) - 2) / cols : 0;
-  return mc > nmat ? nmat : mc;
+// matrices per K chunk: the int32 accumulators of the int8 GEMM hold 2^17 - 2 terms; a sum that (together with `extra_terms` the
+// caller adds to the result in the transform domain) exceeds the exactness bound of the basis is cut into chunks that respect it,
+// and their results are added mod q, not mod the limb primes (*reduce).  false: not even one matrix fits.
+bool crs_stream_plan(const lab_ctx* c, int basis, size_t nmat, size_t cols, uint64_t extra_terms, size_t* mc_out, bool* reduce) {
+  if (cols == 0 || nmat == 0) return false;
+  const uint64_t limit = basis ? c->dg_terms : c->max_len;
+  size_t mc = ((1u << 17) - 2) / cols;
+  *reduce = (unsigned __int128)nmat * cols + extra_terms > limit;
+  if (*reduce) {
+    if (extra_terms >= limit) return false;
+    if ((limit - extra_terms) / cols < mc) mc = (size_t)((limit - extra_terms) / cols);
+  }
+  if (mc > nmat) mc = nmat;
+  *mc_out = mc;
+  return mc > 0;
 }
-size_t crs_stream_scratch_bytes(lab_ctx* c, int basis, size_t nmat, size_t rows, size_t cols, int ns) {
+size_t crs_stream_scratch_bytes(lab_ctx* c, int basis, size_t nmat, size_t rows, size_t cols, int ns, uint64_t extra_terms) {
   // the V8 tiles (or prepacked digit tiles) of one chunk: sized like a packed matrix of MC x cols
-  const size_t mc = crs_stream_mats(nmat, cols);
+  size_t mc = 0;
+  bool reduce = false;
+  if (!crs_stream_plan(c, basis, nmat, cols, extra_terms, &mc, &reduce)) return 0;
   const size_t kt = ((mc * cols + 31) / 32 + 11) / 12 * 12;
   const int L = basis_nlimbs(c, basis);
   return (size_t)L * Carver::padded((size_t)D * kt * 8 * 1024) + 8192;   // 8 column tiles at most per limb
 }
 
-int crs_stream_create(lab_ctx* c, int basis, size_t nmat, size_t rows, size_t cols, int ns, CrsStream** out) {
+int crs_stream_create(lab_ctx* c, int basis, size_t nmat, size_t rows, size_t cols, int ns, CrsStream** out, uint64_t extra_terms) {
   CrsStream* st = new CrsStream();
   st->c = c; st->basis = basis; st->rows = rows; st->cols = cols; st->ns = (size_t)ns;
   st->R = crs_stream_rows(rows);
-  st->MC = crs_stream_mats(nmat, cols);
-  if (st->MC == 0) { delete st; return fail(c, LAB_ERR_RANGE, "streamed commitment: %zu columns per matrix exceed the int32 bound of the int8 GEMM", cols); }
+  if (!crs_stream_plan(c, basis, nmat, cols, extra_terms, &st->MC, &st->reduce)) st->MC = 0;
+  if (st->MC == 0) { delete st; return fail(c, LAB_ERR_RANGE, "streamed commitment: %zu columns per matrix exceed the int32 bound of the int8 GEMM or the exactness bound of this basis", cols); }
   const int L = basis_nlimbs(c, basis);
   const size_t slab_elems = st->MC * st->R * cols;
-  st->chunk = slab_elems < ((size_t)1 << 18) ? slab_elems : ((size_t)1 << 18);
+  st->chunk = slab_elems < (CRS_CHUNK_POLYS) ? slab_elems : (CRS_CHUNK_POLYS);
   int rc = mat8_alloc(c, basis, st->MC, st->R, cols, &st->m8);
   if (rc) { delete st; return rc; }
   st->fused = mat8_can_fill_rows(st->m8) && c->q < (1ull << 40);
   hipError_t e = hipSuccess;
   if (st->fused) {   // expansion chunks of whole rows; no slab of residues
-    const size_t rows_per = std::max<size_t>(1, (((size_t)1 << 18) / cols));
+    const size_t rows_per = std::max<size_t>(1, ((CRS_CHUNK_POLYS) / cols));
     st->chunk = std::min(rows_per, st->R) * cols;
   } else {
     e = hipMalloc(reinterpret_cast<void**>(&st->slab), (size_t)L * slab_elems * D * 4);
   }
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&st->coefs), st->chunk * D * 8);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&st->tmp), (size_t)L * ns * st->R * D * 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&st->tmp), (size_t)(st->reduce ? 2 : 1) * L * ns * st->R * D * 4);
+  if (e == hipSuccess && st->reduce) e = hipMalloc(reinterpret_cast<void**>(&st->acc), (size_t)ns * rows * D * 8);
+  if (e == hipSuccess && st->reduce) e = hipMalloc(reinterpret_cast<void**>(&st->cur), (size_t)ns * st->R * D * 8);
+  // (rows past a ragged slab and sets past ns_valid are never stored by the GEMM but are read by the chunk reduction)
+  if (e == hipSuccess && st->reduce) e = hipMemsetAsync(st->tmp, 0, (size_t)2 * L * ns * st->R * D * 4, c->stream);
   if (e != hipSuccess) { delete st; return fail(c, LAB_ERR_HIP, "streamed commitment: hipMalloc of the slab: %s", hipGetErrorString(e)); }
   *out = st;
   return LAB_OK;
@@ -95,7 +127,11 @@ static int fill_slab(CrsStream* st, const uint8_t seed[32], const uint64_t* mat_
       for (size_t r0 = 0; r0 < nr; r0 += rows_per) {
         const size_t rows = nr - r0 < rows_per ? nr - r0 : rows_per;
         const u128 off = base + (u128)r0 * cols * D;
-        LAB_HIP(c, launch_crs_expand(st->coefs, rows * cols, seed, (uint64_t)off, (uint64_t)(off >> 64), c->q, c->stream));
+        {
+          PhaseSample ps(c, PH_EXPAND, (double)rows * cols * D);
+          LAB_HIP(c, launch_crs_expand(st->coefs, rows * cols, seed, (uint64_t)off, (uint64_t)(off >> 64), c->q, c->stream));
+        }
+        PhaseSample ps(c, PH_TILES, (double)rows * cols * D);
         if ((rc = mat8_fill_rows(c, st->m8, st->coefs, m, r0, rows))) return rc;
       }
     }
@@ -110,51 +146,88 @@ static int fill_slab(CrsStream* st, const uint8_t seed[32], const uint64_t* mat_
     for (size_t done = 0; done < total; done += st->chunk) {
       const size_t cnt = total - done < st->chunk ? total - done : st->chunk;
       const u128 off = base + (u128)done * D;
-      LAB_HIP(c, launch_crs_expand(st->coefs, cnt, seed, (uint64_t)off, (uint64_t)(off >> 64), c->q, c->stream));
+      {
+        PhaseSample ps(c, PH_EXPAND, (double)cnt * D);
+        LAB_HIP(c, launch_crs_expand(st->coefs, cnt, seed, (uint64_t)off, (uint64_t)(off >> 64), c->q, c->stream));
+      }
       // element (m, row, col) of the slab at (m*R + row)*cols + col
       HatView dst{st->slab + ((m * st->R) * cols + done) * D, slab_elems * D};
+      PhaseSample ps(c, PH_TILES, (double)cnt * D);
       int rc = to_hat(c, st->coefs, dst, cnt, st->basis);
       if (rc) return rc;
     }
   }
+  PhaseSample ps(c, PH_TILES, 0.0);
   return mat8_repack(c, st->m8, st->slab, slab_elems * D, mc, nr);
 }
 
 // The engine.  Vector sets either as transform-domain vectors (V: set s at V.base + s*v_set_stride words, element
 // (m, c) at + (m*cols + c)*64) or as 16-bit decomposition digits per set (dig.p[s]: [nmat*cols][64] words, the prover's
 // step 3).  out: set s at out.base + s*out_set_stride.  `scratch` >= crs_stream_scratch_bytes().
+// Loop order: K chunk outside, row slab inside — the vector operand of a chunk (the digits of t transformed and packed as
+// B-operand tiles of every limb) is made ONCE per chunk and multiplied with every slab of that chunk's matrices (slab outside
+// re-made it for each of the kappa1 / 128 slabs: 5.6 % of a kappa = 2^14 step).
 int crs_stream_run(CrsStream* st, const uint8_t seed[32], const uint64_t* mat_offsets, size_t nmat, HatView out, size_t out_set_stride,
                    const ConstHatView* V, size_t v_set_stride, const JobPtrs* dig, int ns, int ns_valid, void* scratch) {
   lab_ctx* c = st->c;
   const int L = basis_nlimbs(c, st->basis);
   const LimbTable* tabs = basis_tabs(c, st->basis);
-  const size_t cols = st->cols;
-  for (size_t rho0 = 0; rho0 < st->rows; rho0 += st->R) {
-    const size_t nr = st->rows - rho0 < st->R ? st->rows - rho0 : st->R;
-    for (size_t m0 = 0; m0 < nmat; m0 += st->MC) {
-      const size_t mc = nmat - m0 < st->MC ? nmat - m0 : st->MC;
+  const size_t cols = st->cols, rows = st->rows;
+  if (st->reduce) LAB_HIP(c, hipMemsetAsync(st->acc, 0, (size_t)ns * rows * D * 8, c->stream));
+  for (size_t m0 = 0; m0 < nmat; m0 += st->MC) {
+    const size_t mc = nmat - m0 < st->MC ? nmat - m0 : st->MC;
+    const bool first = m0 == 0;
+    bool tiles_made = false;
+    for (size_t rho0 = 0; rho0 < rows; rho0 += st->R) {
+      const size_t nr = rows - rho0 < st->R ? rows - rho0 : st->R;
       int rc = fill_slab(st, seed, mat_offsets, m0, mc, rho0, nr);
       if (rc) return rc;
-      const bool first = m0 == 0;
-      HatView dst = first ? HatView{out.base + rho0 * D, out.plane_stride} : HatView{st->tmp, (size_t)ns * st->R * D};
-      const size_t dst_ss = first ? out_set_stride : st->R * D;
-      if (dig) {
+      const bool direct = first && !st->reduce;
+      HatView dst = direct ? HatView{out.base + rho0 * D, out.plane_stride} : HatView{st->tmp, (size_t)ns * st->R * D};
+      const size_t dst_ss = direct ? out_set_stride : st->R * D;
+      if (dig && !tiles_made) {
         JobPtrs d;
         for (int s = 0; s < MAX_JOBS; s++)
           d.p[s] = (s < ns_valid && dig->p[s]) ? static_cast<void*>(static_cast<uint16_t*>(dig->p[s]) + m0 * cols * D) : nullptr;
+        PhaseSample ps(c, PH_DIGITS, (double)ns_valid * mc * cols * D);
         if ((rc = digits_to_v8_impl(c, st->m8, d, ns, ns_valid, static_cast<int8_t*>(scratch)))) return rc;
-        if ((rc = matvec_mfma_impl(c, dst, dst_ss, st->m8, ConstHatView(), 0, ns, ns_valid, scratch, D, 1, 0, 0, false, nullptr,
-                                   static_cast<const int8_t*>(scratch)))) return rc;
-      } else {
-        ConstHatView v(V->base + m0 * cols * D, V->plane_stride);
-        if ((rc = matvec_mfma_impl(c, dst, dst_ss, st->m8, v, v_set_stride, ns, ns_valid, scratch, D, 1, 0, 0))) return rc;
       }
-      if (!first)
+      {
+        PhaseSample ps(c, PH_GEMM, mfma_gemm_bytes(st->m8, ns, ns_valid));
+        if (dig || tiles_made) {
+          if ((rc = matvec_mfma_impl(c, dst, dst_ss, st->m8, ConstHatView(), 0, ns, ns_valid, scratch, D, 1, 0, 0, false, nullptr,
+                                     static_cast<const int8_t*>(scratch)))) return rc;
+        } else {   // first slab of the chunk: pack the transform-domain vectors, keep the tiles of every limb for the other slabs
+          ConstHatView v(V->base + m0 * cols * D, V->plane_stride);
+          if ((rc = matvec_mfma_impl(c, dst, dst_ss, st->m8, v, v_set_stride, ns, ns_valid, scratch, D, 1, 0, 0, false, nullptr, nullptr, nullptr,
+                                     static_cast<int8_t*>(scratch)))) return rc;
+        }
+      }
+      tiles_made = true;
+      if (st->reduce) {
+        // this (chunk, slab)'s exact sums -> coefficients mod q, added mod q to the rows of the running sum
+        const size_t cnt = (size_t)ns * st->R;
+        uint64_t* cur = st->cur;
+        if ((rc = from_hat(c, ConstHatView(st->tmp, cnt * D), cnt, st->tmp + (size_t)L * cnt * D, cur, st->basis))) return rc;
+        JobPtrs o, b;
+        JobU64 zero;
+        for (int s = 0; s < MAX_JOBS; s++) {
+          o.p[s] = s < ns_valid ? st->acc + ((size_t)s * rows + rho0) * D : nullptr;
+          b.p[s] = s < ns_valid ? cur + (size_t)s * st->R * D : nullptr;
+          zero.v[s] = 0;
+        }
+        LAB_HIP(c, launch_coef_elementwise_jobs(o, o, b, nr, c->q, zero, 2, (size_t)ns_valid, c->stream));
+      } else if (!first)
         LAB_HIP(c, launch_pointwise(PW_ADD, HatView{out.base + rho0 * D, out.plane_stride}, HatView{out.base + rho0 * D, out.plane_stride},
                                     HatView{st->tmp, (size_t)ns * st->R * D}, nr, L, tabs, c->stream, (size_t)ns_valid, out_set_stride,
                                     out_set_stride, st->R * D));
     }
   }
+  if (st->reduce)   // the sums mod q back into the transform domain, set by set
+    for (int s = 0; s < ns_valid; s++) {
+      int rc = to_hat(c, st->acc + (size_t)s * rows * D, HatView{out.base + (size_t)s * out_set_stride, out.plane_stride}, rows, st->basis);
+      if (rc) return rc;
+    }
   return LAB_OK;
 }
 
@@ -170,7 +243,7 @@ extern "C" int lab_crs_matvec_mfma(lab_ctx* c, lab_vec* out, size_t out_off, con
   if ((rc = check_range(c, V, v_off, (size_t)ns * nmat * cols, "lab_crs_matvec_mfma(V)"))) return rc;
   if (V->basis != out->basis || V->compact || out->compact) return fail(c, LAB_ERR_ARG, "lab_crs_matvec_mfma: V and out must be plain vectors of one basis");
   const uint64_t limit = V->basis ? c->dg_terms : c->max_len;
-  if ((u128)nmat * cols > limit) return fail(c, LAB_ERR_RANGE, "lab_crs_matvec_mfma: reduction length %zu exceeds the exactness bound %llu of this basis", nmat * cols, (unsigned long long)limit);
+  if (cols > limit) return fail(c, LAB_ERR_RANGE, "lab_crs_matvec_mfma: one matrix row of %zu terms exceeds the exactness bound %llu of this basis", cols, (unsigned long long)limit);
   LAB_HIP(c, hipSetDevice(c->device));
   if ((rc = ensure_scratch(c, crs_stream_scratch_bytes(c, V->basis, nmat, rows, cols, ns)))) return rc;
   CrsStream* st = nullptr;

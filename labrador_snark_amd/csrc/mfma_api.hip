@@ -49,6 +49,14 @@ static size_t stage_bytes(const lab_mat8* m, int ns, size_t njobs) {
   return njobs > 1 ? Carver::padded(njobs * (size_t)D * m->rt_count * 32 * ns * 4) : 0;
 }
 size_t mfma_scratch_bytes(const lab_mat8* m, int ns, size_t njobs) { return v8_job_bytes(m, ns) * njobs + stage_bytes(m, ns, njobs); }
+double mfma_gemm_bytes(const lab_mat8* m, int ns, int ns_valid) {
+  const double kt_real = (double)((m->nmat * m->cols + 31) / 32);
+  double b = 0.0;
+  for (int l = 0; l < m->nlimbs; l++)
+    b += (double)D * m->planes[l] * ((m->rows + 31) / 32) * kt_real * 1024 + (double)D * kt_real * nt_for(ns, m->planes[l]) * 1024 +
+         (double)ns_valid * m->rows * D * 4;
+  return b;
+}
 
 // recombination weights 256^e mod p and the bias that entering every int32 D as D + 2^31 adds to the sum
 static void recomb_consts(uint32_t p, int pl, uint32_t (&pw)[7], uint32_t* bias) {

@@ -157,11 +157,22 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   const u128 bmax = (u128)(in->b1 > in->b2 ? in->b1 : in->b2);
   if (!exact_ok(c, n, qm1) || !exact_ok(c, rr + nr, qm1) || !exact_ok(c, r, qm1))
     return fail(c, LAB_ERR_RANGE, "lab_prove_core: a reduction exceeds the CRT range of this context; create it with a larger max_len");
+  // (B streamed: the K chunks of step 3 are reduced mod q one by one when the whole sum exceeds the basis — crs_stream.hip — so
+  // only one chunk's sum has to be exact)
+  u128 outer_terms = (u128)r * t1 * kappa;
+  const uint64_t rhs_terms = (uint64_t)pairs * t2;
+  if (stream_b) {
+    size_t mc = 0;
+    bool reduce = false;
+    if (!crs_stream_plan(c, bdig, r * (size_t)t1, kappa, rhs_terms, &mc, &reduce))
+      return fail(c, LAB_ERR_RANGE, "lab_prove_core: one row of B (%zu terms) exceeds the int32 bound of the int8 GEMM or the exactness bound of the CRS basis", kappa);
+    if (reduce) outer_terms = (u128)mc * kappa;
+  }
   if (bdig) {
-    if ((u128)r * t1 * kappa + (u128)pairs * t2 > c->dg_terms || (u128)pairs * t1 > c->dg_terms || bmax - 1 > c->dg_vmax)
+    if (outer_terms + (u128)pairs * t2 > c->dg_terms || (u128)pairs * t1 > c->dg_terms || bmax - 1 > c->dg_vmax)
       return fail(c, LAB_ERR_RANGE, "lab_prove_core: outer commitments exceed the digit basis bounds (max_terms %llu, digit_bound %llu)",
                   (unsigned long long)c->dg_terms, (unsigned long long)(c->dg_vmax + 1));
-  } else if (!exact_ok(c, (u128)r * t1 * kappa + (u128)pairs * t2, bmax) || !exact_ok(c, (u128)pairs * t1, (u128)in->b1)) {
+  } else if (!exact_ok(c, outer_terms + (u128)pairs * t2, bmax) || !exact_ok(c, (u128)pairs * t1, (u128)in->b1)) {
     return fail(c, LAB_ERR_RANGE, "lab_prove_core: a reduction exceeds the CRT range of this context; create it with a larger max_len");
   }
   if ((u128)r * n * D * qm1 >= ((u128)1 << 63)) return fail(c, LAB_ERR_RANGE, "lab_prove_core: JL projection does not fit 64 bits");
@@ -175,7 +186,10 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   const int L = c->nlimbs;
   const bool sd_only = a8d && gram_mfma_ok(a8d, n, r);   // every product with the witness in the basis of B, C, D (see hPd below)
   HatArena ha;
-  const size_t hS = ha.take(sd_only ? 1 : nr), hphi = ha.take(sd_only ? 1 : nr), hT = ha.take(rk), hG = ha.take(rr),
+  // t = A s leaves the matrix-core product of several proofs through the GEMM's staging array straight into coefficients
+  // (MfmaCoefOut): its transform-domain copy is then never written — 0.4 + 0.5 GB per proof at kappa = 2^14
+  const bool t_coef_only = (a8d || in->A8) && np > 1;
+  const size_t hS = ha.take(sd_only ? 1 : nr), hphi = ha.take(sd_only ? 1 : nr), hT = ha.take(a8d || t_coef_only ? 1 : rk), hG = ha.take(rr),
                hphipp = ha.take(sd_only ? 1 : nr),
                happ = ha.take(rr), hGc = ha.take(rr), hbpp = ha.take(2), hX1 = ha.take(rr), hX2 = ha.take(rr),
                hX = ha.take(rr), hc = ha.take(r), hz = ha.take(n), hab = ha.take(2);
@@ -191,7 +205,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if (!in->C8 && axpy_partial_elems(pairs * t2, k2) > partd_elems) partd_elems = axpy_partial_elems(pairs * t2, k2);
   if (!in->D8 && axpy_partial_elems(pairs * t1, k2) > partd_elems) partd_elems = axpy_partial_elems(pairs * t1, k2);
   const size_t hpartd = hd.take(partd_elems);
-  const size_t hSd = a8d ? hd.take(nr) : 0, hTd = a8d ? hd.take(rk) : 0;   // witness and t = A s in the digit basis
+  const size_t hSd = a8d ? hd.take(nr) : 0, hTd = a8d ? hd.take(t_coef_only ? 1 : rk) : 0;   // witness and t = A s in the digit basis
   const size_t hGd = a8d ? hd.take(rr) : 0;                                 // G = S^T S from the same packed operands
   // Under the same norm bound every other product with the witness is exact in that basis too (|<x, s>| <= |x|_2 |s|_2 for any
   // x with entries below q): phi'^T S, W^T S (steps 6-8) on the matrix cores from packed tiles, z = sum_i c_i s_i (step 10)
@@ -207,7 +221,10 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if (k1 > tmp_elems) tmp_elems = k1;
   if (rr > tmp_elems) tmp_elems = rr;
 
-  const size_t coef_elems = rk /*cT*/ + rk * t1 /*cTdec*/ + rr /*cG*/ + pairs /*cGup*/ + pairs * t2 /*cGdec*/ +
+  // decomposition digits travel between k_decompose / the CRT pass and the transforms as 16-bit words when both bases allow it
+  const bool dig16 = in->b1 <= 65536 && in->b2 <= 65536;
+  const size_t tdec_elems = dig16 ? (rk * t1 + 3) / 4 : rk * t1;   // in units of 64 64-bit words
+  const size_t coef_elems = rk /*cT*/ + tdec_elems /*cTdec*/ + rr /*cG*/ + pairs /*cGup*/ + pairs * t2 /*cGdec*/ +
                             nr /*cW*/ + rr /*capp*/ + 2 * rr /*cX1, cX2*/ + rr /*cX*/ + rr /*cH*/ +
                             pairs /*cHup*/ + pairs * t1 /*cHdec*/ + k1 /*cu1*/ + k2 /*cu2*/ + n /*cz*/ + 1 /*cbpp*/ +
                             2 /*cab*/;
@@ -224,8 +241,8 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   const int mf_ns = np > 32 ? 64 : np > 16 ? 32 : np > 8 ? 16 : 8;
   size_t mf_bytes = b8 ? mfma_scratch_bytes(b8, mf_ns, 1) + 4096 : 0;
   if (stream_b && !fuse_t) return fail(c, LAB_ERR_ARG, "lab_prove_core: the streamed outer commitment needs decomposition bases up to 65536 below the limb primes");
-  if (stream_b && crs_stream_scratch_bytes(c, bdig, r * (size_t)t1, k1, kappa, mf_ns) + 4096 > mf_bytes)
-    mf_bytes = crs_stream_scratch_bytes(c, bdig, r * (size_t)t1, k1, kappa, mf_ns) + 4096;
+  if (stream_b && crs_stream_scratch_bytes(c, bdig, r * (size_t)t1, k1, kappa, mf_ns, rhs_terms) + 4096 > mf_bytes)
+    mf_bytes = crs_stream_scratch_bytes(c, bdig, r * (size_t)t1, k1, kappa, mf_ns, rhs_terms) + 4096;
   if (fuse_t && b8 && mfma_prepacked_bytes(b8, mf_ns) + 4096 > mf_bytes) mf_bytes = mfma_prepacked_bytes(b8, mf_ns) + 4096;
   const int a8_ns = r <= 8 ? 8 : r <= 16 ? 16 : 32;       // witness columns per Ajtai GEMM pass
   if (a8 && mfma_scratch_bytes(a8, a8_ns, np) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(a8, a8_ns, np) + 4096;
@@ -258,7 +275,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     Job& J = jobs[j];
     const lab_prove_input* x = ins[j];
     lab_transcript* o = outs[j];
-    J.cT = OUT(o->t_i_all, rk); J.cTdec = CO(rk * t1); J.cG = OUT(o->g_mat, rr); J.cGup = CO(pairs); J.cGdec = CO(pairs * t2);
+    J.cT = OUT(o->t_i_all, rk); J.cTdec = CO(tdec_elems); J.cG = OUT(o->g_mat, rr); J.cGup = CO(pairs); J.cGdec = CO(pairs * t2);
     J.cW = CO(nr); J.capp = CO(rr); J.cX1 = CO(rr); J.cX2 = CO(rr); J.cX = CO(rr); J.cH = OUT(o->h_mat, rr);
     J.cHup = CO(pairs); J.cHdec = CO(pairs * t1); J.cu1 = OUT(o->u_1, k1); J.cu2 = OUT(o->u_2, k2); J.cz = OUT(o->z, n);
     J.cbpp = OUT(o->b_prime_prime, 1); J.cab = CO(2);
@@ -289,8 +306,6 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     return t;
   };
   // `darena`: the offset lives in the second arena (operands of the digit reductions, in the basis `bdig` of B/C/D)
-  // decomposition digits travel between k_decompose and to_hat as 16-bit words when both bases allow it
-  const bool dig16 = in->b1 <= 65536 && in->b2 <= 65536;
   auto to_hat_jobs = [&](const JobPtrs& src, size_t off, size_t count, bool darena, uint64_t in_bound = ~0ull, bool src16 = false) -> int {
     const int basis = darena ? bdig : 0;
     HatView dst = darena ? HD(0, off) : HV(0, off);
@@ -423,7 +438,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
       const size_t left = np - j0;
       const int ns = left > 32 ? 64 : left > 16 ? 32 : left > 8 ? 16 : 8, valid = (int)(left < (size_t)ns ? left : (size_t)ns);
       CrsStream* cs = nullptr;
-      if ((rc = crs_stream_create(c, bdig, nmat, k1, kappa, ns, &cs))) return rc;
+      if ((rc = crs_stream_create(c, bdig, nmat, k1, kappa, ns, &cs, rhs_terms))) return rc;
       JobPtrs dig;
       for (int i = 0; i < MAX_JOBS; i++) dig.p[i] = i < valid ? jobs[j0 + i].cTdec : nullptr;
       rc = crs_stream_run(cs, in->crs_seed, offs.data(), nmat, HD(j0, hlhs), perd * D, nullptr, 0, &dig, ns, valid, mf_scratch);

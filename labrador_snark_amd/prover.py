@@ -59,14 +59,21 @@ class ResidentCRS:
         pairs = k.R * (k.R + 1) // 2
         self.ctx, self.constants = ctx, k
         self.compact = False
+        # longest exact sum of digit products: step 3's r*t1*kappa terms plus the C terms added to it.  With B streamed from the
+        # seed (with_B=False) the K chunks of step 3 (at most 2^17 - 2 terms each) are reduced mod q one by one when the basis
+        # does not hold the whole sum, so one chunk's length is enough: three 23-bit primes instead of four at kappa = 2^14
+        outer = k.R * k.T_1 * k.KAPPA
+        if not with_B and k.KAPPA <= (1 << 17) - 2:
+            outer = min(outer, (((1 << 17) - 2) // k.KAPPA) * k.KAPPA)
+        terms = outer + pairs * max(k.T_1, k.T_2)
         if mfma_basis:
             if not getattr(ctx, "digit_primes", None):
-                ctx.enable_digit_basis(k.R * k.T_1 * k.KAPPA + pairs * max(k.T_1, k.T_2), max(k.B_1, k.B_2), mfma=True)
+                ctx.enable_digit_basis(terms, max(k.B_1, k.B_2), mfma=True)
             self.compact = True
         elif compact and ctx.nlimbs > 1:
             if not getattr(ctx, "digit_primes", None):
                 try:
-                    ctx.enable_digit_basis(k.R * k.T_1 * k.KAPPA + pairs * max(k.T_1, k.T_2), max(k.B_1, k.B_2))
+                    ctx.enable_digit_basis(terms, max(k.B_1, k.B_2))
                 except _lib.LabradorError:
                     pass
             self.compact = bool(getattr(ctx, "digit_primes", None))
@@ -89,16 +96,17 @@ class ResidentCRS:
         self.A.load(A); self.B.load(B); self.C.load(Cm); self.Dm.load(Dm)
         return self
 
-    def pack_mfma(self, drop_B=False):
+    def pack_mfma(self, drop_B=False, main_basis_A=True):
         """Re-stores the B matrices for the matrix cores (lab_mat8_pack): step 3 of prove_core[_batch] then runs as exact
         int8 GEMMs over up to 64 proofs per pass over B.  drop_B=True frees the original B (the verifier and
-        single-proof VALU path need it; a prover-only service does not)."""
+        single-proof VALU path need it; a prover-only service does not).  main_basis_A=False skips A8 (12 bytes per
+        coefficient of A): step 1 then has the digit-basis A8d, and the multiply-add kernel for a witness above its norm bound."""
         from .api import Mat8
         k = self.constants
         self.B8 = Mat8(self.ctx, self.B, k.R * k.T_1, k.KAPPA_1, k.KAPPA) if self.B is not None else None
         # (a single-limb strict-32 context — q its own NTT prime in [2^30, 2^32) — has no main-basis matrix-core form: step 1
         # then has the digit-basis A8d or the multiply-add kernel)
-        self.A8 = Mat8(self.ctx, self.A, 1, k.KAPPA, k.N) if not self.ctx.wide else None
+        self.A8 = Mat8(self.ctx, self.A, 1, k.KAPPA, k.N) if main_basis_A and not self.ctx.wide else None
         pairs = k.R * (k.R + 1) // 2
         self.C8 = Mat8(self.ctx, self.C, pairs * k.T_2, k.KAPPA_2, 1)      # element (rho, m) = C[m][rho]
         self.D8 = Mat8(self.ctx, self.Dm, pairs * k.T_1, k.KAPPA_2, 1)

@@ -272,6 +272,12 @@ def _digit_basis(ctx, which, terms):
         primes, small, _ = ctx.enable_digit_basis(terms, 1625)
         assert small
         return primes
+    if which in ("chunk17", "chunk70000"):
+        # a basis that holds ONE K chunk but not the whole sum: the chunks are reduced mod q one by one (crs_stream.hip `reduce`) —
+        # 2^17 terms: the chunking of the int8 GEMM stands (MC = 31 / 7 / 3 matrices); 70000 terms: the basis cuts shorter chunks
+        primes, small, _ = ctx.enable_digit_basis((1 << 17) if which == "chunk17" else 70000, 1625, mfma=True)
+        assert not small and len(primes) == 3 and terms > (1 << 17)
+        return primes
     primes, small, _ = ctx.enable_digit_basis((1 << 21) if which == "mfma23x4" else terms, 1625, mfma=True)
     assert not small and all(p < 8355712 for p in primes)
     assert len(primes) == (4 if which == "mfma23x4" else 3), primes
@@ -279,7 +285,7 @@ def _digit_basis(ctx, which, terms):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("basis", ["mfma23", "mfma23x4", "u16"])
+@pytest.mark.parametrize("basis", ["mfma23", "mfma23x4", "u16", "chunk17", "chunk70000"])
 # more matrices than fit one K chunk of the int8 GEMM (MC = floor((2^17 - 2) / cols) matrices per chunk): chunks after the first
 # land in the side buffer and are added mod every limb prime — 4096 columns: MC = 31 -> 40 = 31 + 9 and 70 = 31 + 31 + 8;
 # 16384 columns (kappa = 2^14's own shape): MC = 7 -> 9 = 7 + 2, 130 rows = a full slab + a ragged one of 2 rows;
@@ -298,11 +304,18 @@ def test_streamed_crs_matvec_with_k_chunks(basis, nmat, rows, cols, ns):
     offs = [555 + m * (rows * cols * D + 13) + ((1 << 65) if m == 2 else 0) for m in range(nmat)]
     hV = ctx.vec(ns * nmat * cols, digit=True).fill_synthetic(91, bound=1625)
     got = lab.crs_matvec_mfma(ctx, base, offs, rows, cols, hV, ns).store().reshape(ns, rows, D)
-    M = ctx.vec(nmat * rows * cols, digit=True)
+    ref = ctx
+    if basis.startswith("chunk"):
+        # the multiply-add reference needs a basis that holds the whole sum: a second context (same q, four digit primes)
+        ref = lab.Context(q, 0, **ctx_kw(q))
+        ref.enable_digit_basis(1 << 21, 1625, mfma=True)
+        hV.close()
+        hV = ref.vec(ns * nmat * cols, digit=True).fill_synthetic(91, bound=1625)
+    M = ref.vec(nmat * rows * cols, digit=True)
     for m in range(nmat):
-        ctx._check(ctx._lib.lab_crs_expand(ctx._h, M._h, m * rows * cols, rows * cols, base, offs[m] & ((1 << 64) - 1), offs[m] >> 64))
+        ref._check(ref._lib.lab_crs_expand(ref._h, M._h, m * rows * cols, rows * cols, base, offs[m] & ((1 << 64) - 1), offs[m] >> 64))
     for s in sorted({0, 1, ns // 2, ns - 1}):
-        want = lab.matvec_sum(ctx, M, hV, nmat, rows, cols, v_off=s * nmat * cols).store()
+        want = lab.matvec_sum(ref, M, hV, nmat, rows, cols, v_off=s * nmat * cols).store()
         assert np.array_equal(got[s], want), (s,)
     K = nmat * cols
     for s, rho in ((ns - 1, rows - 1), (2, 0)):
@@ -313,37 +326,47 @@ def test_streamed_crs_matvec_with_k_chunks(basis, nmat, rows, cols, ns):
             acc = co.poly_add(q, acc, co.inner_product(q, row, v[m]))
         assert np.array_equal(got[s, rho], acc), (s, rho)
     M.close(); hV.close()
+    if ref is not ctx:
+        ref.close()
     ctx.close()
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("nproofs", [2, 9])
-def test_prover_streamed_with_k_chunks_and_four_digit_primes(nproofs):
+@pytest.mark.parametrize("chunk_basis", [False, True])
+def test_prover_streamed_with_k_chunks(nproofs, chunk_basis):
     # the streamed prover in the configuration of the kappa = 2^14 bench run, scaled down in kappa1 only: kappa = 16384 columns
-    # per B_ik (MC = 7 matrices per K chunk, r*t1 = 9 matrices -> two chunks), digit basis sized for 2^21 terms (four primes
-    # below 2^23), A8d in that basis.  == the resident CRS on the multiply-add kernels (B as residues), field by field; u_1 row 0
-    # of proof 0 == the oracle on its own CRS expansion at the reference's literal offsets (src/structs.rs:78-82)
+    # per B_ik (MC = 7 matrices per K chunk, r*t1 = 9 matrices -> two chunks), A8d in the basis of the CRS.
+    #   chunk_basis = False: digit basis sized for 2^21 terms (FOUR primes below 2^23; chunks added mod the limb primes)
+    #   chunk_basis = True:  the basis ResidentCRS(with_B=False) asks for by itself — one chunk's length, THREE primes; the chunks
+    #                        are reduced mod q one by one (what bench.py's kappa = 2^14 record runs)
+    # == the resident CRS on the multiply-add kernels (B as residues, four-prime basis), field by field; u_1 row 0 of proof 0 ==
+    # the oracle on its own CRS expansion at the reference's literal offsets (src/structs.rs:78-82); entries of t == the oracle
     import labrador_snark_amd as lab
     import cases
     q, n, r, kappa, kappa1 = Q_REF33, 2, 3, 16384, 3
-    ctx = lab.Context(q, 0, **ctx_kw(q))
+    ref = lab.Context(q, 0, **ctx_kw(q))
     p = cases.Params(q, n, r, kappa, kappa1)
     k = lab.RuntimeConstants(q, n, r, kappa, kappa1, kappa1)
     assert k.T_1 == 3 and r * k.T_1 * kappa > (1 << 17)
-    primes, _, _ = ctx.enable_digit_basis(1 << 21, max(k.B_1, k.B_2), mfma=True)
+    primes, _, _ = ref.enable_digit_basis(1 << 21, max(k.B_1, k.B_2), mfma=True)
     assert len(primes) == 4
     base = bytes((i * 41 + 3) % 256 for i in range(32))
-    crs = lab.CRS(ctx, k, base)
-    full = crs.materialize(mfma_basis=True)                     # B resident as residues: the multiply-add kernels
-    streamed = crs.materialize(mfma_basis=True, stream_B=True)
-    streamed.pack_mfma()                                        # A8d, C8, D8 in the four-prime basis; B stays a seed
+    full = lab.CRS(ref, k, base).materialize(mfma_basis=True)            # B resident as residues: the multiply-add kernels
+    if chunk_basis:
+        ctx = lab.Context(q, 0, **ctx_kw(q))
+    else:
+        ctx = ref
+    streamed = lab.CRS(ctx, k, base).materialize(mfma_basis=True, stream_B=True)
+    assert len(ctx.digit_primes) == (3 if chunk_basis else 4)
+    streamed.pack_mfma(main_basis_A=not chunk_basis)              # A8d, C8, D8 in the CRS basis; B stays a seed
     assert streamed.B is None and getattr(streamed, "B8", None) is None and streamed.A8d.nbytes > 0
     ws, sts, tapes = [], [], []
     for j in range(nproofs):
         S, phi, a, tape = cases.make_inputs(p, seed=61 + j)
         ws.append(S); tapes.append(tape)
-        sts.append(lab.State(phi, a, int(lab.gen_f_b(ctx, S, phi, a, n, r)[0])))
-    want, c1 = lab.prove_core_batch(ctx, k, ws, sts, full, tapes, raise_on_reject=False)
+        sts.append(lab.State(phi, a, int(lab.gen_f_b(ref, S, phi, a, n, r)[0])))
+    want, c1 = lab.prove_core_batch(ref, k, ws, sts, full, tapes, raise_on_reject=False)
     got, c2 = lab.prove_core_batch(ctx, k, ws, sts, streamed, tapes, raise_on_reject=False)
     assert c1 == c2 and ctx.prove_flags() == 1                  # step 1 ran in the digit basis (A8d), no fallback
     for j in range(nproofs):
@@ -353,7 +376,6 @@ def test_prover_streamed_with_k_chunks_and_four_digit_primes(nproofs):
     T, rho = got[0], 0
     acc = np.zeros(D, np.uint64)
     for i in range(r):
-        # t itself against the oracle's A rows on a few entries, then its digits through the oracle's decomposition
         dec = co.decompose_vec(q, T.t_i_all[i], k.B_1, k.T_1)
         for kk in range(k.T_1):
             b_row = co.crs_fill(base, off("B", i=i, k=kk, row=rho), kappa * D, q).reshape(kappa, D)
@@ -367,5 +389,18 @@ def test_prover_streamed_with_k_chunks_and_four_digit_primes(nproofs):
     for (i, row) in ((0, 0), (r - 1, kappa - 1), (1, 7777)):
         a_row = co.crs_fill(base, off("A", row=row), n * D, q).reshape(n, D)
         assert np.array_equal(T.t_i_all[i, row], co.inner_product(q, a_row, ws[0][:, i]))
+    # a witness above its norm bound: the call falls back to the main basis for step 1 (the multiply-add kernel when A8 is
+    # absent) and still equals the resident run
+    big = [w.copy() for w in ws]
+    big[1][1, 2, 5] = q - 1
+    bad = [sts[0], lab.State(sts[1].phi, sts[1].a, 0)] + sts[2:]
+    want2, codes_ref = lab.prove_core_batch(ref, k, big, bad, full, tapes, raise_on_reject=False)
+    got2, codes = lab.prove_core_batch(ctx, k, big, bad, streamed, tapes, raise_on_reject=False)
+    assert ctx.prove_flags() == 2 and list(codes) == list(codes_ref)
+    for j in range(nproofs):
+        for f in ("t_i_all", "g_mat", "h_mat", "u_1", "u_2", "z"):
+            assert np.array_equal(getattr(got2[j], f), getattr(want2[j], f)), (j, f)
     full.close(); streamed.close()
-    ctx.close()
+    if ctx is not ref:
+        ctx.close()
+    ref.close()
