@@ -5,13 +5,15 @@ Workload (BASELINE.json configs[2], SURVEY §8d config 3): one full Prover::proo
 (src/proofgen.rs:30-427) per step on a synthetic instance n=1024, r=32, d=64 with commitment ranks
 kappa = kappa1 = kappa2 = 1024 (stated explicitly: the reference hard-wires n*64 = 65536, which makes each
 B_ik a 1 TiB matrix).  Witness, state, challenge tape and the CRS matrices (transform domain) are resident
-in HBM before the timed region; CRS expansion from a seed (src/structs.rs:55-171) is NOT in the timed region
-(out of scope this round).  The modulus is the reference's "32-bit" choice
+in HBM before the timed region; for the headline the CRS expansion from a seed (src/structs.rs:55-171) is NOT in the timed
+region.  The same prover at the contract's kappa = 2^14 — where B cannot be resident and is regenerated from the ChaCha20 seed
+INSIDE the step — is measured right after as extra.config3_kappa16384_streamed (one step; --crs streamed runs that mode as
+the headline).  The modulus is the reference's "32-bit" choice
 q = 2^32+15 (src/constants.rs:196; 33 bits, not NTT-friendly -> exact 3-limb RNS path).
 
 metric  = prover constraints/sec  (K = 1 constraint per proof, src/constants.rs:26)  => proofs/sec.
 N > 1   = N independent instances, one per GPU (weak scaling, BASELINE configs[4]); the only collective is one
-          RCCL all-reduce of a 64-bit checksum of the aggregated commitments (u_1, u_2) after the timed steps.
+          RCCL all-reduce of the folded (u_1, u_2) commitment vector (plus a count of the ranks) after the timed steps.
 """
 import argparse
 import json
@@ -205,17 +207,40 @@ def make_inputs(k, q, seed, dev=None, packed_pi=False):
     return S, phi, a, tape
 
 
+def folded_commitments(T):
+    """(u_1, u_2) of one transcript folded over their rows: int64[128] = 64 coefficient-wise sums of u_1 | 64 of u_2, each mod 2^62
+    (the aggregate the ranks all-reduce is a VECTOR the host reads as one buffer)."""
+    import torch
+    m = (1 << 62) - 1
+    return torch.cat([T.u_1.to(torch.int64).sum(dim=0) & m, T.u_2.to(torch.int64).sum(dim=0) & m])
+
+
+def aggregate_over_ranks(dist, vec, elapsed, dev):
+    """After the timed steps: one all-reduce(SUM) of the folded commitment vector, one of a tensor of ones (how many ranks the
+    collective really saw) and one MAX of the step time.  dist is None for a single process."""
+    import torch
+    seen = torch.ones(1, dtype=torch.int64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    backend = None
+    if dist is not None:
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        backend = dist.get_backend()
+    host = vec.cpu()                      # ONE buffer read by the host
+    return {"ranks_seen": int(seen.item()), "backend": backend, "vector": [int(x) for x in host.tolist()],
+            "scalar": int(sum(int(x) for x in host.tolist()) & ((1 << 62) - 1)), "tmax": float(tmax.item())}
+
+
 def checksum_u64(t):
     """Order-independent 64-bit checksum of a device tensor of residues (sum mod 2^63)."""
     import torch
     return (t.to(torch.int64).sum() & ((1 << 62) - 1)).reshape(1)
 
 
-def build_workload(lab, ctx, k, q, dev, nbatch, seed0, crs_seed, use_mfma=True, basis23=True, compact=True, packed_pi=True,
-                   stream_b=False):
-    """The resident inputs of one bench step: `nbatch` instances (seeds seed0 .. seed0+nbatch-1; witness, state, tape as
-    device tensors) and the CRS they share.  tests/test_gpu_bench_config.py builds the same objects and checks the
-    transcripts lab_prove_core_batch returns for them against the oracle."""
+def build_inputs(lab, ctx, k, q, dev, nbatch, seed0, packed_pi=True):
+    """`nbatch` instances (seeds seed0 .. seed0+nbatch-1): witness, state, tape as device tensors.  They do not depend on the
+    commitment ranks kappa, so the kappa = 2^14 record reuses the headline's."""
     import torch
     n, r = k.N, k.R
 
@@ -233,6 +258,11 @@ def build_workload(lab, ctx, k, q, dev, nbatch, seed0, crs_seed, use_mfma=True, 
         dtapes.append({pikey: tape[pikey] if torch.is_tensor(tape[pikey]) else torch.from_numpy(tape[pikey]).to(dev),
                        "psi": tape["psi"], "omega": dev64(tape["omega"]),
                        "alpha": dev64(tape["alpha"]), "beta": dev64(tape["beta"]), "c": dev64(tape["c"])})
+    return dSs, sts, dtapes
+
+
+def build_crs(lab, ctx, k, crs_seed, use_mfma=True, basis23=True, compact=True, stream_b=False):
+    import torch
     if stream_b:
         # the reference's own CRS: A, C, D expanded from the 32-byte seed once (resident), the B_ik rows regenerated from it
         # inside every step (lab_prove_input.crs_seed) — B is never materialised, so its expansion IS in the timed region
@@ -241,12 +271,22 @@ def build_workload(lab, ctx, k, q, dev, nbatch, seed0, crs_seed, use_mfma=True, 
         # (no main-basis A8: step 1 runs from A8d; a witness above its norm bound would fall back to the multiply-add kernel)
         crs.pack_mfma(main_basis_A=False)
         torch.cuda.synchronize()
-        return dSs, sts, dtapes, crs
+        return crs
     # B, C, D are only ever multiplied by decomposition digits: keep them in the digit basis
     crs = lab.ResidentCRS(ctx, k, compact=compact, mfma_basis=basis23).fill_synthetic(crs_seed)
     if use_mfma:
         crs.pack_mfma(drop_B=True)     # one-time, like the CRS expansion: outside every timed region
     torch.cuda.synchronize()
+    return crs
+
+
+def build_workload(lab, ctx, k, q, dev, nbatch, seed0, crs_seed, use_mfma=True, basis23=True, compact=True, packed_pi=True,
+                   stream_b=False):
+    """The resident inputs of one bench step: `nbatch` instances (seeds seed0 .. seed0+nbatch-1; witness, state, tape as
+    device tensors) and the CRS they share.  tests/test_gpu_bench_config.py builds the same objects and checks the
+    transcripts lab_prove_core_batch returns for them against the oracle."""
+    dSs, sts, dtapes = build_inputs(lab, ctx, k, q, dev, nbatch, seed0, packed_pi=packed_pi)
+    crs = build_crs(lab, ctx, k, crs_seed, use_mfma=use_mfma, basis23=basis23, compact=compact, stream_b=stream_b)
     return dSs, sts, dtapes, crs
 
 
@@ -294,6 +334,89 @@ def streamed_roofline(phases, elapsed, steps):
     return out
 
 
+def host_chacha_rate(q, seconds=4.0):
+    """CRS coefficients per second the host regenerates (oracle orc_crs_fill: one ChaCha20 key set-up + block + gen_range per
+    coefficient, scalar C) with every thread of this process's CPU share busy."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import coracle as co
+    cores = cpu_share()
+    base = bytes(range(32))
+    n0 = 1 << 18
+    t0 = time.perf_counter()
+    co.crs_fill(base, 0, n0, q)
+    per = max(time.perf_counter() - t0, 1e-4)
+    reps = max(1, int(seconds / per))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(lambda i: [co.crs_fill(base, (i * reps + j) * n0, n0, q) for j in range(reps)], range(cores)))
+    dt = time.perf_counter() - t0
+    return cores * reps * n0 / dt, cores, dt
+
+
+def config3_streamed(lab, dev, q, n, r, kappa, inputs, b1_s_per_proof_k1024=None, with_cpu=True):
+    """SURVEY section 8(d) config 3 at the contract's commitment rank: kappa = kappa1 = kappa2 = 2^14 (the floor BASELINE.md names;
+    the reference hard-wires n*d = 2^16, src/constants.rs:237-239).  One B_ik is 2^28 ring elements, the 96 of them 6 TiB as byte
+    planes: B is STREAMED — regenerated from the ChaCha20 seed inside the step (CRS::fetch_B_ik_row, src/structs.rs:74-88,
+    147-171) — so the expansion is inside the timed region.  ONE step, no warm-up (a step is ~80 s), all proofs of the step share
+    one pass over the regenerated rows."""
+    import torch
+    dSs, sts, dtapes = inputs
+    nbatch = len(dSs)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa, kappa)
+    ctx = lab.Context(q, dev.index or 0, max(65536, n * r + r * r))
+    ctx.use_torch_stream()
+    rec = {"workload": "full Prover::proof_gen n=%d r=%d d=64, kappa=kappa1=kappa2=%d, q=%d; B regenerated from the ChaCha20 seed inside "
+                       "the timed region (A, C, D resident); %d proofs per step share one pass over the regenerated rows; 1 step, no warm-up"
+                       % (n, r, kappa, q, nbatch), "kappa": kappa, "proofs_per_step": nbatch}
+    try:
+        t0 = time.perf_counter()
+        crs = build_crs(lab, ctx, k, 1000, stream_b=True)
+        rec["crs_setup_s"] = time.perf_counter() - t0
+        rec["digit_primes"] = ctx.digit_primes
+        plan = lab.BatchPlan(ctx, k, dSs, sts, crs, dtapes, device_outputs=True)
+        torch.cuda.synchronize()
+        ctx.profile_begin()
+        t0 = time.perf_counter()
+        T = plan.run()[-1]
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        ctx.profile_end()
+        phases = ctx.profile_phases()
+        coefs = r * k.T_1 * kappa * kappa * D
+        rec.update({"proofs_per_s": nbatch / elapsed, "ms_per_step": elapsed * 1e3, "s_per_proof": elapsed / nbatch,
+                    "prove_flags": ctx.prove_flags(), "checksum_u1_u2": int((checksum_u64(T.u_1) + checksum_u64(T.u_2)).item()),
+                    "B_coefficients_regenerated_per_step": coefs, "coefficients_per_s_end_to_end": coefs / elapsed,
+                    "roofline": streamed_roofline(phases, elapsed, 1)})
+        del plan, T
+        crs.close()
+    except Exception as e:
+        rec["error"] = repr(e)
+    ctx.close()
+    torch.cuda.empty_cache()
+    if with_cpu:
+        try:
+            rate, cores, dt = host_chacha_rate(q)
+            coefs = r * k.T_1 * kappa * kappa * D
+            regen_s = coefs / rate
+            cb = {"unit": "constraints/s", "cores": cores, "kind": "port", "extrapolated": True,
+                  "host_chacha_coefficients_per_s": rate,
+                  "sample": "CRS regeneration: %.2e coefficients of the oracle's scalar ChaCha20 + gen_range on %d threads in %.1f s -> %.0f s for "
+                            "the %.2e coefficients of B per proof (one proof per pass over B, as the reference regenerates rows per fetch)"
+                            % (rate * dt, cores, dt, regen_s, coefs)}
+            arith_s = None
+            if b1_s_per_proof_k1024:
+                # the arithmetic of step 3 grows with kappa1 * kappa: (2^14 / 2^10)^2 = 256 x the kappa = 1024 measurement (upper
+                # bound: the whole kappa = 1024 proof is scaled, not only its step 3)
+                arith_s = b1_s_per_proof_k1024 * (kappa / 1024.0) ** 2
+                cb["sample"] += "; arithmetic: B1's measured %.2f s per proof at kappa = 1024 x %d" % (b1_s_per_proof_k1024, int((kappa / 1024) ** 2))
+            cb["value"] = 1.0 / (regen_s + (arith_s or 0.0))
+            cb["s_per_proof"] = regen_s + (arith_s or 0.0)
+            rec["cpu_baseline"] = cb
+        except Exception as e:
+            rec["cpu_baseline"] = {"value": None, "unit": "constraints/s", "cores": cpu_share(), "kind": "port", "error": repr(e)}
+    return rec
+
+
 def launch_ranks(n_gpus, argv):
     """`bench.py --gpus N` without a launcher around it: start N ranks (one process per GPU) with torch.distributed.run
     BEFORE this process imports torch or touches the GPU, relay their output (rank 0 prints the JSON line) and exit
@@ -318,14 +441,17 @@ def launcher_selftest(args):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if os.environ["LAB_BENCH_SELFTEST"] == "fail" and rank == world - 1:
         return 3
-    seen = torch.ones(1, dtype=torch.int64)
+    # the same aggregation main() runs after its timed steps, on a stand-in vector (rank k contributes k+1 in every entry)
+    vec = torch.full((128,), rank + 1, dtype=torch.int64)
     if world > 1:
         dist.init_process_group("gloo")
-        dist.all_reduce(seen)
+    agg = aggregate_over_ranks(dist if world > 1 else None, vec, float(rank + 1), torch.device("cpu"))
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"selftest": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ranks_seen": int(seen.item())}))
+        print(json.dumps({"selftest": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ranks_seen": agg["ranks_seen"],
+                          "collective_backend": agg["backend"], "aggregate_commitment_vector": agg["vector"], "tmax": agg["tmax"]}))
     return 0
 
 
@@ -353,6 +479,8 @@ def main():
                     help="projection matrices Pi on the device: 2 bits per entry (lab_prove_input.Pi2) or one int8 per entry")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-kappa16384", action="store_true",
+                    help="skip extra.config3_kappa16384_streamed (one ~80 s step of the streamed prover at kappa = 2^14 after the headline)")
     ap.add_argument("--no-compact-crs", action="store_true", help="keep B, C, D in the main RNS basis (12 B/coefficient at the 33-bit q)")
     ap.add_argument("--digit-basis", choices=["auto", "u16", "mfma23"], default="auto",
                     help="digit basis of B, C, D: u16 = a prefix of the main primes plus one prime below 2^16 (10 B per coefficient, "
@@ -394,9 +522,9 @@ def main():
     nbatch = max(1, args.batch)
     use_mfma = args.step3 == "mfma" or (args.step3 == "auto" and nbatch > 8)
     basis23 = not args.no_compact_crs and (args.digit_basis == "mfma23" or (args.digit_basis == "auto" and use_mfma))
-    dSs, sts, dtapes, crs = build_workload(lab, ctx, k, q, dev, nbatch, 50 + rank * nbatch, 1000 + 10 * rank, use_mfma=use_mfma,
-                                           basis23=basis23, compact=not args.no_compact_crs, packed_pi=args.pi == "packed",
-                                           stream_b=args.crs == "streamed")
+    dSs, sts, dtapes = build_inputs(lab, ctx, k, q, dev, nbatch, 50 + rank * nbatch, packed_pi=args.pi == "packed")
+    crs = build_crs(lab, ctx, k, 1000 + 10 * rank, use_mfma=use_mfma, basis23=basis23, compact=not args.no_compact_crs,
+                    stream_b=args.crs == "streamed")
 
     # the boundary structures of the 64 proofs are built once (persistent input and output buffers, as a prover service
     # keeps them): a step is one lab_prove_core_batch call
@@ -426,13 +554,9 @@ def main():
     step3_kernel = ctx.profile_kernel()
     phases = ctx.profile_phases() if args.crs == "streamed" else None
 
-    # aggregate of the commitments across instances: one RCCL all-reduce of a checksum (outside the timed steps)
-    chk = checksum_u64(T.u_1) + checksum_u64(T.u_2)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(chk, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+    # aggregate of the commitments across instances: one RCCL all-reduce of the folded (u_1, u_2) vector (outside the timed steps)
+    agg = aggregate_over_ranks(dist, folded_commitments(T), elapsed, dev)
+    elapsed = agg["tmax"]
 
     result = None
     if rank == 0:
@@ -479,7 +603,8 @@ def main():
             "ms_per_proof": elapsed / (args.steps * nbatch) * 1e3,
             "proofs_per_s": value, "witness_Rq_elems_per_s": value * n * r,
             "ring_products_per_proof": sum(counts.values()),
-            "checksum_u1_u2": int(chk.item()),
+            "checksum_u1_u2": agg["scalar"], "aggregate_commitment_vector": agg["vector"],
+            "ranks_seen": agg["ranks_seen"], "collective_backend": agg["backend"],
             "roofline": {"bound": "hbm", "kernel": (("lab::%s — one 23-bit limb (3 digit planes) of the outer commitment "
                                                      "sum_ik B_ik t_i^(k) (src/proofgen.rs:101-132) for the %d proofs of a step, "
                                                      "one launch per limb" if basis23 else
@@ -549,6 +674,14 @@ def main():
                 result["cpu_baseline"] = {"value": None, "unit": "constraints/s", "cores": cpu_share(), "kind": "port", "error": repr(e)}
         else:
             result["cpu_baseline"] = None
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_kappa16384 and args.crs == "resident" and kappa < 16384:
+        # config 3 at the contract's commitment rank (kappa = 2^14, B streamed): the same instances, one step
+        b1 = (result.get("cpu_baseline") or {}).get("s_per_proof") if kappa == 1024 else None
+        plan = None
+        ctx.close()
+        torch.cuda.empty_cache()
+        extras["config3_kappa16384_streamed"] = config3_streamed(lab, dev, q, n, r, 16384, (dSs, sts, dtapes), b1_s_per_proof_k1024=b1,
+                                                                 with_cpu=not args.no_cpu_baseline)
         if extras:
             result["extra"] = extras
         print(json.dumps(result))
@@ -626,6 +759,12 @@ def side_measurements(lab, ctx, q, dev):
         c1.close()
     except Exception as e:  # never let a side measurement break the headline line
         out["outer_commitment_single_limb_q1073738753"] = {"error": str(e)}
+    # one proof per call at the headline modulus (latency, next to the batch-64 throughput of the headline line): B, C, D in the
+    # compact digit basis (10 B per coefficient), streamed by the multiply-add kernels
+    try:
+        out["single_proof_headline_q"] = single_proof_latency(lab, dev, q)
+    except Exception as e:
+        out["single_proof_headline_q"] = {"error": repr(e)}
     # SURVEY section 8(d) "q: report both": the NTT-friendly 32-bit q = 4294966657 on path (b) (q its own NTT prime: one limb,
     # 4 B per coefficient, strict-32 kernels) and on path (a) (LAB_CTX_RNS_ONLY: three 30-bit RNS limbs)
     try:
@@ -633,6 +772,32 @@ def side_measurements(lab, ctx, q, dev):
     except Exception as e:
         out["q4294966657_both_paths"] = {"error": repr(e)}
     return out
+
+
+def single_proof_latency(lab, dev, q, kappa=1024, rns_only=False):
+    """One proof per lab_prove_core call (n=1024, r=32, kappa=kappa1=kappa2=1024) in the best single-proof configuration: B, C, D in
+    the compact digit basis when one exists (else the main basis), B streamed from HBM by the multiply-add kernel."""
+    import torch
+    n, r = 1024, 32
+    ctx = lab.Context(q, dev.index or 0, max(65536, n * r + r * r), rns_only=rns_only)
+    ctx.use_torch_stream()
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa, kappa)
+    L = ctx.nlimbs
+    dSs, sts, dtapes, crs = build_workload(lab, ctx, k, q, dev, 1, 50, 1000, use_mfma=False, basis23=False, compact=True)
+    step = lambda: lab.prove_core(ctx, k, dSs[0], sts[0], crs, dtapes[0], device_outputs=True)
+    step()
+    torch.cuda.synchronize()
+    ctx.profile_begin()
+    t = _time(step, 5, warm=1)
+    ms, launches, alg = ctx.profile_end()
+    rec = {"q": q, "limbs": L, "proofs_per_s": 1.0 / t, "ms_per_proof": t * 1e3,
+           "crs_basis": "digit basis %s" % getattr(ctx, "digit_primes", None) if crs.compact else "main basis (q itself)" if L == 1 else "main basis",
+           "step3_kernel": ctx.profile_kernel(), "step3_launch_ms": ms / max(launches, 1),
+           "step3_algorithmic_GBps": alg / max(launches, 1) / (ms / max(launches, 1) / 1e3) / 1e9 if launches else None}
+    crs.close()
+    ctx.close()
+    torch.cuda.synchronize()
+    return rec
 
 
 def both_paths_q32(lab, dev, q=4294966657, kappa=1024):

@@ -34,7 +34,12 @@
  *   30-bit primes and only then reduced mod q — the same thing
  *   concrete-ntt's native64::Plan32 does for the reference, without its mod
  *   2^64 wrap (src/algebraic.rs:417-420).  If q itself is a prime with
- *   q == 1 (mod 128) and q < 2^30 the context uses q as its single limb.
+ *   q == 1 (mod 128) and q < 2^32 the context uses q as its single limb
+ *   (4 bytes per coefficient, no CRT): below 2^30 on the lazy kernels, in
+ *   [2^30, 2^32) on the strict-32 kernels (lab_info.nlimbs == 1 either way;
+ *   LAB_CTX_RNS_ONLY keeps the generic RNS path).  The main basis of such a
+ *   strict-32 context has no matrix-core form (lab_mat8_pack refuses it);
+ *   the 23-bit digit basis (lab_ctx_enable_digit_basis_mfma) serves it.
  *
  * Errors
  *   Every function returns LAB_OK (0) or a negative lab_status; nothing
@@ -173,8 +178,8 @@ int lab_vec_load_u64(lab_ctx *ctx, lab_vec *dst, size_t dst_off, const uint64_t 
 int lab_vec_store_u64(lab_ctx *ctx, const lab_vec *src, size_t src_off, size_t count, uint64_t *coeffs);
 /* Synthetic CRS / witness data: element k, coefficient j = splitmix64 stream
  * (seed, (first_elem+k)*64+j) scaled into [0,bound); identical to the oracle's
- * orc_synth_fill.  Stands in for CRS::fetch_* (src/structs.rs:55-171), whose
- * ChaCha20 expansion is out of scope this round. */
+ * orc_synth_fill.  A cheap stand-in for CRS::fetch_* (src/structs.rs:55-171) where the reference's own
+ * ChaCha20 expansion (lab_crs_expand below, lab_prove_input.crs_seed) is not what is being tested or timed. */
 int lab_vec_fill_synthetic(lab_ctx *ctx, lab_vec *dst, size_t dst_off, size_t count, uint64_t seed,
                            uint64_t first_elem, uint64_t bound);
 
@@ -362,10 +367,11 @@ typedef struct {
 int lab_prove_core(lab_ctx *ctx, const lab_prove_input *in, lab_transcript *out);
 
 /* `nproofs` independent proofs under ONE common reference string (same A, B, C, D handles, dimensions and
- * constants; each with its own witness, state and challenge tape).  Per-proof work is issued proof by proof; the
- * outer commitment sum_{i,k} B_ik t_i^(k) — whose cost is streaming the B matrices from HBM — is issued once per
- * group of up to 8 proofs with lab_matvec_sum_batched's kernel, so the CRS is read once per group rather than once
- * per proof.  Every transcript is bit-identical to what lab_prove_core returns for that proof alone.
+ * constants; each with its own witness, state and challenge tape).  The per-proof kernels take all proofs of the call as
+ * jobs of one launch; the outer commitment sum_{i,k} B_ik t_i^(k) — whose cost is streaming (B8 / B) or regenerating
+ * (crs_seed) the B matrices — is issued once per group of proofs: up to 64 per pass over B on the matrix cores (exact int8
+ * GEMMs), up to 8 with the multi-set multiply-add kernel when B is only present as residues.  Every transcript is
+ * bit-identical to what lab_prove_core returns for that proof alone.
  * status[j] (if status != NULL) receives LAB_OK / LAB_ERR_JL_REJECTED / LAB_ERR_BPP_CHECK for proof j and the call
  * returns LAB_OK; with status == NULL the first failing proof's code is returned. */
 int lab_prove_core_batch(lab_ctx *ctx, size_t nproofs, const lab_prove_input *const *in, lab_transcript *const *out,

@@ -54,7 +54,22 @@ struct CrsStream {
 };
 
 // rows per slab / matrices per chunk the engine will use
-size_t crs_stream_rows(size_t rows) { return rows < 128 ? rows : 128; }
+// rows per slab: the GEMM over a slab is one block per NTT slot and four 32-row tiles — 128 rows are 64 blocks, a quarter of the
+// chip's 256 CUs, and ran at 2.3 TB/s; 512 rows fill it.  Taken when the slab (its byte planes in operand order) stays below
+// 40 GB and free memory allows it, else 256 / 128.
+size_t crs_stream_rows(lab_ctx* c, int basis, size_t rows, size_t mc, size_t cols) {
+  if (rows <= 128) return rows;
+  const int L = basis_nlimbs(c, basis);
+  const size_t kt = ((mc * cols + 31) / 32 + 11) / 12 * 12;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+  for (size_t R = 512; R > 128; R /= 2) {
+    if (rows < R) continue;
+    const size_t slab = (size_t)L * D * 4 /* planes, at most */ * (R / 32) * kt * 1024;
+    if (slab <= ((size_t)40 << 30) && slab + ((size_t)8 << 30) <= free_b) return R;
+  }
+  return 128;
+}
 // matrices per K chunk: the int32 accumulators of the int8 GEMM hold 2^17 - 2 terms; a sum that (together with `extra_terms` the
 // caller adds to the result in the transform domain) exceeds the exactness bound of the basis is cut into chunks that respect it,
 // and their results are added mod q, not mod the limb primes (*reduce).  false: not even one matrix fits.
@@ -84,9 +99,9 @@ size_t crs_stream_scratch_bytes(lab_ctx* c, int basis, size_t nmat, size_t rows,
 int crs_stream_create(lab_ctx* c, int basis, size_t nmat, size_t rows, size_t cols, int ns, CrsStream** out, uint64_t extra_terms) {
   CrsStream* st = new CrsStream();
   st->c = c; st->basis = basis; st->rows = rows; st->cols = cols; st->ns = (size_t)ns;
-  st->R = crs_stream_rows(rows);
   if (!crs_stream_plan(c, basis, nmat, cols, extra_terms, &st->MC, &st->reduce)) st->MC = 0;
   if (st->MC == 0) { delete st; return fail(c, LAB_ERR_RANGE, "streamed commitment: %zu columns per matrix exceed the int32 bound of the int8 GEMM or the exactness bound of this basis", cols); }
+  st->R = crs_stream_rows(c, basis, rows, st->MC, cols);
   const int L = basis_nlimbs(c, basis);
   const size_t slab_elems = st->MC * st->R * cols;
   st->chunk = slab_elems < (CRS_CHUNK_POLYS) ? slab_elems : (CRS_CHUNK_POLYS);

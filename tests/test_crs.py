@@ -182,7 +182,10 @@ def test_gpu_prove_on_seed_addressed_crs_matches_oracle(contexts):
 @pytest.mark.parametrize("mfma_basis", [True, False])
 # cols % 64 == 0 on the 3-plane basis: the slab goes from coefficients to tiles in one pass (k_coefs_to_a8) — 131 rows: a 3-row
 # ragged slab; 4096 columns: expansion chunks of 64 rows inside a slab
-@pytest.mark.parametrize("nmat,rows,cols,ns", [(3, 40, 37, 8), (2, 300, 64, 32), (5, 130, 70, 64), (3, 131, 128, 16), (1, 70, 4096, 8)])
+# 300 rows: slabs of 256 rows (one full, one ragged of 44); 600 and 1100 rows: slabs of 512 (ragged 88 resp. 76 rows), on the
+# one-pass and on the transform + pack path
+@pytest.mark.parametrize("nmat,rows,cols,ns", [(3, 40, 37, 8), (2, 300, 64, 32), (5, 130, 70, 64), (3, 131, 128, 16), (1, 70, 4096, 8),
+                                               (2, 600, 70, 16), (3, 1100, 128, 8)])
 def test_streamed_crs_matvec_equals_materialise_then_multiply(mfma_basis, nmat, rows, cols, ns):
     # lab_crs_matvec_mfma: slabs of 128 rows expanded from the seed, transformed, packed, multiplied on the matrix cores
     # and discarded == lab_crs_expand of whole matrices + lab_mat8_pack + lab_matvec_sum_mfma, bit for bit; and the oracle's

@@ -79,6 +79,9 @@ def test_bench_launcher_starts_the_ranks_itself():
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["selftest"] is True and rec["ranks_seen"] == 2
+    # bench.aggregate_over_ranks, the code main() runs after its timed steps: the collective saw both ranks, says which backend
+    # carried it, summed the 128-entry commitment vector (rank k contributes k + 1 everywhere) and took the MAX of the times
+    assert rec["collective_backend"] == "gloo" and rec["aggregate_commitment_vector"] == [3] * 128 and rec["tmax"] == 2.0
     # a failing rank makes the launcher fail
     env["LAB_BENCH_SELFTEST"] = "fail"
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
