@@ -682,6 +682,7 @@ def main():
         torch.cuda.empty_cache()
         extras["config3_kappa16384_streamed"] = config3_streamed(lab, dev, q, n, r, 16384, (dSs, sts, dtapes), b1_s_per_proof_k1024=b1,
                                                                  with_cpu=not args.no_cpu_baseline)
+    if rank == 0:
         if extras:
             result["extra"] = extras
         print(json.dumps(result))

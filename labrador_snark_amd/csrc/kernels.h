@@ -155,6 +155,7 @@ struct Gemm8Args {
   unsigned planes, rt_count, kt_count, rgroups /* row groups per slot */, njobs, rows, ns, ns_valid;
   unsigned kt_real;         // k-tiles that hold terms (the rest of kt_count is zero padding): k_gemm_i8_w3 stops after them
   unsigned nsub;            // sets per source job (= ns unless several source jobs are multiplied as one job); ns_valid counts within it
+  unsigned jobs_per_block = 1;   // k_gemm_i8_w3p: jobs a persistent block works off (set by launch_gemm_i8)
   unsigned tile_r, tile_j;   // block-order super-tile (set by launch_gemm_i8)
   uint32_t p;
   const LimbTable* tab;     // this limb's table (device): Montgomery constants for the recombination

@@ -1009,6 +1009,149 @@ k_gemm_i8_w3(const Gemm8Args a) {
   }
 }
 
+// recombination of one job's 18 accumulator tiles (see k_gemm_i8_w3p) into the slot-major staging array (the kernel is only
+// launched for many jobs, which always go through it).  SMALL: sums of at most 2^15 terms over a 23-bit prime — the equal-weight
+// tiles add up in 32 bits, the five weights carry the Montgomery factor (pwm[e] = 256^e * 2^32 mod p), so ONE reduction of the
+// lifted 64-bit sum gives the residue.
+template <int NT, bool SMALL>
+__device__ __forceinline__ void w3p_recombine(const i32x16_t (&acc)[3 * NT], const Gemm8Args& a, unsigned job, unsigned j, unsigned rt, int lane,
+                                              uint32_t p, uint32_t p2, uint32_t pinv, uint32_t r2, const uint32_t (&pw)[5], uint64_t lift) {
+  constexpr int HALVES = NT / 3;
+  const unsigned ns = a.ns, rt_count = a.rt_count;
+  const bool whole = rt * 32 + 32 <= a.rows;        // every row of this tile exists (uniform)
+  uint32_t* st = a.stage + (((size_t)job * D + j) * (rt_count * 32) + rt * 32) * ns;
+#pragma unroll
+  for (int h = 0; h < HALVES; h++) {
+    const unsigned s = h * 32 + (lane & 31);
+    const bool s_ok = s % a.nsub < a.ns_valid;
+    uint32_t res[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      if constexpr (SMALL) {
+        const int32_t d00 = acc[0 * NT + 0 * HALVES + h][e], d01 = acc[0 * NT + 1 * HALVES + h][e], d02 = acc[0 * NT + 2 * HALVES + h][e];
+        const int32_t d10 = acc[1 * NT + 0 * HALVES + h][e], d11 = acc[1 * NT + 1 * HALVES + h][e], d12 = acc[1 * NT + 2 * HALVES + h][e];
+        const int32_t d20 = acc[2 * NT + 0 * HALVES + h][e], d21 = acc[2 * NT + 1 * HALVES + h][e], d22 = acc[2 * NT + 2 * HALVES + h][e];
+        int64_t s64 = (int64_t)lift + (int64_t)d00 * (int32_t)pw[0];
+        s64 += (int64_t)(d01 + d10) * (int32_t)pw[1];
+        s64 += (int64_t)(d02 + d11 + d20) * (int32_t)pw[2];
+        s64 += (int64_t)(d12 + d21) * (int32_t)pw[3];
+        s64 += (int64_t)d22 * (int32_t)pw[4];
+        // 0 <= s64 < 2^57: the high word is below 2^25 < 8p
+        uint32_t hi = (uint32_t)((uint64_t)s64 >> 32);
+        hi = min(hi, hi - 4 * p); hi = min(hi, hi - p2); hi = min(hi, hi - p);
+        res[e] = redc64(((uint64_t)hi << 32) | (uint32_t)s64, p, pinv);
+      } else {
+        uint64_t s64 = 0;                             // 9 products < 2^32 * p: the high word stays below 9p
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int iv = 0; iv < 3; iv++) s64 += (uint64_t)((uint32_t)acc[i * NT + iv * HALVES + h][e] ^ 0x80000000u) * pw[i + iv];
+        uint32_t hi = (uint32_t)(s64 >> 32);
+        hi = min(hi, hi - 8 * p); hi = min(hi, hi - 4 * p); hi = min(hi, hi - p2); hi = min(hi, hi - p);
+        const uint32_t v = mont_mul(redc64(((uint64_t)hi << 32) | (uint32_t)s64, p, pinv), r2, p, pinv);
+        res[e] = csub(v + p - a.bias, p);
+      }
+    }
+    if (!s_ok) continue;
+    if (whole) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) st[(size_t)((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * ns + s] = res[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const unsigned row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (rt * 32 + row < a.rows) st[(size_t)row * ns + s] = res[e];
+      }
+    }
+  }
+}
+
+// ---- the same GEMM for MANY jobs that share the matrix (the Ajtai product t = A S of a batch: 32 two-proof jobs of 64 sets
+// against a kappa x n matrix whose K loop is only n / 32 = 32 k-tiles long).  In k_gemm_i8_w3 every (job, 128 rows, slot) is its
+// own block: 11.9 us of matrix instructions sit between 3.9 us of block start-up (dispatch, argument loads, 288 accumulator
+// moves, the first loads' round trip) and 6 us of recombination, with one wave per SIMD and nothing to overlap them — the
+// matrix pipe is 54 % busy (in-kernel stamps; tools/ubench_mfma_i8.hip puts the ceiling of this operand
+// traffic at 2.6 POP/s against 1.77).  Here a block is PERSISTENT over `jobs_per_block` jobs of its (slot, row group):
+//   * the B stages 0..2 of job b+1 are on their way (LDS-DMA: no register is in flight while compiler code runs) before the
+//     results of job b are recombined, the A operands (L2 hits: the matrix is shared) are issued at the top of its loop;
+//   * the first k-tile's matrix instructions take 0 as their C operand: the accumulators are never zeroed;
+//   * dispatch, argument loads and address set-up are paid once per block;
+//   * sums of at most 2^15 terms (|D| <= K * 2^14 < 2^29: equal-weight tiles add up in 32 bits) recombine with 4 signed
+//     multiply-adds instead of 9 unsigned ones.
+// DIAG (lab_ctx_gemm_diag mode 4): every block records shader / constant clock ticks of its whole life and of its K loops alone
+// in diag_buf[4 * block .. + 3]
+template <int NT, bool SMALL, bool DIAG = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_gemm_i8_w3p(const Gemm8Args a) {
+  uint64_t d_t0 = 0, d_r0 = 0, d_loop_t = 0, d_loop_r = 0;
+  if constexpr (DIAG) { d_t0 = __builtin_amdgcn_s_memtime(); d_r0 = __builtin_amdgcn_s_memrealtime(); }
+  static_assert(NT == 6, "64 sets of 3 planes");
+  constexpr int PIECES = W3_KS * NT;
+  constexpr int PPW = (PIECES + 3) / 4;
+  __shared__ u32x4_t bring[W3_RING * PIECES * 64];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const unsigned rt_count = a.rt_count, kt_count = a.kt_count;
+  const unsigned jpb = a.jobs_per_block, nchunks = (a.njobs + jpb - 1) / jpb;
+  const unsigned x = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const unsigned per_j = a.rgroups * nchunks;
+  const unsigned j = x + 8 * (seq / per_j), sub = seq % per_j;
+  const unsigned chunk = sub % nchunks, rg = sub / nchunks;
+  const unsigned rt = rg * 4 + w;
+  const unsigned rtc = min(rt, rt_count - 1);
+  const int first_piece = min(w * PPW, PIECES - PPW);
+  const uint64_t a0 = (uint64_t)(uintptr_t)a.M8 + (((size_t)j * 3 + 0) * rt_count + rtc) * kt_count * 1024;
+  const uint64_t a1 = (uint64_t)(uintptr_t)a.M8 + (((size_t)j * 3 + 1) * rt_count + rtc) * kt_count * 1024;
+  const uint64_t a2 = (uint64_t)(uintptr_t)a.M8 + (((size_t)j * 3 + 2) * rt_count + rtc) * kt_count * 1024;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)bring;
+  const uint32_t voff = lane * 16, vlds = lds0 + lane * 16;
+  const uint32_t m0b = __builtin_amdgcn_readfirstlane(lds0 + first_piece * 1024);
+  const uint32_t nstages = __builtin_amdgcn_readfirstlane(min(kt_count / W3_KS, 2 * ((a.kt_real + 2 * W3_KS - 1) / (2 * W3_KS))));
+  const unsigned job0 = chunk * jpb, job1 = min(a.njobs, job0 + jpb);
+  auto bg_of = [&](unsigned job) {
+    return (uint64_t)(uintptr_t)a.V8 + (size_t)job * a.v8_job_stride + (size_t)j * kt_count * NT * 1024 + first_piece * 1024 + lane * 16;
+  };
+  const uint32_t p = a.p;
+  const LimbTable* tab = a.tab;
+  const uint32_t p2 = tab->p2, pinv = tab->pinv, r2 = tab->r2;
+  uint32_t pw[5];
+#pragma unroll
+  for (int e = 0; e < 5; e++) pw[e] = SMALL ? mont_mul(a.pw[e], tab->r2, p, pinv) : a.pw[e];   // SMALL: 256^e * 2^32 mod p
+  // SMALL (chosen by the launcher): every tile entry is below K * 2^14 with 3 * K * 2^14 < 2^31, so three of them add up in 32
+  // bits and the weighted sum of the nine tiles stays below 3 * 2^54 in absolute value; `lift` (a multiple of p above that)
+  // makes it non-negative, and the high word of the lifted sum is below 2^25 < 8p for the 23-bit primes this path is taken for
+  const uint64_t lift = (((1ull << 56) / p) + 1) * (uint64_t)p;
+
+  uint64_t bg = bg_of(job0);
+  asm volatile(W3P_BISSUE_ASM_NT6 : "+v"(bg) : "s"(m0b), "s"(nstages) : W3P_BISSUE_CLOBBERS);
+  for (unsigned job = job0; job < job1; job++) {
+    i32x16_t acc[3 * NT];
+    uint64_t lt0 = 0, lr0 = 0;
+    if constexpr (DIAG) { lt0 = __builtin_amdgcn_s_memtime(); lr0 = __builtin_amdgcn_s_memrealtime(); }
+    asm volatile(W3P_LOOP_ASM_NT6
+                 : "=&a"(acc[0]), "=&a"(acc[1]), "=&a"(acc[2]), "=&a"(acc[3]), "=&a"(acc[4]), "=&a"(acc[5]), "=&a"(acc[6]), "=&a"(acc[7]),
+                   "=&a"(acc[8]), "=&a"(acc[9]), "=&a"(acc[10]), "=&a"(acc[11]), "=&a"(acc[12]), "=&a"(acc[13]), "=&a"(acc[14]),
+                   "=&a"(acc[15]), "=&v"(acc[16]), "=&v"(acc[17]), "+v"(bg)
+                 : "s"(a0), "s"(a1), "s"(a2), "v"(voff), "v"(vlds), "s"(m0b), "s"(nstages)
+                 : W3_LOOP_CLOBBERS_NT6_PLAIN);
+    if constexpr (DIAG) { d_loop_t += __builtin_amdgcn_s_memtime() - lt0; d_loop_r += __builtin_amdgcn_s_memrealtime() - lr0; }
+    if (job + 1 < job1) {   // the next job's first B stages travel while this job's results are recombined
+      bg = bg_of(job + 1);
+      asm volatile(W3P_BISSUE_ASM_NT6 : "+v"(bg) : "s"(m0b), "s"(nstages) : W3P_BISSUE_CLOBBERS);
+    }
+    if (rt >= rt_count) continue;
+    w3p_recombine<NT, SMALL>(acc, a, job, j, rt, lane, p, p2, pinv, r2, pw, lift);
+  }
+  if constexpr (DIAG) {
+    if (t == 0 && a.diag_buf && 4 * (size_t)blockIdx.x + 3 < a.diag_words) {
+      a.diag_buf[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - d_t0;
+      a.diag_buf[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - d_r0;
+      a.diag_buf[4 * blockIdx.x + 2] = d_loop_t;
+      a.diag_buf[4 * blockIdx.x + 3] = d_loop_r;
+    }
+  }
+}
+
 // stage[job][j][row][s] -> out[job*out_job_stride + s*out_set_stride + row*64 + j]; block = (row, job)
 __global__ void __launch_bounds__(256)
 k_slot_transpose(uint32_t* __restrict__ out, size_t out_set_stride, size_t out_job_stride, const uint32_t* __restrict__ stage,
@@ -1053,9 +1196,21 @@ hipError_t launch_gemm_i8(const Gemm8Args& a, size_t nt, int waves, hipStream_t 
   if (waves == 6) hipLaunchKernelGGL((k_gemm_i8<NTV, 6>), g, dim3(384), 0, s, a);                     \
   else hipLaunchKernelGGL((k_gemm_i8<NTV, 3>), g, dim3(192), 0, s, a)
   if (a.planes == 3 && waves == 4) {                // 3-plane limbs, one row tile (all three planes) per wave
-    if (nt == 6 && ((a.diag == 1 && a.njobs == 1) || (a.diag == 4 && a.njobs > 1))) hipLaunchKernelGGL((k_gemm_i8_w3<6, 1>), g, dim3(256), 0, s, a);
+    if (nt == 6 && ((a.diag == 1 && a.njobs == 1) || (a.diag == 4 && a.njobs > 1 && a.njobs < 4))) hipLaunchKernelGGL((k_gemm_i8_w3<6, 1>), g, dim3(256), 0, s, a);
     else if (nt == 6 && a.diag == 2 && a.njobs == 1) hipLaunchKernelGGL((k_gemm_i8_w3<6, 2>), g, dim3(256), 0, s, a);
     else if (nt == 6 && a.diag == 3 && a.njobs == 1) hipLaunchKernelGGL((k_gemm_i8_w3<6, 3>), g, dim3(256), 0, s, a);
+    else if (nt == 6 && a.njobs >= 4 && (a.diag == 0 || a.diag == 4)) {
+      // many jobs share the matrix: persistent blocks, about four per CU over the launch
+      Gemm8Args b = a;
+      unsigned jpb = 16;
+      while (jpb > 1 && (size_t)D * a.rgroups * ((a.njobs + jpb - 1) / jpb) < 1024) jpb /= 2;
+      b.jobs_per_block = jpb;
+      dim3 gp((unsigned)(D * a.rgroups * ((a.njobs + jpb - 1) / jpb)));
+      const bool small = (uint64_t)a.kt_real * 32 * 3 * 16384 < (1ull << 31) && a.p > (1u << 22);
+      if (a.diag == 4 && small) hipLaunchKernelGGL((k_gemm_i8_w3p<6, true, true>), gp, dim3(256), 0, s, b);
+      else if (small) hipLaunchKernelGGL((k_gemm_i8_w3p<6, true>), gp, dim3(256), 0, s, b);
+      else hipLaunchKernelGGL((k_gemm_i8_w3p<6, false>), gp, dim3(256), 0, s, b);
+    }
     else if (nt == 6) hipLaunchKernelGGL((k_gemm_i8_w3<6>), g, dim3(256), 0, s, a);
     else if (nt == 3) hipLaunchKernelGGL((k_gemm_i8_w3<3>), g, dim3(256), 0, s, a);
     else return hipErrorInvalidValue;

@@ -334,6 +334,37 @@ def test_verifier_needs_the_unpacked_B():
     ctx.close()
 
 
+@pytest.mark.parametrize("nb,kappa", [(8, 130), (12, 256), (16, 128), (34, 130)])
+def test_ajtai_product_on_persistent_blocks(nb, kappa):
+    # r = 32, at least 8 proofs, at least 128 rows of A: the Ajtai product t = A S of the batch runs on k_gemm_i8_w3p — blocks that
+    # stay on their (slot, 128 rows) for several two-proof jobs, the next job's operands under way while the last one's sums are
+    # recombined (130 rows: a second row group whose waves 2, 3 have no tile; 34 proofs: 17 jobs in chunks of 16 + 1).  Every field
+    # equals the multiply-add path, t and u_1 of the first and last proof equal the oracle.
+    import labrador_snark_amd as lab
+    q, n, r, kappa1 = Q_REF33, 6, 32, 36
+    ctx = lab.Context(q, 0, **ctx_kw(q))
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
+    crs = lab.ResidentCRS(ctx, k, mfma_basis=True).fill_synthetic(1000)
+    ws, sts, tapes, wants = [], [], [], {}
+    for j in range(nb):
+        case, (S, phi, a, tape) = cases.oracle_case(p, seed=2100 + j)
+        ws.append(S); sts.append(lab.State(phi, a, case.b_prime)); tapes.append(tape)
+        if j in (0, nb - 1):
+            wants[j] = case.prove()
+    ref = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes)
+    crs.pack_mfma()
+    got = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes)
+    assert ctx.prove_flags() == 1
+    for j in range(nb):
+        for f in ("t_i_all", "g_mat", "h_mat", "u_1", "u_2", "z", "b_prime_prime", "projection_int"):
+            assert np.array_equal(getattr(got[j], f), getattr(ref[j], f)), (j, f)
+    for j, w in wants.items():
+        assert np.array_equal(got[j].t_i_all, w["t"]) and np.array_equal(got[j].u_1, w["u1"]) and np.array_equal(got[j].h_mat, w["H"])
+    crs.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("mfma_basis", [False, True])
 @pytest.mark.parametrize("nb", [2, 4, 5])
 def test_prove_core_batch_matrix_cores_r32(nb, mfma_basis):

@@ -31,9 +31,13 @@ KS, RING, PF = 2, 4, 3
 RING0, FR0 = 120, 216
 
 
-def gen(NT, nt_loads, mode="full"):
+def gen(NT, nt_loads, mode="full", persistent=False):
     """mode: "full"; the diagnostic variants "noload" (no global loads / LDS-DMA: the multiply side alone) and "nomfma"
-    (no matrix instructions or LDS reads: the load side alone) keep everything else — waits, barriers, address updates"""
+    (no matrix instructions or LDS reads: the load side alone) keep everything else — waits, barriers, address updates.
+    persistent: the loop of a block that works off several jobs (k_gemm_i8_w3p) — the B stages 0..2 of the job were issued by
+    gen_bissue()'s block BEFORE the previous job's results were recombined (LDS-DMA: no register is in flight while the
+    compiler's code runs), so the prologue here issues the A operands only; the first k-tile's matrix instructions take 0 as
+    their C operand (the accumulators are never zeroed)."""
     nacc = 3 * NT
     pieces = KS * NT
     ppw = (pieces + 3) // 4
@@ -81,7 +85,19 @@ def gen(NT, nt_loads, mode="full"):
             for ins in grp:
                 emit(ins)
 
-    def stage(k):
+    def issue_a_only(slot):
+        """persistent prologue: the A operands of one stage (its B pieces are already on their way)"""
+        for ks in range(KS):
+            for i in range(3):
+                emit("global_load_dwordx4 %s, %%%d, %s offset:%d%s" % (ring(slot, ks, i), o_voff, sa[i], ks * 1024, nt))
+        emit("s_add_u32 s40, s40, 1")
+        emit("s_cmp_lt_u32 s40, %%%d" % o_nst)
+        emit("s_cselect_b32 s44, %d, 0" % (KS * 1024))
+        for i in range(3):
+            emit("s_add_u32 s%d, s%d, s44" % (46 + 2 * i, 46 + 2 * i))
+            emit("s_addc_u32 s%d, s%d, 0" % (47 + 2 * i, 47 + 2 * i))
+
+    def stage(k, first=False):
         """multiply ring slot k; issue the loads of three stages ahead into slot (k+3)%4, spread between the matrix instructions"""
         emit("s_waitcnt vmcnt(%d)" % left)
         emit("s_barrier")
@@ -92,7 +108,8 @@ def gen(NT, nt_loads, mode="full"):
             emit("s_waitcnt lgkmcnt(%d)" % (PF - 1))
             for i in range(3):
                 if mode != "nomfma":
-                    emit("v_mfma_i32_32x32x32_i8 %%%d, %s, %s, %%%d" % (i * NT + n, ring(k, ks, i), fr(f % PF), i * NT + n))
+                    c_op = "0" if (first and ks == 0) else "%%%d" % (i * NT + n)
+                    emit("v_mfma_i32_32x32x32_i8 %%%d, %s, %s, %s" % (i * NT + n, ring(k, ks, i), fr(f % PF), c_op))
             nxt = f + PF
             if mode == "nomfma":
                 pass
@@ -107,19 +124,43 @@ def gen(NT, nt_loads, mode="full"):
             for ins in pending.pop(0):
                 emit(ins)
 
-    emit("s_waitcnt vmcnt(0) lgkmcnt(0)")     # nothing of the compiler's may be counted with this block's operations
-    for i in range(3):
-        emit("s_mov_b64 %s, %%%d" % (sa[i], o_a[i]))
-    emit("s_mov_b32 s40, 0")
-    emit("s_mov_b32 s41, 0")
-    emit("s_mov_b32 s43, 0")
-    for s in range(3):
-        issue_now(s)
-    emit("s_waitcnt vmcnt(%d)" % (2 * ops))
+    if persistent:
+        # The queue holds, oldest first: the compiler's result stores of the previous job, the B stages 0..2 (gen_bissue) and now
+        # the A operands of stages 0..2.  Everything but the last two A stages has landed at vmcnt(2 * 3 * KS).
+        emit("s_waitcnt lgkmcnt(0)")
+        for i in range(3):
+            emit("s_mov_b64 %s, %%%d" % (sa[i], o_a[i]))
+        emit("s_mov_b32 s40, 0")
+        emit("s_mov_b32 s41, 0")
+        emit("s_mov_b32 s43, 0")
+        for s_ in range(3):
+            issue_a_only(s_)
+        emit("s_waitcnt vmcnt(%d)" % (2 * 3 * KS))
+    else:
+        emit("s_waitcnt vmcnt(0) lgkmcnt(0)")     # nothing of the compiler's may be counted with this block's operations
+        for i in range(3):
+            emit("s_mov_b64 %s, %%%d" % (sa[i], o_a[i]))
+        emit("s_mov_b32 s40, 0")
+        emit("s_mov_b32 s41, 0")
+        emit("s_mov_b32 s43, 0")
+        for s_ in range(3):
+            issue_now(s_)
+        emit("s_waitcnt vmcnt(%d)" % (2 * ops))
     emit("s_barrier")
     for f in range(PF):
         if mode != "nomfma":
             emit("ds_read_b128 %s, %%%d offset:%d" % (fr(f), o_vlds, f * 1024))
+    if persistent:   # the first two stages once more in front of the loop, the very first k-tile writing fresh sums
+        stage(0, first=True)
+        stage(1)
+        emit("s_add_u32 s41, s41, 2")
+        emit("s_cmp_ge_u32 s41, %%%d" % o_nst)
+        emit("s_cbranch_scc1 2f")
+        stage(2)
+        stage(3)
+        emit("s_add_u32 s41, s41, 2")
+        emit("s_cmp_ge_u32 s41, %%%d" % o_nst)
+        emit("s_cbranch_scc1 2f")
     emit("1:")
     stage(0)
     stage(1)
@@ -140,6 +181,23 @@ def gen(NT, nt_loads, mode="full"):
     return L, clob
 
 
+def gen_bissue(NT):
+    """B stages 0..2 of a job by LDS-DMA into ring slots 0..2 (k_gemm_i8_w3p issues them for job b+1 as soon as the K loop of job b
+    has ended, before its results are recombined).  Operands: %0 BG (+v, 64-bit, advanced by three stages like the loop's own
+    issue would), %1 M0B (s), %2 NST (s).  The barrier: no wave may still be reading the previous job's fragments from the ring."""
+    pieces = KS * NT
+    ppw = (pieces + 3) // 4
+    slot_bytes = pieces * 1024
+    L = ["s_waitcnt lgkmcnt(0)", "s_barrier", "s_mov_b32 s45, 0", "s_mov_b32 s43, 0"]
+    for slot in range(3):
+        L += ["s_add_u32 m0, %%1, %d" % (slot * slot_bytes), "s_nop 0", "global_load_lds_dwordx4 %0, off"]
+        for q in range(1, ppw):
+            L.append("global_load_lds_dwordx4 %%0, off offset:%d" % (q * 1024))
+        L += ["s_add_u32 s45, s45, 1", "s_cmp_lt_u32 s45, %2", "s_cselect_b32 s42, %d, 0" % (pieces * 1024),
+              "v_lshl_add_u64 %0, %0, 0, s[42:43]"]
+    return L, ['"s42"', '"s43"', '"s45"', '"scc"', '"memory"']
+
+
 def main():
     out = ["// GENERATED by tools/gen_gemm_w3_asm.py — do not edit.  The K loop of k_gemm_i8_w3 (see mfma_kernels.hip).", ""]
     for NT in (3, 6):
@@ -152,6 +210,19 @@ def main():
             out.append("")
             out.append("#define W3_LOOP_CLOBBERS_%s %s" % (name, ", ".join(clob)))
             out.append("")
+    # the persistent-block variant (k_gemm_i8_w3p: many jobs share the matrix): plain A loads, 64 sets
+    L, clob = gen(6, 0, persistent=True)
+    out.append("#define W3P_LOOP_ASM_NT6 \\")
+    for k, ins in enumerate(L):
+        out.append('    "%s\\n\\t"%s' % (ins, " \\" if k + 1 < len(L) else ""))
+    out.append("")
+    L, clob = gen_bissue(6)
+    out.append("#define W3P_BISSUE_ASM_NT6 \\")
+    for k, ins in enumerate(L):
+        out.append('    "%s\\n\\t"%s' % (ins, " \\" if k + 1 < len(L) else ""))
+    out.append("")
+    out.append("#define W3P_BISSUE_CLOBBERS %s" % ", ".join(clob))
+    out.append("")
     # diagnostic variants of the outer commitment's loop (NT = 6, non-temporal A loads): lab_ctx_gemm_diag modes 2 and 3
     for mode in ("noload", "nomfma"):
         L, clob = gen(6, 1, mode)

@@ -31,14 +31,36 @@ __device__ __forceinline__ uint32_t mix(uint32_t x) {
   return x;
 }
 
+// hipcc's wait-count pass cannot follow loads that are consumed several loop trips after they were issued (it falls back to
+// vmcnt(0..1) inside the loop — the very thing the product kernel's assembly K loop exists to avoid), so the stream variant issues
+// its loads and counts its waits by hand: 16 loads in flight, the oldest one is complete at vmcnt(15)
+#define GLOAD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(ptr) : "memory")
+#define WAIT_OLDEST_OF_16(reg) asm volatile("s_waitcnt vmcnt(15)" : "+v"(reg) : : "memory")
+
 constexpr int NACC = 3;   // independent accumulator tiles per wave (an MFMA result is not read again for 3 instructions)
 constexpr int NOPS = 4;   // distinct A and B register operands cycled through
 
 // MODE 0: operands stay in registers.  MODE 1: every third MFMA's B operand arrives from HBM (each wave streams its own
 // region with 16-byte non-temporal loads, three loads in flight).  ZERO: all-zero operands (the "idle data" clock).
-template <int MODE, bool ZERO>
+__global__ void k_fill(uint32_t* p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = mix((uint32_t)i * 2654435761u + (uint32_t)(i >> 32));
+}
+
+// MODE = streamed B operands per 12-MFMA trip (0: none; 2: 171 B per MFMA, the product kernel's ratio — 20.55 GB per 1.13e8 MFMAs;
+// 4: twice that)
+// HOT: the streamed operands come from a 1-MiB region every wave shares (L2 hits, like the A tiles of the Ajtai product that 32
+// jobs share) and every group's second MFMA takes its B operand from LDS (one ds_read_b128 per 3 MFMAs, the product kernels' ratio)
+template <int MODE, bool ZERO, bool HOT = false>
 __global__ void __launch_bounds__(256) k_mfma(uint64_t* __restrict__ stamps, int* __restrict__ sink, const v4i* __restrict__ stream,
                                               size_t stream_words_per_wave, int iters, uint32_t seed) {
+  __shared__ v4i lds[HOT ? 256 * 4 : 1];
+  if (HOT) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) lds[i * 256 + threadIdx.x][j] = (int)mix(seed * 7u + threadIdx.x * 4099u + i * 16u + j);
+    __syncthreads();
+  }
   const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   v4i a[NOPS], b[NOPS];
 #pragma unroll
@@ -53,30 +75,52 @@ __global__ void __launch_bounds__(256) k_mfma(uint64_t* __restrict__ stamps, int
   for (int n = 0; n < NACC; n++)
 #pragma unroll
     for (int j = 0; j < 16; j++) acc[n][j] = 0;
-  const v4i* src = stream + (size_t)wave * stream_words_per_wave + lane;
-  v4i ring[3];
+  if (HOT) stream_words_per_wave = 4096;   // 64 KiB per wave slot, 16 slots: 1 MiB shared by all waves
+  const v4i* src = stream + (size_t)(HOT ? wave % 16 : wave) * stream_words_per_wave + lane;
+  // MODE 1: 16 one-KiB wave loads in flight (the product kernel keeps 72 KB per CU = 18 KB per wave in flight): a load is used 48
+  // MFMAs (~1 us) after it was issued
+  v4i ring[16];
   size_t pos = 0;
-  if (MODE == 1) {
+  if (MODE != 0) {
 #pragma unroll
-    for (int i = 0; i < 3; i++) { ring[i] = __builtin_nontemporal_load(src + pos); pos += 64; }
+    for (int i = 0; i < 16; i++) { GLOAD(ring[i], src + pos); pos += 64; }
   }
   const uint64_t t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-  for (int it = 0; it < iters; it++) {
-    // 12 MFMAs per trip: 3 groups of NACC; in MODE 1 the first MFMA of every group of three takes a streamed B operand
+  constexpr int LPT = MODE ? MODE : 4;     // streamed operands per 12-MFMA trip
+  constexpr int TRIPS = 16 / LPT;          // trips unrolled so that one pass over the ring of 16 is one outer iteration
+  for (int it = 0; it < iters; it += TRIPS) {
+    // 12 MFMAs per trip: 4 groups of 3; a group's first MFMA takes a streamed B operand when it is that group's turn
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-      v4i bs = b[g % NOPS];
-      if (MODE == 1) {
-        bs = ring[g % 3];
-        if (pos + 64 <= stream_words_per_wave) ring[g % 3] = __builtin_nontemporal_load(src + pos);
-        pos += 64;
-        if (pos + 64 > stream_words_per_wave) pos = 0;
+    for (int tt = 0; tt < TRIPS; tt++) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        v4i bs = b[g % NOPS];
+        if (MODE != 0 && g % (4 / LPT) == 0) {
+          const int slot = tt * LPT + g / (4 / LPT);
+          WAIT_OLDEST_OF_16(ring[slot]);
+          bs = ring[slot];
+          GLOAD(ring[slot], src + pos);
+          pos += 64;
+          if (pos + 64 > stream_words_per_wave) pos = 0;
+        }
+        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[g % NOPS], bs, acc[0], 0, 0, 0);
+        v4i bl = b[(g + 1) % NOPS];
+        if (HOT) bl = lds[((tt + g) % 4) * 256 + threadIdx.x];
+        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[(g + 1) % NOPS], bl, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[(g + 2) % NOPS], b[(g + 3) % NOPS], acc[2], 0, 0, 0);
       }
-      acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[g % NOPS], bs, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[(g + 1) % NOPS], b[(g + 1) % NOPS], acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[(g + 2) % NOPS], b[(g + 3) % NOPS], acc[2], 0, 0, 0);
     }
+    if (HOT) asm volatile("" ::: "memory");   // the LDS reads stay inside the loop
   }
+  // The compiler does not know that the hand-issued loads still write the ring registers: they must have landed before those
+  // registers are dead and handed to other values (a late load into a reused register — e.g. the one holding the address of the
+  // stamps — is a wild store).  The operands keep all 16 alive up to this wait.
+  if (MODE != 0)
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(ring[0]), "+v"(ring[1]), "+v"(ring[2]), "+v"(ring[3]), "+v"(ring[4]), "+v"(ring[5]), "+v"(ring[6]), "+v"(ring[7]),
+                   "+v"(ring[8]), "+v"(ring[9]), "+v"(ring[10]), "+v"(ring[11]), "+v"(ring[12]), "+v"(ring[13]), "+v"(ring[14]), "+v"(ring[15])
+                 :
+                 : "memory");
   const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   int x = 0;
 #pragma unroll
@@ -89,16 +133,16 @@ __global__ void __launch_bounds__(256) k_mfma(uint64_t* __restrict__ stamps, int
 
 struct Result { double ms, pops, shader_ghz, busy; };
 
-template <int MODE, bool ZERO>
+template <int MODE, bool ZERO, bool HOT = false>
 static int run(int blocks, int iters, uint64_t* dstamps, int* dsink, const v4i* dstream, size_t words_per_wave, Result* res) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
   const int waves = blocks * 4;
-  hipLaunchKernelGGL((k_mfma<MODE, ZERO>), dim3(blocks), dim3(256), 0, 0, dstamps, dsink, dstream, words_per_wave, iters / 8, 1u);   // warm-up
+  hipLaunchKernelGGL((k_mfma<MODE, ZERO, HOT>), dim3(blocks), dim3(256), 0, 0, dstamps, dsink, dstream, words_per_wave, iters / 8, 1u);   // warm-up
   CHECK(hipDeviceSynchronize());
   CHECK(hipEventRecord(e0));
-  hipLaunchKernelGGL((k_mfma<MODE, ZERO>), dim3(blocks), dim3(256), 0, 0, dstamps, dsink, dstream, words_per_wave, iters, 7u);
+  hipLaunchKernelGGL((k_mfma<MODE, ZERO, HOT>), dim3(blocks), dim3(256), 0, 0, dstamps, dsink, dstream, words_per_wave, iters, 7u);
   CHECK(hipEventRecord(e1));
   CHECK(hipDeviceSynchronize());
   float ms = 0;
@@ -112,6 +156,7 @@ static int run(int blocks, int iters, uint64_t* dstamps, int* dsink, const v4i* 
   res->pops = (double)waves * mfmas * 32768.0 * 2.0 / (ms * 1e-3) / 1e15;
   res->shader_ghz = ticks / real * 0.1;                   // s_memrealtime ticks at 100 MHz
   // cycles a SIMD's matrix pipe is busy per MFMA: 32 for 32x32x32 i8 (8 passes x 4 cycles); waves per SIMD share the pipe
+  // (meaningful at one wave per SIMD; with two, blocks that start late run alone for part of their loop)
   res->busy = mfmas * 32.0 * (waves / 1024.0 > 1.0 ? waves / 1024.0 : 1.0) / (ticks / waves);
   return 0;
 }
@@ -125,23 +170,28 @@ int main(int argc, char** argv) {
   CHECK(hipMalloc(reinterpret_cast<void**>(&dstamps), 2 * 2048 * 8));
   CHECK(hipMalloc(reinterpret_cast<void**>(&dsink), 2048 * 4));
   CHECK(hipMalloc(reinterpret_cast<void**>(&dstream), 2048 * words_per_wave * 16));
-  CHECK(hipMemset(dstream, 0x5a, 2048 * words_per_wave * 16));
+  hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, reinterpret_cast<uint32_t*>(dstream), 2048 * words_per_wave * 4);   // random bytes
+  CHECK(hipDeviceSynchronize());
   printf("{\n \"instruction\": \"v_mfma_i32_32x32x32_i8\", \"mfmas_per_wave\": %.0f, \"datasheet_peak_POPs\": 5.0,\n", 12.0 * iters);
   printf(" \"note\": \"POP/s = 2 x int8 multiply-adds per second over the whole launch (HIP events); shader clock = s_memtime / s_memrealtime "
          "ticks around the loop of every wave; pipe_busy = 32 cycles per MFMA x waves per SIMD / loop cycles\",\n \"runs\": [\n");
   struct Case { const char* name; int blocks; int mode; bool zero; } cases[] = {
       {"registers_random_1_wave_per_simd", 256, 0, false}, {"registers_random_2_waves_per_simd", 512, 0, false},
-      {"registers_zero_1_wave_per_simd", 256, 0, true},    {"hbm_stream_random_1_wave_per_simd", 256, 1, false},
-      {"hbm_stream_random_2_waves_per_simd", 512, 1, false}};
+      {"registers_zero_1_wave_per_simd", 256, 0, true},
+      {"hbm_stream_171B_per_mfma_1_wave_per_simd", 256, 2, false}, {"hbm_stream_171B_per_mfma_2_waves_per_simd", 512, 2, false},
+      {"hbm_stream_341B_per_mfma_1_wave_per_simd", 256, 4, false},
+      {"l2_hot_171B_per_mfma_plus_lds_operand_per_3_mfma_1_wave_per_simd", 256, 5, false}};
   for (size_t i = 0; i < sizeof(cases) / sizeof(cases[0]); i++) {
     Result r{};
     int rc;
     const Case& c = cases[i];
     if (c.mode == 0 && !c.zero) rc = run<0, false>(c.blocks, iters, dstamps, dsink, dstream, words_per_wave, &r);
     else if (c.mode == 0) rc = run<0, true>(c.blocks, iters, dstamps, dsink, dstream, words_per_wave, &r);
-    else rc = run<1, false>(c.blocks, iters, dstamps, dsink, dstream, words_per_wave, &r);
+    else if (c.mode == 2) rc = run<2, false>(c.blocks, iters, dstamps, dsink, dstream, words_per_wave, &r);
+    else if (c.mode == 5) rc = run<2, false, true>(c.blocks, iters, dstamps, dsink, dstream, words_per_wave, &r);
+    else rc = run<4, false>(c.blocks, iters, dstamps, dsink, dstream, words_per_wave, &r);
     if (rc) return rc;
-    const double stream_gbs = c.mode == 1 ? (double)c.blocks * 4 * (4.0 * iters) * 1024.0 / (r.ms * 1e-3) / 1e9 : 0.0;
+    const double stream_gbs = c.mode == 5 ? 0.0 : (double)c.blocks * 4 * ((double)c.mode * iters) * 1024.0 / (r.ms * 1e-3) / 1e9;
     printf("  {\"case\": \"%s\", \"waves\": %d, \"ms\": %.3f, \"POPs\": %.3f, \"frac_of_datasheet\": %.3f, \"in_loop_shader_clock_GHz\": %.3f, "
            "\"matrix_pipe_busy\": %.3f, \"hbm_stream_GBps\": %.0f}%s\n",
            c.name, c.blocks * 4, r.ms, r.pops, r.pops / 5.0, r.shader_ghz, r.busy, stream_gbs, i + 1 < sizeof(cases) / sizeof(cases[0]) ? "," : "");
