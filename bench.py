@@ -745,6 +745,28 @@ def side_measurements(lab, ctx, q, dev):
     except Exception as e:
         out["ajtai_2p14x2p10_rhs32_matrix_cores"] = {"error": str(e)}
     A.close()
+    # ... and once more with A re-stored in FOUR primes below 2^23 (lab_ctx_enable_digit_basis_mfma with digit_bound = q: the basis
+    # holds 1024-term sums of products of two full-range residues, 2^80 < M/2): 4 limbs x 9 byte products = 36 per coefficient
+    # product instead of 3 x 16 = 48, the same 12 bytes of A per coefficient, and every limb runs on the assembly K loop
+    # (k_gemm_i8_w3) instead of round 1's 4-plane kernel.  Same residues mod q in and out (tests/test_gpu_ops.py).
+    try:
+        c4 = lab.Context(q, ctx.device, 65536)
+        c4.use_torch_stream()
+        primes4, _, _ = c4.enable_digit_basis(cols, q, mfma=True)
+        A4 = c4.vec(rows * cols, digit=True).fill_synthetic(4)
+        A84 = lab.Mat8(c4, A4, 1, rows, cols)
+        c4.synchronize()
+        A4.close()
+        Vs = c4.vec(32 * cols, digit=True).fill_synthetic(5)
+        o = c4.vec(32 * rows, digit=True)
+        t = _time(lambda: lab.matvec_sum_mfma(c4, A84, Vs, 32, out=o), 5)
+        out["ajtai_2p14x2p10_rhs32_matrix_cores_23bit_basis"] = {"ms": t * 1e3, "primes": primes4, "packed_matrix_GBps": A84.nbytes / t / 1e9,
+                                                                "packed_matrix_bytes": A84.nbytes,
+                                                                "int8_TOPs": 2.0 * 9 * len(primes4) * rows * cols * 32 * 64 / t / 1e12}
+        A84.close(); Vs.close(); o.close()
+        c4.close()
+    except Exception as e:
+        out["ajtai_2p14x2p10_rhs32_matrix_cores_23bit_basis"] = {"error": str(e)}
     # the same mat-vec shape as the prover's step 3 when q is its own NTT prime (single limb, 4 B per coefficient):
     # the data point for an NTT-friendly modulus (q = 1073738753, 30 bits); 24 GiB streamed per call
     try:

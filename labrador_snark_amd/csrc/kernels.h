@@ -85,7 +85,8 @@ hipError_t launch_reduce_u64_jobs(const JobPtrs& coeffs, HatView dst, size_t dst
 hipError_t launch_to_hat_fused(const JobPtrs& coeffs, HatView dst, size_t dst_js, size_t count, int nlimbs, const LimbTable* tabs,
                                size_t njobs, hipStream_t s, uint64_t in_bound = ~0ull /* coefficients are below this */,
                                unsigned long long* norm_sum = nullptr /* [njobs], += saturating sum of squares */, uint64_t norm_limit = 0,
-                               bool src_u16 = false /* coefficients are 16-bit words (digits from launch_decompose_jobs) */);
+                               bool src_u16 = false /* coefficients are 16-bit words (digits from launch_decompose_jobs) */,
+                               unsigned* above16 = nullptr /* with norm_sum: [njobs], |= 1 when a coefficient of the job is >= 2^16 */);
 hipError_t launch_crt_to_u64(ConstHatView src, uint64_t* coeffs, size_t count, const CrtTable* crt, int nlimbs, hipStream_t s);
 // decomposition digits written by the CRT pass itself: out16.p[job] as launch_decompose_jobs(.., out_u16 = true) lays them out
 struct CrtDigits { JobPtrs out16; uint32_t base; int exp; size_t group; uint64_t q; };
@@ -217,8 +218,11 @@ hipError_t launch_pi_fused_jobs(const JobPtrs& proj, const JobPtrs& W, const Job
                                 size_t n, size_t r, uint64_t q, size_t njobs, hipStream_t s);
 // the same pass over Pi at 2 bits per entry in MFMA-operand tiles (field = entry + 1; see k_pi_mfma); launch_pi_pack converts
 // `mats` int8 matrices of 256 x cols
+// above16 (with small_witness): [njobs] flags from launch_to_hat_fused — jobs whose witness coefficients all fit 16 bits take the
+// projection on v_dot2_u32_u16 (two entries per multiply-add)
 hipError_t launch_pi_fused2_jobs(const JobPtrs& proj, const JobPtrs& W, const JobPtrs& Pi2, const JobPtrs& S, const JobPtrs& omega,
-                                 size_t n, size_t r, uint64_t q, size_t njobs, bool small_witness, hipStream_t s);
+                                 size_t n, size_t r, uint64_t q, size_t njobs, bool small_witness, hipStream_t s,
+                                 const unsigned* above16 = nullptr);
 hipError_t launch_pi_pack(uint8_t* dst, const int8_t* src, size_t mats, size_t cols, hipStream_t s);
 hipError_t launch_lift_i64(uint64_t* out, const int64_t* in, size_t n, uint64_t q, hipStream_t s);
 hipError_t launch_norm_sq(uint64_t* lo, uint64_t* hi, const uint64_t* in, size_t count, hipStream_t s);

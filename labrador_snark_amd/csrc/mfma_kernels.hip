@@ -127,13 +127,11 @@ k_pack_matrix_i8x8(int8_t* __restrict__ dst, const uint32_t* __restrict__ src, u
 hipError_t launch_pack_matrix_i8(int8_t* dst, const void* src, bool src_u16, size_t nmat, size_t rows, size_t cols,
                                  size_t rt_count, size_t kt_count, int planes, hipStream_t s) {
   if (!src_u16) {
-    static bool attr_set = false;
+    // more than the 64 KB default of dynamic LDS: the attribute belongs to the (function, current device) pair, so it is set on
+    // every launch (a process may hold contexts on several devices; the call is a table lookup after the first time)
     const size_t lds = (size_t)8 * PM_RP * 4;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pack_matrix_i8x8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      attr_set = true;
-    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pack_matrix_i8x8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_pack_matrix_i8x8, dim3((unsigned)(rt_count * 4), (unsigned)kt_count), dim3(256), lds, s, dst,
                        static_cast<const uint32_t*>(src), (unsigned)nmat, (unsigned)rows, (unsigned)cols, (unsigned)rt_count,
                        (unsigned)kt_count, planes);

@@ -157,7 +157,7 @@ template <bool NORM, bool SRC16, bool WIDE = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_to_hat_fused(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, size_t dst_js, size_t count, int nlimbs,
                const LimbTable* __restrict__ tabs, uint64_t in_bound, unsigned long long* __restrict__ norm_sum,
-               uint64_t norm_limit, uint32_t norm_vmax) {
+               uint64_t norm_limit, uint32_t norm_vmax, unsigned* __restrict__ above16 = nullptr) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[TILE_WORDS];
   const uint64_t* __restrict__ coeffs = static_cast<const uint64_t*>(src.p[blockIdx.y]);
   dst += (size_t)blockIdx.y * dst_js;
@@ -231,6 +231,14 @@ k_to_hat_fused(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, siz
     }
 #pragma unroll
     for (int k = 0; k < D / 4; k++) over = over || chi[k] != 0;
+    if (above16) {   // does any coefficient of this job need more than 16 bits?  (the pass over Pi has a cheaper form when none does)
+      bool big = false;
+#pragma unroll
+      for (int k = 0; k < D; k++) big = big || clo[k] > 0xFFFFu;
+#pragma unroll
+      for (int k = 0; k < D / 4; k++) big = big || chi[k] != 0;
+      if (__builtin_amdgcn_ballot_w64(big) != 0 && lane == 0) atomicOr(&above16[blockIdx.y], 1u);
+    }
     if (over || ss > norm_limit) ss = norm_limit + 1;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off);   // <= 64 * (2^48 + 1)
@@ -274,7 +282,7 @@ k_to_hat_fused(const JobPtrs src, uint32_t* __restrict__ dst, size_t dst_ps, siz
 
 hipError_t launch_to_hat_fused(const JobPtrs& coeffs, HatView dst, size_t dst_js, size_t count, int nlimbs, const LimbTable* tabs,
                                size_t njobs, hipStream_t s, uint64_t in_bound, unsigned long long* norm_sum, uint64_t norm_limit,
-                               bool src_u16) {
+                               bool src_u16, unsigned* above16) {
   if (count == 0 || njobs == 0) return hipSuccess;
   const dim3 g((unsigned)((count + 63) / 64), (unsigned)njobs);
   if (norm_sum) {
@@ -286,10 +294,10 @@ hipError_t launch_to_hat_fused(const JobPtrs& coeffs, HatView dst, size_t dst_js
     if (src_u16) return hipErrorInvalidValue;
     if (limb_tables_wide(tabs))
       hipLaunchKernelGGL((k_to_hat_fused<true, false, true>), g, dim3(64), 0, s, coeffs, dst.base, dst.plane_stride, dst_js, count, nlimbs, tabs,
-                         in_bound, norm_sum, norm_limit, vmax);
+                         in_bound, norm_sum, norm_limit, vmax, above16);
     else
     hipLaunchKernelGGL((k_to_hat_fused<true, false>), g, dim3(64), 0, s, coeffs, dst.base, dst.plane_stride, dst_js, count, nlimbs, tabs,
-                       in_bound, norm_sum, norm_limit, vmax);
+                       in_bound, norm_sum, norm_limit, vmax, above16);
   } else if (limb_tables_wide(tabs)) {
     if (src_u16)
       hipLaunchKernelGGL((k_to_hat_fused<false, true, true>), g, dim3(64), 0, s, coeffs, dst.base, dst.plane_stride, dst_js, count, nlimbs, tabs,

@@ -614,12 +614,21 @@ k_pi_fused(const JobPtrs projp, const JobPtrs Wp, const JobPtrs Pip, const JobPt
 // Word address: ((i*4 + s) * (cols/16) + ct) * 64 + lane.  Block = 4 waves x CT column tiles of witness column i.
 constexpr int PI_LIMBS = 6;                        // 7-bit limbs of omega (< 2^42)
 
-template <bool SMALL, int CT>
+// TINY (a SMALL variant): every witness coefficient of the job fits 16 bits (flag from the witness transform's pass).  The
+// projection then takes TWO entries per multiply-add: byte kk of the dwords of two neighbouring column tiles side by side
+// (one v_perm_b32 per pair and kk), field j of both masked in place (one v_and_b32) and v_dot2_u32_u16 against the two
+// coefficients packed as halves — 4 + 16 + 16 = 36 instructions for 32 entries instead of 64.  The row sums carry the factor
+// 4^j of the in-place fields (taken off after the lane reduction).  `flags` / `want`: the launcher starts the TINY and the plain
+// SMALL kernel back to back; a block leaves at once when its job's flag says the other one serves it.
+template <bool SMALL, int CT, bool TINY = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMALL ? 3 : 2, SMALL ? 3 : 2)))
 k_pi_mfma(const JobPtrs projp, const JobPtrs Wp, const JobPtrs Pip, const JobPtrs Sp, const JobPtrs omegap, unsigned n, unsigned r,
-          unsigned ib, uint64_t q) {
+          unsigned ib, uint64_t q, const unsigned* __restrict__ flags = nullptr, unsigned want = 0) {
+  static_assert(!TINY || (SMALL && CT % 2 == 0), "TINY is a SMALL variant over pairs of column tiles");
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
   typedef int i32x4_t __attribute__((ext_vector_type(4)));
+  typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+  if (flags && (flags[blockIdx.z] != 0) != (want != 0)) return;
   unsigned long long* __restrict__ proj = static_cast<unsigned long long*>(projp.p[blockIdx.z]);
   uint64_t* __restrict__ W = static_cast<uint64_t*>(Wp.p[blockIdx.z]);
   const uint32_t* __restrict__ Pi = static_cast<const uint32_t*>(Pip.p[blockIdx.z]);
@@ -668,6 +677,11 @@ k_pi_mfma(const JobPtrs projp, const JobPtrs Wp, const JobPtrs Pip, const JobPtr
       else { s_lo[c] = (unsigned)(v & 0xFFFFF); s_hi[SMALL ? 0 : c] = (unsigned)(v >> 20); }
       if (kq == 0) my_s += (long long)v;            // each column once per wave
     }
+    unsigned s_pair[TINY ? CT / 2 : 1];              // TINY: the coefficients of column tiles 2c, 2c + 1 as 16-bit halves
+    if constexpr (TINY) {
+#pragma unroll
+      for (int c = 0; c < CT / 2; c++) s_pair[c] = (s_lo[2 * c] & 0xFFFFu) | (s_lo[2 * c + 1] << 16);
+    }
     i32x4_t acc[CT];
 #pragma unroll
     for (int c = 0; c < CT; c++) acc[c] = i32x4_t{0, 0, 0, 0};
@@ -700,12 +714,29 @@ k_pi_mfma(const JobPtrs projp, const JobPtrs Wp, const JobPtrs Pip, const JobPtr
 #pragma unroll
         for (int j = 0; j < 4; j++) bf[j] = (int)__builtin_amdgcn_perm(0u, 0x020100FFu, (w >> (2 * j)) & 0x03030303u);
         acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, acc[c], 0, 0, 0);
+        if constexpr (TINY) {
+          if (c & 1) {                                // tiles c - 1, c together
+            const uint32_t w0 = cur[c - 1];
+            const u16x2_t sp = __builtin_bit_cast(u16x2_t, s_pair[c / 2]);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+              // byte kk of w0 in byte 0, byte kk of w in byte 2 (selector 0x0C: a zero byte)
+              const uint32_t both = __builtin_amdgcn_perm(w, w0, 0x0C000C00u | ((4u + kk) << 16) | (unsigned)kk);
+#pragma unroll
+              for (int j = 0; j < 4; j++) {           // row 4j + kk: field j of both bytes, in place (factor 4^j)
+                const u16x2_t g2 = __builtin_bit_cast(u16x2_t, both & (0x00030003u << (2 * j)));
+                p_lo[4 * j + kk] = __builtin_amdgcn_udot2(g2, sp, p_lo[4 * j + kk], false);
+              }
+            }
+          }
+        } else {
         const unsigned sl = s_lo[c], sh = SMALL ? 0u : s_hi[SMALL ? 0 : c];
 #pragma unroll
         for (int k = 0; k < 16; k++) {             // row 4j + kk of this lane's block sits at bit 8kk + 2j
           const unsigned g = (w >> (8 * (k & 3) + 2 * (k >> 2))) & 3u;
           p_lo[k] = __umul24(g, sl) + p_lo[k];
           if (!SMALL) p_hi[SMALL ? 0 : k] = __umul24(g, sh) + p_hi[SMALL ? 0 : k];
+        }
         }
       }
 #pragma unroll
@@ -716,7 +747,7 @@ k_pi_mfma(const JobPtrs projp, const JobPtrs Wp, const JobPtrs Pip, const JobPtr
           unsigned x = p_lo[k];
           x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
           x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
-          p_lo[k] = x;
+          p_lo[k] = TINY ? x >> (2 * (k >> 2)) : x;  // TINY: row 4j + kk carries the factor 4^j (sums < 2 * 2^6 * 2^16 * CT * 4 < 2^31)
         }
         if ((lane & 3) == 3) {
           u32x4_t* dst = parked + (((size_t)wave * 4 + s) * 16 + (lane >> 2)) * 4;
@@ -820,14 +851,18 @@ hipError_t launch_pi_pack(uint8_t* dst, const int8_t* src, size_t mats, size_t c
 
 // small_witness: witness coefficients are known to be below 2^24
 hipError_t launch_pi_fused2_jobs(const JobPtrs& proj /*zeroed*/, const JobPtrs& W, const JobPtrs& Pi2, const JobPtrs& S,
-                                 const JobPtrs& omega, size_t n, size_t r, uint64_t q, size_t njobs, bool small_witness, hipStream_t s) {
+                                 const JobPtrs& omega, size_t n, size_t r, uint64_t q, size_t njobs, bool small_witness, hipStream_t s,
+                                 const unsigned* above16) {
   if (n == 0 || r == 0 || njobs == 0) return hipSuccess;
   constexpr int CT = 16;
   const size_t cols = n * D, ctiles = cols / 16;
   const size_t xblocks = (ctiles + 4 * CT - 1) / (4 * CT);
   const unsigned ib = 1;     // witness columns per block (more than one would need the row sums accumulated: slower, see the kernel)
   const dim3 g((unsigned)xblocks, (unsigned)((r + ib - 1) / ib), (unsigned)njobs);
-  if (small_witness)
+  if (small_witness && above16) {   // per job: the 16-bit form or the 24-bit form (the block of the other kernel returns at once)
+    hipLaunchKernelGGL((k_pi_mfma<true, CT, true>), g, dim3(256), 0, s, proj, W, Pi2, S, omega, (unsigned)n, (unsigned)r, ib, q, above16, 0u);
+    hipLaunchKernelGGL((k_pi_mfma<true, CT>), g, dim3(256), 0, s, proj, W, Pi2, S, omega, (unsigned)n, (unsigned)r, ib, q, above16, 1u);
+  } else if (small_witness)
     hipLaunchKernelGGL((k_pi_mfma<true, CT>), g, dim3(256), 0, s, proj, W, Pi2, S, omega, (unsigned)n, (unsigned)r, ib, q);
   else
     hipLaunchKernelGGL((k_pi_mfma<false, CT>), g, dim3(256), 0, s, proj, W, Pi2, S, omega, (unsigned)n, (unsigned)r, ib, q);

@@ -269,6 +269,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   std::vector<Job> jobs(np);
   // [np][256] integer projections | [np][256] omega | [np][64] b'': contiguous, so the host-side checks need ONE copy
   uint64_t* host_stage = cv.take<uint64_t>(np * (256 + 256 + D + 1));   // ... | [np] squared witness norms (digit-basis step 1)
+  unsigned* above16 = cv.take<unsigned>(np);   // [np] flags: a witness coefficient of the proof needs more than 16 bits (digit-basis step 1)
   int64_t* proj_all = reinterpret_cast<int64_t*>(host_stage);
   Staging st(c, &cv);  // inputs only (no pending outputs are registered on it)
   for (size_t j = 0; j < np; j++) {
@@ -356,9 +357,10 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   bool t_in_dense = false, g_in_digit = false, t_digits_done = false;
   if (a8d) {  // matrix cores, in the basis of B, C, D (see a8d above): S once more into that basis, its norm summed on the way
     LAB_HIP(c, hipMemsetAsync(norm_sums, 0, np * 8, s));
+    LAB_HIP(c, hipMemsetAsync(above16, 0, np * 4, s));
     // (coefficients above beta_bound are caught by the norm sum and the batch is redone: the transform may assume the bound)
     LAB_HIP(c, launch_to_hat_fused(JP(&Job::dS), HD(0, hSd), jsd, nr, Ld, tabsd, np, s, (uint64_t)in->beta_bound + 1,
-                                   reinterpret_cast<unsigned long long*>(norm_sums), norm_limit));
+                                   reinterpret_cast<unsigned long long*>(norm_sums), norm_limit, false, above16));
     for (size_t i0 = 0; i0 < r; i0 += 32) {
       const int valid = (int)(r - i0 < 32 ? r - i0 : 32);
       MfmaCoefOut co{dense_tmp + i0 * kappa * D, rk * D, tmp_js, kappa, false};   // t is only wanted as coefficients
@@ -505,7 +507,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   LAB_HIP(c, hipMemsetAsync(proj_all, 0, np * 256 * 8, s));
   if (in->Pi2)   // 2 bits per entry; with the digit-basis step 1 the witness is inside its norm bound (coefficients < 2^24) or the batch is redone
     LAB_HIP(c, launch_pi_fused2_jobs(JP(&Job::dproj_int), JP(&Job::cW), JP(&Job::dPi2), JP(&Job::dS), JP(&Job::domega), n, r, q, np,
-                                     a8d != nullptr, s));
+                                     a8d != nullptr, s, a8d ? above16 : nullptr));
   else
     LAB_HIP(c, launch_pi_fused_jobs(JP(&Job::dproj_int), JP(&Job::cW), JP(&Job::dPi), JP(&Job::dS), JP(&Job::domega), n, r, q, np, s));
   LAB_HIP(c, launch_lift_i64_jobs(JP(&Job::dproj), JP(&Job::dproj_int), 256, q, np, s));

@@ -591,3 +591,32 @@ def test_matvec_sum_mfma_long_sums_main_basis(K):
     assert np.array_equal(got[b, r_], want)
     M8.close()
     ctx.close()
+
+
+def test_matvec_sum_mfma_full_range_operands_in_the_23_bit_basis():
+    # lab_ctx_enable_digit_basis_mfma with digit_bound = q: the "digit" operand may be any residue — FOUR primes below 2^23 then hold
+    # 1024-term sums of products of two full-range residues.  bench.py's config-4 leg with 32 right-hand sides runs there
+    # (k_gemm_i8_w3<3>: 32 sets x 3 planes); results equal the multiply-add kernel in the main basis and the oracle.
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    q = Q_REF33
+    ctx = lab.Context(q, 0)
+    ns, nmat, rows, cols = 32, 1, 260, 1024
+    primes, small, _ = ctx.enable_digit_basis(cols, q, mfma=True)
+    assert len(primes) == 4 and not small and all(pr < 8355712 for pr in primes)
+    rng = np.random.default_rng(77)
+    M = rp(rng, q, nmat, rows, cols)
+    V = rp(rng, q, ns, nmat, cols)
+    M[0, :2] = q - 1
+    V[ns - 1] = q - 1
+    hM = ctx.vec(nmat * rows * cols, digit=True).load(M)
+    hV = ctx.vec(ns * nmat * cols, digit=True).load(V)
+    M8 = lab.Mat8(ctx, hM, nmat, rows, cols)
+    got = lab.matvec_sum_mfma(ctx, M8, hV, ns).store().reshape(ns, rows, D)
+    mM, mV = ctx.vec_from(M), ctx.vec_from(V)               # main basis, multiply-add kernel
+    for b in (0, 5, ns - 1):
+        assert np.array_equal(got[b], lab.matvec_sum(ctx, mM, mV, nmat, rows, cols, v_off=b * nmat * cols).store()), (b,)
+    for b, r_ in ((ns - 1, 0), (ns - 1, 1), (3, rows - 1)):
+        assert np.array_equal(got[b, r_], co.inner_product(q, M[0, r_], V[b, 0])), (b, r_)
+    M8.close()
+    ctx.close()

@@ -518,10 +518,15 @@ def test_packed_pi_on_the_norm_bounded_fast_path_and_its_fallback():
     crs = lab.ResidentCRS(ctx, k, mfma_basis=True).fill_synthetic(1000)
     crs.pack_mfma()
     ws, sts, tapes, tapes2 = [], [], [], []
-    for j in range(3):
+    # per proof the pass picks the 16-bit form (two entries per v_dot2_u32_u16) or the 24-bit form from a flag the witness transform
+    # sets: proof 0 has a coefficient that needs all 24 bits, proof 1 one at 2^16 - 1 (the largest the 16-bit form takes, in the
+    # last column tile of a pair), proof 2 one at 2^16 (the smallest that does not), proof 3 is small throughout
+    special = {0: ((0, 0, 0), min(k.BETA_BOUND // 2, (1 << 24) - 1)), 1: ((n - 1, r - 1, 63), 65535), 2: ((1, 2, 17), 65536)}
+    for j in range(4):
         case, (S, phi, a, tape) = cases.oracle_case(p, seed=900 + j)
         S = S.copy()
-        S[0, 0, 0] = min(k.BETA_BOUND // 2, (1 << 24) - 1)        # a coefficient that needs all 24 bits of the fast path
+        if j in special:
+            S[special[j][0]] = special[j][1]
         st = lab.State(phi, a, int(lab.gen_f_b(ctx, S, phi, a, n, r)[0]))
         ws.append(S); sts.append(st); tapes.append(tape)
         t2 = {kk: v for kk, v in tape.items() if kk != "Pi"}
@@ -537,9 +542,14 @@ def test_packed_pi_on_the_norm_bounded_fast_path_and_its_fallback():
     got2, c_got2 = lab.prove_core_batch(ctx, k, big, sts, crs, tapes2, raise_on_reject=False)
     assert ctx.prove_flags() == 2 and c_ref2 == c_got2
     for A, B in ((ref, got), (ref2, got2)):
-        for j in range(3):
+        for j in range(4):
             for f in ("projection_int", "projection", "b_prime_prime", "h_mat", "u_2", "u_1", "z", "t_i_all", "g_mat"):
                 assert np.array_equal(getattr(A[j], f), getattr(B[j], f)), (j, f)
+    # the integer projection itself against the oracle's jl_project (src/proofgen.rs:429-456), every proof
+    from oracle import coracle as co
+    for j in range(4):
+        s_cols = np.ascontiguousarray(ws[j].transpose(1, 0, 2)).reshape(r, n * 64)        # column i of the witness, flattened
+        assert np.array_equal(np.asarray(got[j].projection_int, dtype=np.int64), co.jl_project(tapes[j]["Pi"], s_cols)), j
     crs.close()
     ctx.close()
 

@@ -9,7 +9,7 @@ import json
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 P = "gpurun_out/prof/"
 # the dominant kernel is the one bench.py's profiling hook reports ("lab::<name> — ...")
 DOM = sys.argv[2] if len(sys.argv) > 2 else json.load(open(P + "bench_n1.json"))["roofline"]["kernel"].split(" — ")[0].replace("lab::", "")
