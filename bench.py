@@ -269,7 +269,8 @@ def build_crs(lab, ctx, k, crs_seed, use_mfma=True, basis23=True, compact=True, 
         seed = bytes((crs_seed * 7 + 13 * i) % 256 for i in range(32))
         crs = lab.CRS(ctx, k, seed).materialize(mfma_basis=True, stream_B=True)
         # (no main-basis A8: step 1 runs from A8d; a witness above its norm bound would fall back to the multiply-add kernel)
-        crs.pack_mfma(main_basis_A=False)
+        # (... and no C / D residues: the prover reads their packed forms only)
+        crs.pack_mfma(main_basis_A=False, drop_CD=True)
         torch.cuda.synchronize()
         return crs
     # B, C, D are only ever multiplied by decomposition digits: keep them in the digit basis
@@ -353,22 +354,45 @@ def host_chacha_rate(q, seconds=4.0):
     return cores * reps * n0 / dt, cores, dt
 
 
-def config3_streamed(lab, dev, q, n, r, kappa, inputs, b1_s_per_proof_k1024=None, with_cpu=True):
+def config3_streamed(lab, dev, q, n, r, kappa, inputs, b1_s_per_proof_k1024=None, with_cpu=True, proofs=(160, 128, 96, 64)):
     """SURVEY section 8(d) config 3 at the contract's commitment rank: kappa = kappa1 = kappa2 = 2^14 (the floor BASELINE.md names;
     the reference hard-wires n*d = 2^16, src/constants.rs:237-239).  One B_ik is 2^28 ring elements, the 96 of them 6 TiB as byte
     planes: B is STREAMED — regenerated from the ChaCha20 seed inside the step (CRS::fetch_B_ik_row, src/structs.rs:74-88,
     147-171) — so the expansion is inside the timed region.  ONE step, no warm-up (a step is ~80 s), all proofs of the step share
     one pass over the regenerated rows."""
     import torch
-    dSs, sts, dtapes = inputs
-    nbatch = len(dSs)
     k = lab.RuntimeConstants(q, n, r, kappa, kappa, kappa)
+    rec = None
+    # as many proofs per pass over the regenerated rows as the 288 GB hold (a call of more than 64 proofs shares ONE pass among its
+    # sub-batches of 64; 1.15 GB of workspace per proof at kappa = 2^14): the first size that fits
+    failed = []
+    for nbatch in proofs:
+        rec = _config3_streamed_once(lab, dev, q, n, r, kappa, k, inputs, nbatch)
+        if "error" not in rec:
+            break
+        failed.append({"proofs_per_step": nbatch, "error": rec["error"]})
+        torch.cuda.empty_cache()
+    if failed:
+        rec["sizes_that_did_not_fit"] = failed
+    if with_cpu:
+        rec["cpu_baseline"] = _config3_cpu_baseline(q, r, k, kappa, b1_s_per_proof_k1024)
+    return rec
+
+
+def _config3_streamed_once(lab, dev, q, n, r, kappa, k, inputs, nbatch):
+    import torch
+    dSs, sts, dtapes = (list(x) for x in inputs)
     ctx = lab.Context(q, dev.index or 0, max(65536, n * r + r * r))
     ctx.use_torch_stream()
     rec = {"workload": "full Prover::proof_gen n=%d r=%d d=64, kappa=kappa1=kappa2=%d, q=%d; B regenerated from the ChaCha20 seed inside "
-                       "the timed region (A, C, D resident); %d proofs per step share one pass over the regenerated rows; 1 step, no warm-up"
-                       % (n, r, kappa, q, nbatch), "kappa": kappa, "proofs_per_step": nbatch}
+                       "the timed region (A resident, C and D as byte planes); %d proofs per step share one pass over the regenerated rows; "
+                       "1 step, no warm-up" % (n, r, kappa, q, nbatch), "kappa": kappa, "proofs_per_step": nbatch}
+    crs = plan = T = None
     try:
+        if nbatch > len(dSs):      # more instances than the headline had: seeds continue where it stopped
+            more = build_inputs(lab, ctx, k, q, dev, nbatch - len(dSs), 50 + len(dSs))
+            dSs += more[0]; sts += more[1]; dtapes += more[2]
+        dSs, sts, dtapes = dSs[:nbatch], sts[:nbatch], dtapes[:nbatch]
         t0 = time.perf_counter()
         crs = build_crs(lab, ctx, k, 1000, stream_b=True)
         rec["crs_setup_s"] = time.perf_counter() - t0
@@ -387,13 +411,19 @@ def config3_streamed(lab, dev, q, n, r, kappa, inputs, b1_s_per_proof_k1024=None
                     "prove_flags": ctx.prove_flags(), "checksum_u1_u2": int((checksum_u64(T.u_1) + checksum_u64(T.u_2)).item()),
                     "B_coefficients_regenerated_per_step": coefs, "coefficients_per_s_end_to_end": coefs / elapsed,
                     "roofline": streamed_roofline(phases, elapsed, 1)})
-        del plan, T
-        crs.close()
     except Exception as e:
         rec["error"] = repr(e)
+    del plan, T
+    if crs is not None:
+        crs.close()
     ctx.close()
+    del dSs, sts, dtapes
     torch.cuda.empty_cache()
-    if with_cpu:
+    return rec
+
+
+def _config3_cpu_baseline(q, r, k, kappa, b1_s_per_proof_k1024):
+    if True:
         try:
             rate, cores, dt = host_chacha_rate(q)
             coefs = r * k.T_1 * kappa * kappa * D
@@ -411,10 +441,9 @@ def config3_streamed(lab, dev, q, n, r, kappa, inputs, b1_s_per_proof_k1024=None
                 cb["sample"] += "; arithmetic: B1's measured %.2f s per proof at kappa = 1024 x %d" % (b1_s_per_proof_k1024, int((kappa / 1024) ** 2))
             cb["value"] = 1.0 / (regen_s + (arith_s or 0.0))
             cb["s_per_proof"] = regen_s + (arith_s or 0.0)
-            rec["cpu_baseline"] = cb
+            return cb
         except Exception as e:
-            rec["cpu_baseline"] = {"value": None, "unit": "constraints/s", "cores": cpu_share(), "kind": "port", "error": repr(e)}
-    return rec
+            return {"value": None, "unit": "constraints/s", "cores": cpu_share(), "kind": "port", "error": repr(e)}
 
 
 def launch_ranks(n_gpus, argv):

@@ -130,7 +130,8 @@ const char *lab_ctx_profile_kernel(const lab_ctx *ctx);
  * one matrix with many jobs (the Ajtai product of a batch) instead.  Stays in force until set again. */
 int lab_ctx_gemm_diag(lab_ctx *ctx, int mode, uint64_t *ticks, size_t words);
 /* how the most recent lab_prove_core[_batch] call ran: 1 = step 1 in the digit basis (lab_prove_input.A8d), 2 = that was tried,
- * a witness exceeded beta_bound and the batch was redone in the main basis; 0 = main basis from the start */
+ * a witness exceeded beta_bound and the batch was redone in the main basis; 0 = main basis from the start.  A call with more than
+ * 64 proofs runs in sub-batches of 64 and reports the OR of theirs (3: one was redone, another was not). */
 int lab_ctx_prove_flags(const lab_ctx *ctx);
 
 /* Digit basis (no reference counterpart; a storage/bandwidth optimisation).  The outer commitments multiply CRS
@@ -326,7 +327,8 @@ typedef struct {
                               * per pass and B itself may be NULL (lab_verify_core still needs B) */
   const struct lab_mat8 *A8; /* optional: lab_mat8_pack(A, a_off, 1, kappa, n): step 1 (t_i = A s_i) as int8 GEMMs */
   const struct lab_mat8 *C8; /* optional: lab_mat8_pack(C, c_off, pairs*t2, kappa2, 1): step 4 (sum g^(k) C) as int8 GEMMs */
-  const struct lab_mat8 *D8; /* optional: lab_mat8_pack(Dm, d_off, pairs*t1, kappa2, 1): step 9 (sum h^(k) D) likewise */
+  const struct lab_mat8 *D8; /* optional: lab_mat8_pack(Dm, d_off, pairs*t1, kappa2, 1): step 9 (sum h^(k) D) likewise; with
+                              * C8 and D8 set the prover does not read C and Dm, which may then be NULL (lab_verify_core needs them) */
   const struct lab_mat8 *A8d; /* optional: A packed from a copy in the digit basis of B, C, D (same kappa x n elements).  Step 1 of
                                * a batch then runs in that basis whenever sqrt(64 n) (q-1) beta_bound is inside its CRT range
                                * (|A s| <= |A|_2 |s|_2): with the matrix-core basis 9 instead of 16 byte products per modular
@@ -370,8 +372,10 @@ int lab_prove_core(lab_ctx *ctx, const lab_prove_input *in, lab_transcript *out)
  * constants; each with its own witness, state and challenge tape).  The per-proof kernels take all proofs of the call as
  * jobs of one launch; the outer commitment sum_{i,k} B_ik t_i^(k) — whose cost is streaming (B8 / B) or regenerating
  * (crs_seed) the B matrices — is issued once per group of proofs: up to 64 per pass over B on the matrix cores (exact int8
- * GEMMs), up to 8 with the multi-set multiply-add kernel when B is only present as residues.  Every transcript is
- * bit-identical to what lab_prove_core returns for that proof alone.
+ * GEMMs), up to 8 with the multi-set multiply-add kernel when B is only present as residues.  More than 64 proofs run as
+ * sub-batches of 64; with B streamed from crs_seed (up to 256 proofs) the sub-batches SHARE one pass over the regenerated rows:
+ * each runs steps 1-2, then one streamed step 3 serves all of them, then each finishes — the expansion, ~80 % of such a step,
+ * is paid once per call.  Every transcript is bit-identical to what lab_prove_core returns for that proof alone.
  * status[j] (if status != NULL) receives LAB_OK / LAB_ERR_JL_REJECTED / LAB_ERR_BPP_CHECK for proof j and the call
  * returns LAB_OK; with status == NULL the first failing proof's code is returned. */
 int lab_prove_core_batch(lab_ctx *ctx, size_t nproofs, const lab_prove_input *const *in, lab_transcript *const *out,

@@ -26,6 +26,9 @@ int fail(const lab_ctx* ctx, int code, const char* fmt, ...) {
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
   if (ctx) ctx->err = buf;
+  // a failed HIP call (an allocation that did not fit) also parks its code in the thread's "last error"; the launchers return
+  // hipGetLastError() after every kernel launch and would report it again for an innocent launch of a later call
+  if (code == LAB_ERR_HIP) (void)hipGetLastError();
   return code;
 }
 
@@ -35,7 +38,7 @@ int ensure_scratch(lab_ctx* ctx, size_t bytes) {
   if (ctx->scratch) LAB_HIP(ctx, hipFree(ctx->scratch));
   ctx->scratch = nullptr;
   ctx->scratch_bytes = 0;
-  size_t want = bytes + bytes / 8 + (1u << 20);
+  size_t want = bytes + std::min<size_t>(bytes / 8, (size_t)1 << 30) + (1u << 20);   // some slack for the next, slightly larger call
   LAB_HIP(ctx, hipMalloc(&ctx->scratch, want));
   ctx->scratch_bytes = want;
   return LAB_OK;
@@ -194,6 +197,7 @@ extern "C" int lab_ctx_create_ex(uint64_t q, int device, uint64_t max_len, int f
   if (!out) return LAB_ERR_ARG;
   *out = nullptr;
   if (q < 3 || (q & 1) == 0 || q >= (1ull << 40)) return LAB_ERR_ARG;
+  (void)hipGetLastError();   // whatever an earlier user of the thread left behind is not this context's
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     (void)hipGetLastError();

@@ -228,10 +228,21 @@ size_t crs_stream_scratch_bytes(lab_ctx* c, int basis, size_t nmat, size_t rows,
 // matrices per K chunk of the streamed sum and whether the chunks are added mod q in the coefficient domain (the whole sum exceeds
 // the exactness bound of the basis, one chunk does not); false: not even one matrix row fits
 bool crs_stream_plan(const lab_ctx* c, int basis, size_t nmat, size_t cols, uint64_t extra_terms, size_t* mc, bool* reduce);
-int crs_stream_create(lab_ctx* c, int basis, size_t nmat, size_t rows, size_t cols, int ns, CrsStream** out, uint64_t extra_terms = 0);
+// ngroups: groups of vector sets one pass over the regenerated rows will serve (each with its own results and tile scratch)
+constexpr int CRS_MAX_GROUPS = 4;
+int crs_stream_create(lab_ctx* c, int basis, size_t nmat, size_t rows, size_t cols, int ns, CrsStream** out, uint64_t extra_terms = 0,
+                      size_t ngroups = 1);
 void crs_stream_destroy(CrsStream* st);
-int crs_stream_run(CrsStream* st, const uint8_t seed[32], const uint64_t* mat_offsets, size_t nmat, HatView out, size_t out_set_stride,
-                   const ConstHatView* V, size_t v_set_stride, const JobPtrs* dig, int ns, int ns_valid, void* scratch);
+// one group of up to 64 vector sets: results (set s at out.base + s*out_set_stride), the sets as 16-bit digits (dig->p[s]:
+// [nmat*cols][64] words) or as transform-domain vectors (V, set stride v_set_stride), padded / valid set counts, and the group's
+// own crs_stream_scratch_bytes() of tile scratch
+struct CrsGroup {
+  HatView out; size_t out_set_stride;
+  const JobPtrs* dig; const ConstHatView* V; size_t v_set_stride;
+  int ns, ns_valid;
+  void* scratch;
+};
+int crs_stream_run(CrsStream* st, const uint8_t seed[32], const uint64_t* mat_offsets, size_t nmat, const CrsGroup* groups, size_t ngroups);
 uint32_t basis_min_prime(const lab_ctx* c, int basis);
 bool mat8_matches(const lab_mat8* m, int basis, size_t nmat, size_t rows, size_t cols);
 int mat8_basis(const lab_mat8* m);

@@ -37,9 +37,12 @@ struct CrsStream {
   lab_mat8* m8 = nullptr;
   uint32_t* slab = nullptr;       // [L][MC*R*cols][64]
   uint64_t* coefs = nullptr;      // [chunk][64]
-  uint32_t* tmp = nullptr;        // [L][ns*R][64] (twice that with `reduce`: the inverse transform's scratch behind it)
-  uint64_t* acc = nullptr;        // reduce: [ns][rows][64] coefficients mod q — the running sum over the K chunks
-  uint64_t* cur = nullptr;        // reduce: [ns*R][64] the current (chunk, slab)'s sums mod q
+  // One pass over the regenerated rows serves up to CRS_MAX_GROUPS groups of vector sets (64 proofs each: the prover's batches of
+  // more than 64 proofs share the expansion); per group:
+  uint32_t* tmp[CRS_MAX_GROUPS] = {};   // [L][ns*R][64] (twice that with `reduce`: the inverse transform's scratch behind it)
+  uint64_t* acc[CRS_MAX_GROUPS] = {};   // reduce: [ns][rows][64] coefficients mod q — the running sum over the K chunks
+  uint64_t* cur = nullptr;              // reduce: [ns*R][64] the current (chunk, slab)'s sums mod q (shared: used and consumed in turn)
+  size_t ngroups = 1;
   size_t chunk = 0;
   bool fused = false;             // slab tiles straight from the expanded coefficients (mat8_fill_rows)
   bool reduce = false;            // chunk results are added mod q in the coefficient domain (see the header)
@@ -47,8 +50,10 @@ struct CrsStream {
     if (m8) lab_mat8_destroy(m8);
     if (slab) (void)hipFree(slab);
     if (coefs) (void)hipFree(coefs);
-    if (tmp) (void)hipFree(tmp);
-    if (acc) (void)hipFree(acc);
+    for (size_t g = 0; g < CRS_MAX_GROUPS; g++) {
+      if (tmp[g]) (void)hipFree(tmp[g]);
+      if (acc[g]) (void)hipFree(acc[g]);
+    }
     if (cur) (void)hipFree(cur);
   }
 };
@@ -56,8 +61,8 @@ struct CrsStream {
 // rows per slab / matrices per chunk the engine will use
 // rows per slab: the GEMM over a slab is one block per NTT slot and four 32-row tiles — 128 rows are 64 blocks, a quarter of the
 // chip's 256 CUs, and ran at 2.3 TB/s; 512 rows fill it.  Taken when the slab (its byte planes in operand order) stays below
-// 40 GB and free memory allows it, else 256 / 128.
-size_t crs_stream_rows(lab_ctx* c, int basis, size_t rows, size_t mc, size_t cols) {
+// 40 GB and free memory holds it next to the engine's other buffers (`other_bytes`) and 1 GB to spare, else 256 / 128.
+size_t crs_stream_rows(lab_ctx* c, int basis, size_t rows, size_t mc, size_t cols, size_t other_bytes) {
   if (rows <= 128) return rows;
   const int L = basis_nlimbs(c, basis);
   const size_t kt = ((mc * cols + 31) / 32 + 11) / 12 * 12;
@@ -66,7 +71,7 @@ size_t crs_stream_rows(lab_ctx* c, int basis, size_t rows, size_t mc, size_t col
   for (size_t R = 512; R > 128; R /= 2) {
     if (rows < R) continue;
     const size_t slab = (size_t)L * D * 4 /* planes, at most */ * (R / 32) * kt * 1024;
-    if (slab <= ((size_t)40 << 30) && slab + ((size_t)8 << 30) <= free_b) return R;
+    if (slab <= ((size_t)40 << 30) && slab + other_bytes + ((size_t)1 << 30) <= free_b) return R;
   }
   return 128;
 }
@@ -96,12 +101,19 @@ size_t crs_stream_scratch_bytes(lab_ctx* c, int basis, size_t nmat, size_t rows,
   return (size_t)L * Carver::padded((size_t)D * kt * 8 * 1024) + 8192;   // 8 column tiles at most per limb
 }
 
-int crs_stream_create(lab_ctx* c, int basis, size_t nmat, size_t rows, size_t cols, int ns, CrsStream** out, uint64_t extra_terms) {
+int crs_stream_create(lab_ctx* c, int basis, size_t nmat, size_t rows, size_t cols, int ns, CrsStream** out, uint64_t extra_terms,
+                      size_t ngroups) {
+  if (ngroups == 0 || ngroups > CRS_MAX_GROUPS) return fail(c, LAB_ERR_ARG, "streamed commitment: %zu groups of vector sets (1..%d)", ngroups, CRS_MAX_GROUPS);
   CrsStream* st = new CrsStream();
-  st->c = c; st->basis = basis; st->rows = rows; st->cols = cols; st->ns = (size_t)ns;
+  st->c = c; st->basis = basis; st->rows = rows; st->cols = cols; st->ns = (size_t)ns; st->ngroups = ngroups;
   if (!crs_stream_plan(c, basis, nmat, cols, extra_terms, &st->MC, &st->reduce)) st->MC = 0;
   if (st->MC == 0) { delete st; return fail(c, LAB_ERR_RANGE, "streamed commitment: %zu columns per matrix exceed the int32 bound of the int8 GEMM or the exactness bound of this basis", cols); }
-  st->R = crs_stream_rows(c, basis, rows, st->MC, cols);
+  {   // what the engine allocates besides the slab: the expansion chunk, per group the chunk results (twice with `reduce`) and sums
+    const int Lb = basis_nlimbs(c, basis);
+    const size_t other = CRS_CHUNK_POLYS * D * 8 + ngroups * ((size_t)2 * Lb * ns * 512 * D * 4 + (st->reduce ? (size_t)ns * rows * D * 8 : 0)) +
+                         (size_t)ns * 512 * D * 8;
+    st->R = crs_stream_rows(c, basis, rows, st->MC, cols, other);
+  }
   const int L = basis_nlimbs(c, basis);
   const size_t slab_elems = st->MC * st->R * cols;
   st->chunk = slab_elems < (CRS_CHUNK_POLYS) ? slab_elems : (CRS_CHUNK_POLYS);
@@ -116,11 +128,13 @@ int crs_stream_create(lab_ctx* c, int basis, size_t nmat, size_t rows, size_t co
     e = hipMalloc(reinterpret_cast<void**>(&st->slab), (size_t)L * slab_elems * D * 4);
   }
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&st->coefs), st->chunk * D * 8);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&st->tmp), (size_t)(st->reduce ? 2 : 1) * L * ns * st->R * D * 4);
-  if (e == hipSuccess && st->reduce) e = hipMalloc(reinterpret_cast<void**>(&st->acc), (size_t)ns * rows * D * 8);
+  for (size_t g = 0; g < ngroups; g++) {
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&st->tmp[g]), (size_t)(st->reduce ? 2 : 1) * L * ns * st->R * D * 4);
+    if (e == hipSuccess && st->reduce) e = hipMalloc(reinterpret_cast<void**>(&st->acc[g]), (size_t)ns * rows * D * 8);
+    // (rows past a ragged slab and sets past ns_valid are never stored by the GEMM but are read by the chunk reduction)
+    if (e == hipSuccess && st->reduce) e = hipMemsetAsync(st->tmp[g], 0, (size_t)2 * L * ns * st->R * D * 4, c->stream);
+  }
   if (e == hipSuccess && st->reduce) e = hipMalloc(reinterpret_cast<void**>(&st->cur), (size_t)ns * st->R * D * 8);
-  // (rows past a ragged slab and sets past ns_valid are never stored by the GEMM but are read by the chunk reduction)
-  if (e == hipSuccess && st->reduce) e = hipMemsetAsync(st->tmp, 0, (size_t)2 * L * ns * st->R * D * 4, c->stream);
   if (e != hipSuccess) { delete st; return fail(c, LAB_ERR_HIP, "streamed commitment: hipMalloc of the slab: %s", hipGetErrorString(e)); }
   *out = st;
   return LAB_OK;
@@ -182,13 +196,16 @@ static int fill_slab(CrsStream* st, const uint8_t seed[32], const uint64_t* mat_
 // Loop order: K chunk outside, row slab inside — the vector operand of a chunk (the digits of t transformed and packed as
 // B-operand tiles of every limb) is made ONCE per chunk and multiplied with every slab of that chunk's matrices (slab outside
 // re-made it for each of the kappa1 / 128 slabs: 5.6 % of a kappa = 2^14 step).
-int crs_stream_run(CrsStream* st, const uint8_t seed[32], const uint64_t* mat_offsets, size_t nmat, HatView out, size_t out_set_stride,
-                   const ConstHatView* V, size_t v_set_stride, const JobPtrs* dig, int ns, int ns_valid, void* scratch) {
+int crs_stream_run(CrsStream* st, const uint8_t seed[32], const uint64_t* mat_offsets, size_t nmat, const CrsGroup* groups, size_t ngroups) {
   lab_ctx* c = st->c;
   const int L = basis_nlimbs(c, st->basis);
   const LimbTable* tabs = basis_tabs(c, st->basis);
   const size_t cols = st->cols, rows = st->rows;
-  if (st->reduce) LAB_HIP(c, hipMemsetAsync(st->acc, 0, (size_t)ns * rows * D * 8, c->stream));
+  if (ngroups == 0 || ngroups > st->ngroups) return fail(c, LAB_ERR_ARG, "streamed commitment: %zu groups, the engine was created for %zu", ngroups, st->ngroups);
+  for (size_t g = 0; g < ngroups; g++)
+    if ((size_t)groups[g].ns > st->ns || groups[g].ns_valid > groups[g].ns) return fail(c, LAB_ERR_ARG, "streamed commitment: group %zu has more sets than the engine was created for", g);
+  if (st->reduce)
+    for (size_t g = 0; g < ngroups; g++) LAB_HIP(c, hipMemsetAsync(st->acc[g], 0, (size_t)groups[g].ns * rows * D * 8, c->stream));
   for (size_t m0 = 0; m0 < nmat; m0 += st->MC) {
     const size_t mc = nmat - m0 < st->MC ? nmat - m0 : st->MC;
     const bool first = m0 == 0;
@@ -197,52 +214,58 @@ int crs_stream_run(CrsStream* st, const uint8_t seed[32], const uint64_t* mat_of
       const size_t nr = rows - rho0 < st->R ? rows - rho0 : st->R;
       int rc = fill_slab(st, seed, mat_offsets, m0, mc, rho0, nr);
       if (rc) return rc;
-      const bool direct = first && !st->reduce;
-      HatView dst = direct ? HatView{out.base + rho0 * D, out.plane_stride} : HatView{st->tmp, (size_t)ns * st->R * D};
-      const size_t dst_ss = direct ? out_set_stride : st->R * D;
-      if (dig && !tiles_made) {
-        JobPtrs d;
-        for (int s = 0; s < MAX_JOBS; s++)
-          d.p[s] = (s < ns_valid && dig->p[s]) ? static_cast<void*>(static_cast<uint16_t*>(dig->p[s]) + m0 * cols * D) : nullptr;
-        PhaseSample ps(c, PH_DIGITS, (double)ns_valid * mc * cols * D);
-        if ((rc = digits_to_v8_impl(c, st->m8, d, ns, ns_valid, static_cast<int8_t*>(scratch)))) return rc;
-      }
-      {
-        PhaseSample ps(c, PH_GEMM, mfma_gemm_bytes(st->m8, ns, ns_valid));
-        if (dig || tiles_made) {
-          if ((rc = matvec_mfma_impl(c, dst, dst_ss, st->m8, ConstHatView(), 0, ns, ns_valid, scratch, D, 1, 0, 0, false, nullptr,
-                                     static_cast<const int8_t*>(scratch)))) return rc;
-        } else {   // first slab of the chunk: pack the transform-domain vectors, keep the tiles of every limb for the other slabs
-          ConstHatView v(V->base + m0 * cols * D, V->plane_stride);
-          if ((rc = matvec_mfma_impl(c, dst, dst_ss, st->m8, v, v_set_stride, ns, ns_valid, scratch, D, 1, 0, 0, false, nullptr, nullptr, nullptr,
-                                     static_cast<int8_t*>(scratch)))) return rc;
+      for (size_t gi = 0; gi < ngroups; gi++) {
+        const CrsGroup& G = groups[gi];
+        const int ns = G.ns, ns_valid = G.ns_valid;
+        const bool direct = first && !st->reduce;
+        HatView dst = direct ? HatView{G.out.base + rho0 * D, G.out.plane_stride} : HatView{st->tmp[gi], (size_t)ns * st->R * D};
+        const size_t dst_ss = direct ? G.out_set_stride : st->R * D;
+        if (G.dig && !tiles_made) {
+          JobPtrs d;
+          for (int s = 0; s < MAX_JOBS; s++)
+            d.p[s] = (s < ns_valid && G.dig->p[s]) ? static_cast<void*>(static_cast<uint16_t*>(G.dig->p[s]) + m0 * cols * D) : nullptr;
+          PhaseSample ps(c, PH_DIGITS, (double)ns_valid * mc * cols * D);
+          if ((rc = digits_to_v8_impl(c, st->m8, d, ns, ns_valid, static_cast<int8_t*>(G.scratch)))) return rc;
         }
+        {
+          PhaseSample ps(c, PH_GEMM, mfma_gemm_bytes(st->m8, ns, ns_valid));
+          if (G.dig || tiles_made) {
+            if ((rc = matvec_mfma_impl(c, dst, dst_ss, st->m8, ConstHatView(), 0, ns, ns_valid, G.scratch, D, 1, 0, 0, false, nullptr,
+                                       static_cast<const int8_t*>(G.scratch)))) return rc;
+          } else {   // first slab of the chunk: pack the transform-domain vectors, keep the tiles of every limb for the other slabs
+            ConstHatView v(G.V->base + m0 * cols * D, G.V->plane_stride);
+            if ((rc = matvec_mfma_impl(c, dst, dst_ss, st->m8, v, G.v_set_stride, ns, ns_valid, G.scratch, D, 1, 0, 0, false, nullptr, nullptr, nullptr,
+                                       static_cast<int8_t*>(G.scratch)))) return rc;
+          }
+        }
+        if (st->reduce) {
+          // this (chunk, slab)'s exact sums -> coefficients mod q, added mod q to the rows of the running sum
+          const size_t cnt = (size_t)ns * st->R;
+          uint64_t* cur = st->cur;
+          if ((rc = from_hat(c, ConstHatView(st->tmp[gi], cnt * D), cnt, st->tmp[gi] + (size_t)L * cnt * D, cur, st->basis))) return rc;
+          JobPtrs o, b;
+          JobU64 zero;
+          for (int s = 0; s < MAX_JOBS; s++) {
+            o.p[s] = s < ns_valid ? st->acc[gi] + ((size_t)s * rows + rho0) * D : nullptr;
+            b.p[s] = s < ns_valid ? cur + (size_t)s * st->R * D : nullptr;
+            zero.v[s] = 0;
+          }
+          LAB_HIP(c, launch_coef_elementwise_jobs(o, o, b, nr, c->q, zero, 2, (size_t)ns_valid, c->stream));
+        } else if (!first)
+          LAB_HIP(c, launch_pointwise(PW_ADD, HatView{G.out.base + rho0 * D, G.out.plane_stride}, HatView{G.out.base + rho0 * D, G.out.plane_stride},
+                                      HatView{st->tmp[gi], (size_t)ns * st->R * D}, nr, L, tabs, c->stream, (size_t)ns_valid, G.out_set_stride,
+                                      G.out_set_stride, st->R * D));
       }
       tiles_made = true;
-      if (st->reduce) {
-        // this (chunk, slab)'s exact sums -> coefficients mod q, added mod q to the rows of the running sum
-        const size_t cnt = (size_t)ns * st->R;
-        uint64_t* cur = st->cur;
-        if ((rc = from_hat(c, ConstHatView(st->tmp, cnt * D), cnt, st->tmp + (size_t)L * cnt * D, cur, st->basis))) return rc;
-        JobPtrs o, b;
-        JobU64 zero;
-        for (int s = 0; s < MAX_JOBS; s++) {
-          o.p[s] = s < ns_valid ? st->acc + ((size_t)s * rows + rho0) * D : nullptr;
-          b.p[s] = s < ns_valid ? cur + (size_t)s * st->R * D : nullptr;
-          zero.v[s] = 0;
-        }
-        LAB_HIP(c, launch_coef_elementwise_jobs(o, o, b, nr, c->q, zero, 2, (size_t)ns_valid, c->stream));
-      } else if (!first)
-        LAB_HIP(c, launch_pointwise(PW_ADD, HatView{out.base + rho0 * D, out.plane_stride}, HatView{out.base + rho0 * D, out.plane_stride},
-                                    HatView{st->tmp, (size_t)ns * st->R * D}, nr, L, tabs, c->stream, (size_t)ns_valid, out_set_stride,
-                                    out_set_stride, st->R * D));
     }
   }
   if (st->reduce)   // the sums mod q back into the transform domain, set by set
-    for (int s = 0; s < ns_valid; s++) {
-      int rc = to_hat(c, st->acc + (size_t)s * rows * D, HatView{out.base + (size_t)s * out_set_stride, out.plane_stride}, rows, st->basis);
-      if (rc) return rc;
-    }
+    for (size_t gi = 0; gi < ngroups; gi++)
+      for (int s = 0; s < groups[gi].ns_valid; s++) {
+        int rc = to_hat(c, st->acc[gi] + (size_t)s * rows * D,
+                        HatView{groups[gi].out.base + (size_t)s * groups[gi].out_set_stride, groups[gi].out.plane_stride}, rows, st->basis);
+        if (rc) return rc;
+      }
   return LAB_OK;
 }
 
@@ -264,7 +287,8 @@ extern "C" int lab_crs_matvec_mfma(lab_ctx* c, lab_vec* out, size_t out_off, con
   CrsStream* st = nullptr;
   if ((rc = crs_stream_create(c, V->basis, nmat, rows, cols, ns, &st))) return rc;
   ConstHatView v = V->view(v_off);
-  rc = crs_stream_run(st, base_seed, mat_offsets, nmat, out->view(out_off), rows * D, &v, nmat * cols * D, nullptr, ns, ns, c->scratch);
+  CrsGroup grp{out->view(out_off), rows * D, nullptr, &v, nmat * cols * D, ns, ns, c->scratch};
+  rc = crs_stream_run(st, base_seed, mat_offsets, nmat, &grp, 1);
   if (rc == LAB_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, LAB_ERR_HIP, "lab_crs_matvec_mfma: stream synchronisation failed");
   crs_stream_destroy(st);
   return rc;

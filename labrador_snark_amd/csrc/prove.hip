@@ -12,6 +12,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <coroutine>
 #include <vector>
 
 #include "context.h"
@@ -66,73 +67,108 @@ struct Job {  // device pointers of one proof of the batch
 // proofs of the call as jobs of one launch; the outer commitment (step 3), whose cost is streaming the CRS matrices B_ik, is
 // issued once per group of proofs — up to 64 per pass over B on the matrix cores (B8 or B regenerated from crs_seed), up to 8
 // with the multi-set multiply-add kernel — so B is read (or expanded) once per group instead of once per proof.
+// A batch of more than MAX_JOBS proofs is cut into sub-batches of MAX_JOBS.  With B streamed from the seed the sub-batches must
+// SHARE the pass over the regenerated rows (the expansion is ~80 % of such a step and does not depend on the number of proofs), so
+// the body below is a coroutine: every sub-batch runs steps 1-2 (up to the digits of t), suspends, the driver runs ONE streamed
+// step 3 for all of them (crs_stream_run with one group of vector sets per sub-batch) and resumes each for steps 4-10.  A batch that
+// fits one sub-batch, or has B resident, runs the same body straight through.
+struct ProveTask {
+  struct promise_type {
+    int rc = LAB_OK;
+    ProveTask get_return_object() { return ProveTask{std::coroutine_handle<promise_type>::from_promise(*this)}; }
+    std::suspend_never initial_suspend() noexcept { return {}; }
+    std::suspend_always final_suspend() noexcept { return {}; }
+    void return_value(int v) { rc = v; }
+    void unhandled_exception() { rc = LAB_ERR_HIP; }
+  };
+  std::coroutine_handle<promise_type> h;
+  ProveTask(std::coroutine_handle<promise_type> hh) : h(hh) {}
+  ProveTask(ProveTask&& o) noexcept : h(o.h) { o.h = nullptr; }
+  ProveTask(const ProveTask&) = delete;
+  ~ProveTask() { if (h) h.destroy(); }
+  bool done() const { return h.done(); }
+  int rc() const { return h.promise().rc; }
+  void resume() { h.resume(); }
+};
+constexpr int REDO_IN_MAIN_BASIS = 1 << 20;   // internal result of a sub-batch (never leaves this file)
+struct ProveShared {           // the streamed step 3 the sub-batches of one call share
+  std::vector<CrsGroup> groups;
+  int rc = LAB_OK;
+};
+#define LAB_HIPC(ctx, expr)                                                                           \
+  do {                                                                                                \
+    hipError_t _e = (expr);                                                                           \
+    if (_e != hipSuccess) co_return lab::fail(ctx, LAB_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
 static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const* ins, lab_transcript* const* outs, int* status,
-                            bool allow_digit_ajtai = true) {
-  if (!c) return LAB_ERR_ARG;
-  if (np == 0) return LAB_OK;
+                            bool allow_digit_ajtai = true);
+
+// own_scratch: the call sizes c->scratch itself and carves from its start; otherwise it carves from scratch_off inside an
+// allocation the driver made (region sized by a size_only call: *size_only receives the bytes and nothing is launched)
+static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* const* ins, lab_transcript* const* outs, int* status,
+                                bool allow_digit_ajtai, ProveShared* sh, bool own_scratch, size_t scratch_off, size_t* size_only) {
+  if (!c) co_return LAB_ERR_ARG;
+  if (np == 0) co_return LAB_OK;
   PtrCacheScope ptr_cache;   // every boundary pointer is classified host/device once per call
-  if (!ins || !outs) return fail(c, LAB_ERR_ARG, "lab_prove_core: null argument");
+  if (!ins || !outs) co_return fail(c, LAB_ERR_ARG, "lab_prove_core: null argument");
   for (size_t j = 0; j < np; j++) {
-    if (!ins[j] || !outs[j]) return fail(c, LAB_ERR_ARG, "lab_prove_core: null argument");
+    if (!ins[j] || !outs[j]) co_return fail(c, LAB_ERR_ARG, "lab_prove_core: null argument");
     if (ins[j]->struct_size != sizeof(lab_prove_input))
-      return fail(c, LAB_ERR_ARG, "lab_prove_core: lab_prove_input.struct_size is %zu, this library's layout has %zu bytes (stale binding?)",
+      co_return fail(c, LAB_ERR_ARG, "lab_prove_core: lab_prove_input.struct_size is %zu, this library's layout has %zu bytes (stale binding?)",
                   ins[j]->struct_size, sizeof(lab_prove_input));
   }
-  if (np > (size_t)MAX_JOBS) {   // the per-proof kernels serve up to MAX_JOBS proofs per launch
-    int first = LAB_OK;
-    for (size_t j0 = 0; j0 < np; j0 += MAX_JOBS) {
-      const size_t m = np - j0 < (size_t)MAX_JOBS ? np - j0 : (size_t)MAX_JOBS;
-      const int e = prove_batch_impl(c, m, ins + j0, outs + j0, status ? status + j0 : nullptr, allow_digit_ajtai);
-      if (e != LAB_OK && first == LAB_OK) first = e;
-      if (e != LAB_OK && e != LAB_ERR_JL_REJECTED && e != LAB_ERR_BPP_CHECK) return e;
-    }
-    return first;
-  }
+  if (np > (size_t)MAX_JOBS) co_return fail(c, LAB_ERR_ARG, "lab_prove_core: internal: a sub-batch of %zu proofs", np);
   const lab_prove_input* in = ins[0];
   const size_t n = in->n, r = in->r, kappa = in->kappa, k1 = in->kappa1, k2 = in->kappa2;
   const int t1 = in->t1, t2 = in->t2;
-  if (n == 0 || r == 0 || kappa == 0 || k1 == 0) return fail(c, LAB_ERR_ARG, "lab_prove_core: empty dimension");
-  if (k1 != k2) return fail(c, LAB_ERR_LEN_MISMATCH, "lab_prove_core: u_1 = lhs + rhs needs kappa1 == kappa2 (src/proofgen.rs:153)");
-  if (t1 < 1 || t2 < 1 || t1 > 64 || t2 > 64) return fail(c, LAB_ERR_DECOMPOSE, "lab_prove_core: t1/t2 out of range (t2 = -1 is what RuntimeConstants gives at Q=8191, n=1024)");
-  if (in->b1 < 2 || in->b2 < 2) return fail(c, LAB_ERR_DECOMPOSE, "lab_prove_core: decomposition base < 2 never terminates in the reference");
-  if (r > 4096 || n > (1u << 22) || kappa > (1u << 24) || k1 > (1u << 24)) return fail(c, LAB_ERR_ARG, "lab_prove_core: dimension too large");
+  if (n == 0 || r == 0 || kappa == 0 || k1 == 0) co_return fail(c, LAB_ERR_ARG, "lab_prove_core: empty dimension");
+  if (k1 != k2) co_return fail(c, LAB_ERR_LEN_MISMATCH, "lab_prove_core: u_1 = lhs + rhs needs kappa1 == kappa2 (src/proofgen.rs:153)");
+  if (t1 < 1 || t2 < 1 || t1 > 64 || t2 > 64) co_return fail(c, LAB_ERR_DECOMPOSE, "lab_prove_core: t1/t2 out of range (t2 = -1 is what RuntimeConstants gives at Q=8191, n=1024)");
+  if (in->b1 < 2 || in->b2 < 2) co_return fail(c, LAB_ERR_DECOMPOSE, "lab_prove_core: decomposition base < 2 never terminates in the reference");
+  if (r > 4096 || n > (1u << 22) || kappa > (1u << 24) || k1 > (1u << 24)) co_return fail(c, LAB_ERR_ARG, "lab_prove_core: dimension too large");
   for (size_t j = 0; j < np; j++) {
     const lab_prove_input* x = ins[j];
     if (!x->S || !x->phi || !x->a || (!x->Pi && !x->Pi2) || !x->omega || !x->alpha || !x->beta || !x->c)
-      return fail(c, LAB_ERR_ARG, "lab_prove_core: null input array");
+      co_return fail(c, LAB_ERR_ARG, "lab_prove_core: null input array");
     if ((x->Pi2 != nullptr) != (in->Pi2 != nullptr))
-      return fail(c, LAB_ERR_ARG, "lab_prove_core_batch: either every proof of a batch hands over Pi2 (2 bits per entry) or none");
+      co_return fail(c, LAB_ERR_ARG, "lab_prove_core_batch: either every proof of a batch hands over Pi2 (2 bits per entry) or none");
     if (x->n != n || x->r != r || x->kappa != kappa || x->kappa1 != k1 || x->kappa2 != k2 || x->t1 != t1 || x->t2 != t2 ||
         x->b1 != in->b1 || x->b2 != in->b2 || x->beta_bound != in->beta_bound || x->A != in->A || x->B != in->B || x->crs_seed != in->crs_seed || x->B8 != in->B8 || x->A8 != in->A8 || x->C8 != in->C8 || x->D8 != in->D8 || x->A8d != in->A8d ||
         x->C != in->C || x->Dm != in->Dm || x->a_off != in->a_off || x->b_off != in->b_off || x->c_off != in->c_off ||
         x->d_off != in->d_off)
-      return fail(c, LAB_ERR_ARG, "lab_prove_core_batch: all proofs of a batch must share dimensions, constants and the CRS");
+      co_return fail(c, LAB_ERR_ARG, "lab_prove_core_batch: all proofs of a batch must share dimensions, constants and the CRS");
   }
   const size_t pairs = r * (r + 1) / 2;
   const size_t nr = n * r, rk = r * kappa, rr = r * r;
   int rc;
-  if ((rc = check_range(c, in->A, in->a_off, kappa * n, "lab_prove_core(A)"))) return rc;
+  if ((rc = check_range(c, in->A, in->a_off, kappa * n, "lab_prove_core(A)"))) co_return rc;
   // step 3 runs on the matrix cores when the B matrices were packed for them (lab_mat8_pack); B itself may then be absent
   const lab_mat8* b8 = in->B8;
   // ... or streamed from the CRS seed, slab by slab (crs_stream.hip): B is then never resident
   const bool stream_b = !b8 && !in->B && in->crs_seed;
-  if (!b8 && !in->B && !stream_b) return fail(c, LAB_ERR_ARG, "lab_prove_core: neither B, B8 nor crs_seed given");
-  if (in->B && (rc = check_range(c, in->B, in->b_off, r * (size_t)t1 * k1 * kappa, "lab_prove_core(B)"))) return rc;
-  if ((rc = check_range(c, in->C, in->c_off, pairs * (size_t)t2 * k2, "lab_prove_core(C)"))) return rc;
-  if ((rc = check_range(c, in->Dm, in->d_off, pairs * (size_t)t1 * k2, "lab_prove_core(D)"))) return rc;
+  if (!b8 && !in->B && !stream_b) co_return fail(c, LAB_ERR_ARG, "lab_prove_core: neither B, B8 nor crs_seed given");
+  if (in->B && (rc = check_range(c, in->B, in->b_off, r * (size_t)t1 * k1 * kappa, "lab_prove_core(B)"))) co_return rc;
+  // (C and D themselves may be absent when their packed forms C8 / D8 are given: a prover-only service drops the residues, 46 GB
+  // at kappa = 2^14, like it drops B)
+  if (!in->C && !in->C8) co_return fail(c, LAB_ERR_ARG, "lab_prove_core: neither C nor C8 given");
+  if (!in->Dm && !in->D8) co_return fail(c, LAB_ERR_ARG, "lab_prove_core: neither D nor D8 given");
+  if (in->C && (rc = check_range(c, in->C, in->c_off, pairs * (size_t)t2 * k2, "lab_prove_core(C)"))) co_return rc;
+  if (in->Dm && (rc = check_range(c, in->Dm, in->d_off, pairs * (size_t)t1 * k2, "lab_prove_core(D)"))) co_return rc;
   // B, C, D may live in the context's digit basis (lab_ctx_enable_digit_basis): steps 3, 4, 9 then run in it
-  const int bdig = in->C->basis;
-  if ((in->B && in->B->basis != bdig) || in->Dm->basis != bdig) return fail(c, LAB_ERR_ARG, "lab_prove_core: B, C, D must share one RNS basis");
+  const int bdig = in->C ? in->C->basis : mat8_basis(in->C8);
+  if ((in->B && in->B->basis != bdig) || (in->Dm ? in->Dm->basis : mat8_basis(in->D8)) != bdig)
+    co_return fail(c, LAB_ERR_ARG, "lab_prove_core: B, C, D must share one RNS basis");
   const lab_mat8* a8 = in->A8;
   if (a8 && !mat8_matches(a8, 0, 1, kappa, n))
-    return fail(c, LAB_ERR_ARG, "lab_prove_core: A8 was not packed from the kappa x n matrix A in the main basis");
+    co_return fail(c, LAB_ERR_ARG, "lab_prove_core: A8 was not packed from the kappa x n matrix A in the main basis");
   // Step 1 in the basis of B, C, D (lab_prove_input.A8d): |<A row, s_i>| <= |A row|_2 |s_i|_2 <= sqrt(64 n) (q-1) beta_bound must
   // lie inside that basis' CRT range; the witness norm is summed (saturating, exact) by the pass that transforms S and
   // checked at the end of the call — a witness above beta_bound makes the call start over without this shortcut.
   const lab_mat8* a8d = allow_digit_ajtai ? in->A8d : nullptr;
   uint64_t norm_limit = 0;
   if (in->A8d && (!bdig || !mat8_matches(in->A8d, bdig, 1, kappa, n)))
-    return fail(c, LAB_ERR_ARG, "lab_prove_core: A8d was not packed from the kappa x n matrix A in the basis of B, C, D");
+    co_return fail(c, LAB_ERR_ARG, "lab_prove_core: A8d was not packed from the kappa x n matrix A in the basis of B, C, D");
   if (a8d) {
     long double M = 1.0L;
     for (int l = 0; l < c->dg_nlimbs; l++) M *= (long double)c->dg_primes[l];
@@ -148,15 +184,15 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   // C and D packed the same way: element (rho, m) of the "matrix" is C[m][rho], i.e. pairs*t matrices of kappa2 x 1
   const lab_mat8 *c8 = in->C8, *d8 = in->D8;
   if ((c8 && !mat8_matches(c8, bdig, pairs * (size_t)t2, k2, 1)) || (d8 && !mat8_matches(d8, bdig, pairs * (size_t)t1, k2, 1)))
-    return fail(c, LAB_ERR_ARG, "lab_prove_core: C8 / D8 were not packed as lab_mat8_pack(C, c_off, pairs*t2, kappa2, 1) / (D, d_off, pairs*t1, kappa2, 1)");
+    co_return fail(c, LAB_ERR_ARG, "lab_prove_core: C8 / D8 were not packed as lab_mat8_pack(C, c_off, pairs*t2, kappa2, 1) / (D, d_off, pairs*t1, kappa2, 1)");
   if (b8 && !mat8_matches(b8, bdig, r * (size_t)t1, k1, kappa))
-    return fail(c, LAB_ERR_ARG, "lab_prove_core: B8 was not packed from r*t1 matrices of kappa1 x kappa elements in the basis of C, D");
-  if (in->A->basis != 0 || in->A->compact) return fail(c, LAB_ERR_ARG, "lab_prove_core: A must be a main-basis vector");
+    co_return fail(c, LAB_ERR_ARG, "lab_prove_core: B8 was not packed from r*t1 matrices of kappa1 x kappa elements in the basis of C, D");
+  if (in->A->basis != 0 || in->A->compact) co_return fail(c, LAB_ERR_ARG, "lab_prove_core: A must be a main-basis vector");
   // exactness of every transform-domain reduction (see header comment)
   const u128 qm1 = c->q - 1;
   const u128 bmax = (u128)(in->b1 > in->b2 ? in->b1 : in->b2);
   if (!exact_ok(c, n, qm1) || !exact_ok(c, rr + nr, qm1) || !exact_ok(c, r, qm1))
-    return fail(c, LAB_ERR_RANGE, "lab_prove_core: a reduction exceeds the CRT range of this context; create it with a larger max_len");
+    co_return fail(c, LAB_ERR_RANGE, "lab_prove_core: a reduction exceeds the CRT range of this context; create it with a larger max_len");
   // (B streamed: the K chunks of step 3 are reduced mod q one by one when the whole sum exceeds the basis — crs_stream.hip — so
   // only one chunk's sum has to be exact)
   u128 outer_terms = (u128)r * t1 * kappa;
@@ -165,18 +201,18 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     size_t mc = 0;
     bool reduce = false;
     if (!crs_stream_plan(c, bdig, r * (size_t)t1, kappa, rhs_terms, &mc, &reduce))
-      return fail(c, LAB_ERR_RANGE, "lab_prove_core: one row of B (%zu terms) exceeds the int32 bound of the int8 GEMM or the exactness bound of the CRS basis", kappa);
+      co_return fail(c, LAB_ERR_RANGE, "lab_prove_core: one row of B (%zu terms) exceeds the int32 bound of the int8 GEMM or the exactness bound of the CRS basis", kappa);
     if (reduce) outer_terms = (u128)mc * kappa;
   }
   if (bdig) {
     if (outer_terms + (u128)pairs * t2 > c->dg_terms || (u128)pairs * t1 > c->dg_terms || bmax - 1 > c->dg_vmax)
-      return fail(c, LAB_ERR_RANGE, "lab_prove_core: outer commitments exceed the digit basis bounds (max_terms %llu, digit_bound %llu)",
+      co_return fail(c, LAB_ERR_RANGE, "lab_prove_core: outer commitments exceed the digit basis bounds (max_terms %llu, digit_bound %llu)",
                   (unsigned long long)c->dg_terms, (unsigned long long)(c->dg_vmax + 1));
   } else if (!exact_ok(c, outer_terms + (u128)pairs * t2, bmax) || !exact_ok(c, (u128)pairs * t1, (u128)in->b1)) {
-    return fail(c, LAB_ERR_RANGE, "lab_prove_core: a reduction exceeds the CRT range of this context; create it with a larger max_len");
+    co_return fail(c, LAB_ERR_RANGE, "lab_prove_core: a reduction exceeds the CRT range of this context; create it with a larger max_len");
   }
-  if ((u128)r * n * D * qm1 >= ((u128)1 << 63)) return fail(c, LAB_ERR_RANGE, "lab_prove_core: JL projection does not fit 64 bits");
-  LAB_HIP(c, hipSetDevice(c->device));
+  if ((u128)r * n * D * qm1 >= ((u128)1 << 63)) co_return fail(c, LAB_ERR_RANGE, "lab_prove_core: JL projection does not fit 64 bits");
+  LAB_HIPC(c, hipSetDevice(c->device));
 
   // the digits of t go straight into B-operand tiles of every limb (transform + packing fused) when they are 16-bit words
   // below every prime of B's basis: their transform-domain copy then never exists
@@ -231,6 +267,9 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   size_t bytes = Carver::padded((size_t)L * hat_words * 4) + Carver::padded((size_t)Ld * hatd_words * 4) +
                  Carver::padded(np * (size_t)(L > Ld ? L : Ld) * tmp_elems * D * 4) +
                  np * (coef_elems * (D * 8) + 32 * 256 /*alignment padding of the carves*/ + 3 * 4096 /*proj*/);
+  for (size_t j = 0; j < np; j++) {   // t produced in place in a device-resident caller buffer needs no copy here (268 MB per proof at kappa = 2^14)
+    if (outs[j]->t_i_all && is_device_pointer(outs[j]->t_i_all)) bytes -= rk * (size_t)(D * 8);
+  }
   for (size_t j = 0; j < np; j++) {
     const lab_prove_input* x = ins[j];
     bytes += Staging::need(x->S, nr * D * 8) + Staging::need(x->phi, nr * D * 8) + Staging::need(x->a, rr * D * 8) +
@@ -240,7 +279,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   // int8-MFMA step 3: padded set count of the largest group and its scratch (B-operand tiles + int32 results)
   const int mf_ns = np > 32 ? 64 : np > 16 ? 32 : np > 8 ? 16 : 8;
   size_t mf_bytes = b8 ? mfma_scratch_bytes(b8, mf_ns, 1) + 4096 : 0;
-  if (stream_b && !fuse_t) return fail(c, LAB_ERR_ARG, "lab_prove_core: the streamed outer commitment needs decomposition bases up to 65536 below the limb primes");
+  if (stream_b && !fuse_t) co_return fail(c, LAB_ERR_ARG, "lab_prove_core: the streamed outer commitment needs decomposition bases up to 65536 below the limb primes");
   if (stream_b && crs_stream_scratch_bytes(c, bdig, r * (size_t)t1, k1, kappa, mf_ns, rhs_terms) + 4096 > mf_bytes)
     mf_bytes = crs_stream_scratch_bytes(c, bdig, r * (size_t)t1, k1, kappa, mf_ns, rhs_terms) + 4096;
   if (fuse_t && b8 && mfma_prepacked_bytes(b8, mf_ns) + 4096 > mf_bytes) mf_bytes = mfma_prepacked_bytes(b8, mf_ns) + 4096;
@@ -253,8 +292,9 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if (c8 && mfma_scratch_bytes(c8, mf_ns, 1) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(c8, mf_ns, 1) + 4096;
   if (d8 && mfma_scratch_bytes(d8, mf_ns, 1) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(d8, mf_ns, 1) + 4096;
   bytes += mf_bytes;
-  if ((rc = ensure_scratch(c, bytes + (1 << 16)))) return rc;
-  Carver cv(c->scratch);
+  if (size_only) { *size_only = bytes + (1 << 16); co_return LAB_OK; }
+  if (own_scratch && (rc = ensure_scratch(c, bytes + (1 << 16)))) co_return rc;
+  Carver cv(static_cast<char*>(c->scratch) + (own_scratch ? 0 : scratch_off));
   char* mf_scratch = mf_bytes ? cv.take<char>(mf_bytes) : nullptr;
   int8_t* s_tiles = stile_bytes ? cv.take<int8_t>(stile_bytes) : nullptr;
   uint32_t* hat_base = cv.take<uint32_t>((size_t)L * hat_words);
@@ -282,16 +322,16 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     J.cbpp = OUT(o->b_prime_prime, 1); J.cab = CO(2);
     J.dproj_int = proj_all + j * 256;
     J.dproj = OUT(o->projection, 4);
-    if ((rc = st.in(x->S, nr * D, &J.dS))) return rc;
-    if ((rc = st.in(x->phi, nr * D, &J.dphi))) return rc;
-    if ((rc = st.in(x->a, rr * D, &J.da))) return rc;
+    if ((rc = st.in(x->S, nr * D, &J.dS))) co_return rc;
+    if ((rc = st.in(x->phi, nr * D, &J.dphi))) co_return rc;
+    if ((rc = st.in(x->a, rr * D, &J.da))) co_return rc;
     J.dPi = nullptr; J.dPi2 = nullptr;
-    if (x->Pi2) { if ((rc = st.in(x->Pi2, r * 256 * n * (D / 4), &J.dPi2))) return rc; }
-    else if ((rc = st.in(x->Pi, r * 256 * n * D, &J.dPi))) return rc;
-    if ((rc = st.in(x->omega, (size_t)256, &J.domega))) return rc;
-    if ((rc = st.in(x->alpha, (size_t)D, &J.dalpha))) return rc;
-    if ((rc = st.in(x->beta, (size_t)D, &J.dbeta))) return rc;
-    if ((rc = st.in(x->c, r * D, &J.dc))) return rc;
+    if (x->Pi2) { if ((rc = st.in(x->Pi2, r * 256 * n * (D / 4), &J.dPi2))) co_return rc; }
+    else if ((rc = st.in(x->Pi, r * 256 * n * D, &J.dPi))) co_return rc;
+    if ((rc = st.in(x->omega, (size_t)256, &J.domega))) co_return rc;
+    if ((rc = st.in(x->alpha, (size_t)D, &J.dalpha))) co_return rc;
+    if ((rc = st.in(x->beta, (size_t)D, &J.dbeta))) co_return rc;
+    if ((rc = st.in(x->c, r * D, &J.dc))) co_return rc;
   }
   hipStream_t s = c->stream;
   const LimbTable* tabs = c->d_tabs;
@@ -345,28 +385,28 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
 
   // ================= phase A: transforms
   if (!sd_only) {
-    if ((rc = to_hat_jobs(JP(&Job::dS), hS, nr, false))) return rc;
-    if ((rc = to_hat_jobs(JP(&Job::dphi), hphi, nr, false))) return rc;
+    if ((rc = to_hat_jobs(JP(&Job::dS), hS, nr, false))) co_return rc;
+    if ((rc = to_hat_jobs(JP(&Job::dphi), hphi, nr, false))) co_return rc;
   }
-  if ((rc = to_hat_jobs(JP(&Job::dalpha), hab, 1, false))) return rc;
-  if ((rc = to_hat_jobs(JP(&Job::dbeta), hab + 1, 1, false))) return rc;
-  if ((rc = to_hat_jobs(JP(&Job::dc), hc, r, false))) return rc;
+  if ((rc = to_hat_jobs(JP(&Job::dalpha), hab, 1, false))) co_return rc;
+  if ((rc = to_hat_jobs(JP(&Job::dbeta), hab + 1, 1, false))) co_return rc;
+  if ((rc = to_hat_jobs(JP(&Job::dc), hc, r, false))) co_return rc;
   // ================= step 1 (src/proofgen.rs:41-49): t_i = A s_i for every column of every proof; A is shared, so the
   // whole batch is one (kappa x n)(n x np*r) product (falls back to one launch per proof for shapes it does not take)
   uint64_t* norm_sums = host_stage + np * (256 + 256 + D);
   bool t_in_dense = false, g_in_digit = false, t_digits_done = false;
   if (a8d) {  // matrix cores, in the basis of B, C, D (see a8d above): S once more into that basis, its norm summed on the way
-    LAB_HIP(c, hipMemsetAsync(norm_sums, 0, np * 8, s));
-    LAB_HIP(c, hipMemsetAsync(above16, 0, np * 4, s));
+    LAB_HIPC(c, hipMemsetAsync(norm_sums, 0, np * 8, s));
+    LAB_HIPC(c, hipMemsetAsync(above16, 0, np * 4, s));
     // (coefficients above beta_bound are caught by the norm sum and the batch is redone: the transform may assume the bound)
-    LAB_HIP(c, launch_to_hat_fused(JP(&Job::dS), HD(0, hSd), jsd, nr, Ld, tabsd, np, s, (uint64_t)in->beta_bound + 1,
+    LAB_HIPC(c, launch_to_hat_fused(JP(&Job::dS), HD(0, hSd), jsd, nr, Ld, tabsd, np, s, (uint64_t)in->beta_bound + 1,
                                    reinterpret_cast<unsigned long long*>(norm_sums), norm_limit, false, above16));
     for (size_t i0 = 0; i0 < r; i0 += 32) {
       const int valid = (int)(r - i0 < 32 ? r - i0 : 32);
       MfmaCoefOut co{dense_tmp + i0 * kappa * D, rk * D, tmp_js, kappa, false};   // t is only wanted as coefficients
       MfmaGramOut go{HD(0, hGd).base, hatd_words, perd * D, r, false};            // step 2 (G = S^T S) from the same tiles
       if ((rc = matvec_mfma_impl(c, HD(0, hTd + i0 * kappa), kappa * D, a8d, HD(0, hSd + i0), D, a8_ns, valid, mf_scratch, r * D, np,
-                                 perd * D, perd * D, false, &co, nullptr, r <= 32 ? &go : nullptr, s_tiles))) return rc;
+                                 perd * D, perd * D, false, &co, nullptr, r <= 32 ? &go : nullptr, s_tiles))) co_return rc;
       t_in_dense = co.done;
       g_in_digit = go.done;
     }
@@ -376,7 +416,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
       const int valid = (int)(r - i0 < 32 ? r - i0 : 32);
       MfmaCoefOut co{dense_tmp + i0 * kappa * D, rk * D, tmp_js, kappa, false};
       if ((rc = matvec_mfma_impl(c, HV(0, hT + i0 * kappa), kappa * D, a8, HV(0, hS + i0), D, a8_ns, valid, mf_scratch, r * D, np,
-                                 per * D, per * D, false, &co))) return rc;
+                                 per * D, per * D, false, &co))) co_return rc;
       t_in_dense = co.done;
     }
   } else {
@@ -384,9 +424,9 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
                                        kappa, n, r, L, tabs, s);
     if (e == hipErrorNotSupported) {
       for (size_t j = 0; j < np; j++)
-        LAB_HIP(c, launch_matmul_t(HV(j, hT), in->A->view(in->a_off), HV(j, hS), kappa, n, r, L, tabs, s));
+        LAB_HIPC(c, launch_matmul_t(HV(j, hT), in->A->view(in->a_off), HV(j, hS), kappa, n, r, L, tabs, s));
     } else {
-      LAB_HIP(c, e);
+      LAB_HIPC(c, e);
     }
   }
   if (t_in_dense) {   // the inverse transform already ran from the GEMM's staging array: only the CRT is left
@@ -398,22 +438,22 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
                          : hipErrorNotSupported;
     if (e == hipSuccess) t_digits_done = true;
     else if (e == hipErrorNotSupported)
-      LAB_HIP(c, launch_crt_to_u64_jobs(HatView{dense_tmp, rk * D}, tmp_js, JP(&Job::cT), rk, basis_crt(c, basis), basis_nlimbs(c, basis), np, s));
-    else LAB_HIP(c, e);
+      LAB_HIPC(c, launch_crt_to_u64_jobs(HatView{dense_tmp, rk * D}, tmp_js, JP(&Job::cT), rk, basis_crt(c, basis), basis_nlimbs(c, basis), np, s));
+    else LAB_HIPC(c, e);
   } else if ((rc = a8d ? from_hat_jobs(hTd, rk, JP(&Job::cT), true) : from_hat_jobs(hT, rk, JP(&Job::cT), false))) {
-    return rc;
+    co_return rc;
   }
   // step 2 (:59-70): G = S^T S
-  if (sd_only && !g_in_digit) return fail(c, LAB_ERR_ARG, "lab_prove_core: internal: the digit-basis Gram product was not taken");
+  if (sd_only && !g_in_digit) co_return fail(c, LAB_ERR_ARG, "lab_prove_core: internal: the digit-basis Gram product was not taken");
   if (g_in_digit) {
-    if ((rc = from_hat_jobs(hGd, rr, JP(&Job::cG), true))) return rc;
+    if ((rc = from_hat_jobs(hGd, rr, JP(&Job::cG), true))) co_return rc;
   } else {
-    if ((rc = gram_jobs(hG, hS, hS))) return rc;
-    if ((rc = from_hat_jobs(hG, rr, JP(&Job::cG), false))) return rc;
+    if ((rc = gram_jobs(hG, hS, hS))) co_return rc;
+    if ((rc = from_hat_jobs(hG, rr, JP(&Job::cG), false))) co_return rc;
   }
   // digits of t in [i][k][rho] order, into the basis of B
-  if (!t_digits_done) LAB_HIP(c, launch_decompose_jobs(JP(&Job::cTdec), JP(&Job::cT), rk, q, (uint64_t)in->b1, t1, kappa, np, s, dig16));
-  if (!fuse_t && (rc = to_hat_jobs(JP(&Job::cTdec), hTdec, rk * t1, true, (uint64_t)in->b1, dig16))) return rc;
+  if (!t_digits_done) LAB_HIPC(c, launch_decompose_jobs(JP(&Job::cTdec), JP(&Job::cT), rk, q, (uint64_t)in->b1, t1, kappa, np, s, dig16));
+  if (!fuse_t && (rc = to_hat_jobs(JP(&Job::cTdec), hTdec, rk * t1, true, (uint64_t)in->b1, dig16))) co_return rc;
 
   // ================= step 3 (:101-132) for the whole batch: lhs_j = sum_{i,k} B_ik t_{j,i}^(k); B streamed once per group
   for (size_t j0 = 0; b8 && j0 < np;) {   // matrix cores: up to 64 proofs per pass over B, result written in place
@@ -422,10 +462,10 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     if (fuse_t) {
       JobPtrs dig;
       for (int i = 0; i < valid; i++) dig.p[i] = jobs[j0 + i].cTdec;
-      if ((rc = digits_to_v8_impl(c, b8, dig, ns, valid, reinterpret_cast<int8_t*>(mf_scratch)))) return rc;
+      if ((rc = digits_to_v8_impl(c, b8, dig, ns, valid, reinterpret_cast<int8_t*>(mf_scratch)))) co_return rc;
     }
     if ((rc = matvec_mfma_impl(c, HD(j0, hlhs), perd * D, b8, HD(j0, hTdec), perd * D, ns, valid, mf_scratch, D, 1, 0, 0, true, nullptr,
-                               fuse_t ? reinterpret_cast<const int8_t*>(mf_scratch) : nullptr))) return rc;
+                               fuse_t ? reinterpret_cast<const int8_t*>(mf_scratch) : nullptr))) co_return rc;
     j0 += valid;
   }
   if (stream_b) {   // B streamed from the seed: up to 64 proofs per pass over the regenerated rows
@@ -436,31 +476,35 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
       const u128 off = (u128)kappa * n * D + (u128)m * k1 * kappa;
       offs[2 * m] = (uint64_t)off; offs[2 * m + 1] = (uint64_t)(off >> 64);
     }
-    for (size_t j0 = 0; j0 < np;) {
-      const size_t left = np - j0;
-      const int ns = left > 32 ? 64 : left > 16 ? 32 : left > 8 ? 16 : 8, valid = (int)(left < (size_t)ns ? left : (size_t)ns);
+    // (np <= MAX_JOBS: one group of vector sets)
+    const int ns = np > 32 ? 64 : np > 16 ? 32 : np > 8 ? 16 : 8, valid = (int)np;
+    JobPtrs dig;
+    for (int i = 0; i < MAX_JOBS; i++) dig.p[i] = i < valid ? jobs[i].cTdec : nullptr;
+    const CrsGroup grp{HD(0, hlhs), perd * D, &dig, nullptr, 0, ns, valid, mf_scratch};
+    if (sh) {   // the driver streams B once for every sub-batch of the call
+      sh->groups.push_back(grp);
+      co_await std::suspend_always{};
+      if (sh->rc) co_return sh->rc;
+    } else {
       CrsStream* cs = nullptr;
-      if ((rc = crs_stream_create(c, bdig, nmat, k1, kappa, ns, &cs, rhs_terms))) return rc;
-      JobPtrs dig;
-      for (int i = 0; i < MAX_JOBS; i++) dig.p[i] = i < valid ? jobs[j0 + i].cTdec : nullptr;
-      rc = crs_stream_run(cs, in->crs_seed, offs.data(), nmat, HD(j0, hlhs), perd * D, nullptr, 0, &dig, ns, valid, mf_scratch);
+      if ((rc = crs_stream_create(c, bdig, nmat, k1, kappa, ns, &cs, rhs_terms))) co_return rc;
+      rc = crs_stream_run(cs, in->crs_seed, offs.data(), nmat, &grp, 1);
       if (rc == LAB_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(c, LAB_ERR_HIP, "lab_prove_core: streamed outer commitment failed");
       crs_stream_destroy(cs);
-      if (rc) return rc;
-      j0 += valid;
+      if (rc) co_return rc;
     }
   }
   for (size_t j0 = 0; !b8 && !stream_b && j0 < np;) {
     int g = 1;
     while (g < 8 && j0 + 2 * (size_t)g <= np) g *= 2;
     if (g == 1) {
-      if ((rc = matvec_partial_any(c, HD(j0, hpartd), in->B, in->b_off, HD(j0, hTdec), r * (size_t)t1, k1, kappa))) return rc;
+      if ((rc = matvec_partial_any(c, HD(j0, hpartd), in->B, in->b_off, HD(j0, hTdec), r * (size_t)t1, k1, kappa))) co_return rc;
     } else {
       if ((rc = matvec_partial_batched_any(c, g, HD(j0, hpartd), perd * D, in->B, in->b_off, HD(j0, hTdec), perd * D,
-                                           r * (size_t)t1, k1, kappa))) return rc;
+                                           r * (size_t)t1, k1, kappa))) co_return rc;
     }
     for (int b = 0; b < g; b++)
-      LAB_HIP(c, launch_sum_terms(HD(j0 + b, hlhs), HD(j0 + b, hpartd), r * (size_t)t1, k1, Ld, tabsd, s));
+      LAB_HIPC(c, launch_sum_terms(HD(j0 + b, hlhs), HD(j0 + b, hpartd), r * (size_t)t1, k1, Ld, tabsd, s));
     j0 += g;
   }
 
@@ -477,9 +521,9 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   };
 
   // ================= step 4 (:137-148): rhs = sum_{i<=j,k} g_ij^(k) C_ijk ; u_1 = lhs + rhs (:153)
-  LAB_HIP(c, launch_gather_upper_jobs(JP(&Job::cGup), JP(&Job::cG), r, np, s));
-  LAB_HIP(c, launch_decompose_jobs(JP(&Job::cGdec), JP(&Job::cGup), pairs, q, (uint64_t)in->b2, t2, 1, np, s, dig16));  // [pair][k]
-  if ((rc = to_hat_jobs(JP(&Job::cGdec), hGdec, pairs * t2, true, (uint64_t)in->b2, dig16))) return rc;
+  LAB_HIPC(c, launch_gather_upper_jobs(JP(&Job::cGup), JP(&Job::cG), r, np, s));
+  LAB_HIPC(c, launch_decompose_jobs(JP(&Job::cGdec), JP(&Job::cGup), pairs, q, (uint64_t)in->b2, t2, 1, np, s, dig16));  // [pair][k]
+  if ((rc = to_hat_jobs(JP(&Job::cGdec), hGdec, pairs * t2, true, (uint64_t)in->b2, dig16))) co_return rc;
   // sum_m digits[m] * Cm[m][rho] for every proof: on the matrix cores when Cm was packed for them (up to 64 proofs per
   // pass), else with the multiply-add kernels in groups of 8
   auto commit_digits = [&](const lab_mat8* m8, const lab_vec* Cm, size_t cm_off, size_t out_off, size_t dig_off, size_t nterms) -> int {
@@ -498,19 +542,19 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
                                      HD(j0, hpartd), perd * D);
     });
   };
-  if ((rc = commit_digits(c8, in->C, in->c_off, hrhs, hGdec, pairs * t2))) return rc;
-  LAB_HIP(c, launch_pointwise(PW_ADD, HD(0, hlhs), HD(0, hlhs), HD(0, hrhs), k1, Ld, tabsd, s, np, jsd, jsd, jsd));
-  if ((rc = from_hat_jobs(hlhs, k1, JP(&Job::cu1), true))) return rc;
+  if ((rc = commit_digits(c8, in->C, in->c_off, hrhs, hGdec, pairs * t2))) co_return rc;
+  LAB_HIPC(c, launch_pointwise(PW_ADD, HD(0, hlhs), HD(0, hlhs), HD(0, hrhs), k1, Ld, tabsd, s, np, jsd, jsd, jsd));
+  if ((rc = from_hat_jobs(hlhs, k1, JP(&Job::cu1), true))) co_return rc;
 
   // ================= step 5 (:161-186, 429-456): JL projection over the integers
   // (one pass over Pi also produces W, the Pi part of phi'' used in step 6)
-  LAB_HIP(c, hipMemsetAsync(proj_all, 0, np * 256 * 8, s));
+  LAB_HIPC(c, hipMemsetAsync(proj_all, 0, np * 256 * 8, s));
   if (in->Pi2)   // 2 bits per entry; with the digit-basis step 1 the witness is inside its norm bound (coefficients < 2^24) or the batch is redone
-    LAB_HIP(c, launch_pi_fused2_jobs(JP(&Job::dproj_int), JP(&Job::cW), JP(&Job::dPi2), JP(&Job::dS), JP(&Job::domega), n, r, q, np,
+    LAB_HIPC(c, launch_pi_fused2_jobs(JP(&Job::dproj_int), JP(&Job::cW), JP(&Job::dPi2), JP(&Job::dS), JP(&Job::domega), n, r, q, np,
                                      a8d != nullptr, s, a8d ? above16 : nullptr));
   else
-    LAB_HIP(c, launch_pi_fused_jobs(JP(&Job::dproj_int), JP(&Job::cW), JP(&Job::dPi), JP(&Job::dS), JP(&Job::domega), n, r, q, np, s));
-  LAB_HIP(c, launch_lift_i64_jobs(JP(&Job::dproj), JP(&Job::dproj_int), 256, q, np, s));
+    LAB_HIPC(c, launch_pi_fused_jobs(JP(&Job::dproj_int), JP(&Job::cW), JP(&Job::dPi), JP(&Job::dS), JP(&Job::domega), n, r, q, np, s));
+  LAB_HIPC(c, launch_lift_i64_jobs(JP(&Job::dproj), JP(&Job::dproj_int), 256, q, np, s));
 
   // ================= steps 6-8 (:205-289, :301-314, :320-358).  phi''_i = psi phi'_i + W_i and phi_i = alpha phi'_i + beta phi''_i
   // are only ever used inside inner products with the witness, which are linear in them:
@@ -524,51 +568,51 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   {
     JobPtrs none;
     for (size_t j = 0; j < np; j++) { psi.v[j] = ins[j]->psi % q; none.p[j] = nullptr; }
-    LAB_HIP(c, launch_coef_elementwise_jobs(JP(&Job::capp), JP(&Job::da), none, rr, q, psi, 0, np, s));   // a'' = psi a'
+    LAB_HIPC(c, launch_coef_elementwise_jobs(JP(&Job::capp), JP(&Job::da), none, rr, q, psi, 0, np, s));   // a'' = psi a'
   }
-  if ((rc = to_hat_jobs(JP(&Job::capp), happ, rr, false))) return rc;
-  if (!sd_only && (rc = to_hat_jobs(JP(&Job::cW), hphipp, nr, false))) return rc;   // W in the transform domain
-  if ((rc = to_hat_jobs(JP(&Job::cG), hGc, rr, false))) return rc;
-  if ((rc = inner_product_jobs(hbpp, happ, hGc, rr))) return rc;               // sum a''_ij g_ij
-  if ((rc = from_hat_jobs(hbpp, 1, JP(&Job::cab), false))) return rc;
+  if ((rc = to_hat_jobs(JP(&Job::capp), happ, rr, false))) co_return rc;
+  if (!sd_only && (rc = to_hat_jobs(JP(&Job::cW), hphipp, nr, false))) co_return rc;   // W in the transform domain
+  if ((rc = to_hat_jobs(JP(&Job::cG), hGc, rr, false))) co_return rc;
+  if ((rc = inner_product_jobs(hbpp, happ, hGc, rr))) co_return rc;               // sum a''_ij g_ij
+  if ((rc = from_hat_jobs(hbpp, 1, JP(&Job::cab), false))) co_return rc;
   if (sd_only) {   // both Gram products on the matrix cores, in the basis of the witness tiles
     const HatView xo[2] = {HD(0, hX1d), HD(0, hXWd)};
     const JobPtrs xp[2] = {JP(&Job::dphi), JP(&Job::cW)};
-    if ((rc = gram_mfma_impl(c, a8d, 2, xo, xp, s_tiles, jsd, n, r, np, mf_scratch))) return rc;
-    if ((rc = from_hat_jobs(hX1d, rr, JP(&Job::cX1), true))) return rc;
-    if ((rc = from_hat_jobs(hXWd, rr, JP(&Job::cX), true))) return rc;        // XW
+    if ((rc = gram_mfma_impl(c, a8d, 2, xo, xp, s_tiles, jsd, n, r, np, mf_scratch))) co_return rc;
+    if ((rc = from_hat_jobs(hX1d, rr, JP(&Job::cX1), true))) co_return rc;
+    if ((rc = from_hat_jobs(hXWd, rr, JP(&Job::cX), true))) co_return rc;        // XW
   } else {
-    if ((rc = gram_jobs(hX1, hphi, hS))) return rc;
-    if ((rc = gram_jobs(hX2, hphipp, hS))) return rc;
-    if ((rc = from_hat_jobs(hX1, rr, JP(&Job::cX1), false))) return rc;
-    if ((rc = from_hat_jobs(hX2, rr, JP(&Job::cX), false))) return rc;           // XW
+    if ((rc = gram_jobs(hX1, hphi, hS))) co_return rc;
+    if ((rc = gram_jobs(hX2, hphipp, hS))) co_return rc;
+    if ((rc = from_hat_jobs(hX1, rr, JP(&Job::cX1), false))) co_return rc;
+    if ((rc = from_hat_jobs(hX2, rr, JP(&Job::cX), false))) co_return rc;           // XW
   }
-  LAB_HIP(c, launch_coef_elementwise_jobs(JP(&Job::cX2), JP(&Job::cX1), JP(&Job::cX), rr, q, psi, 1, np, s));   // X2 = psi X1 + XW
-  LAB_HIP(c, launch_add_trace_jobs(JP(&Job::cbpp), JP(&Job::cab), JP(&Job::cX2), r, q, np, s));                  // b''
-  if ((rc = to_hat_jobs(JP(&Job::cX1), hX1, rr, false))) return rc;
-  if ((rc = to_hat_jobs(JP(&Job::cX2), hX2, rr, false))) return rc;
-  LAB_HIP(c, launch_poly_by_vec(HV(0, hX1), HV(0, hab), HV(0, hX1), rr, L, tabs, s, np, js));
-  LAB_HIP(c, launch_poly_by_vec(HV(0, hX2), HV(0, hab + 1), HV(0, hX2), rr, L, tabs, s, np, js));
-  LAB_HIP(c, launch_pointwise(PW_ADD, HV(0, hX), HV(0, hX1), HV(0, hX2), rr, L, tabs, s, np, js, js, js));
-  if ((rc = from_hat_jobs(hX, rr, JP(&Job::cX), false))) return rc;
-  LAB_HIP(c, launch_symmetrize_half_jobs(JP(&Job::cH), JP(&Job::cX), r, q, inv2_mod(q), np, s));
+  LAB_HIPC(c, launch_coef_elementwise_jobs(JP(&Job::cX2), JP(&Job::cX1), JP(&Job::cX), rr, q, psi, 1, np, s));   // X2 = psi X1 + XW
+  LAB_HIPC(c, launch_add_trace_jobs(JP(&Job::cbpp), JP(&Job::cab), JP(&Job::cX2), r, q, np, s));                  // b''
+  if ((rc = to_hat_jobs(JP(&Job::cX1), hX1, rr, false))) co_return rc;
+  if ((rc = to_hat_jobs(JP(&Job::cX2), hX2, rr, false))) co_return rc;
+  LAB_HIPC(c, launch_poly_by_vec(HV(0, hX1), HV(0, hab), HV(0, hX1), rr, L, tabs, s, np, js));
+  LAB_HIPC(c, launch_poly_by_vec(HV(0, hX2), HV(0, hab + 1), HV(0, hX2), rr, L, tabs, s, np, js));
+  LAB_HIPC(c, launch_pointwise(PW_ADD, HV(0, hX), HV(0, hX1), HV(0, hX2), rr, L, tabs, s, np, js, js, js));
+  if ((rc = from_hat_jobs(hX, rr, JP(&Job::cX), false))) co_return rc;
+  LAB_HIPC(c, launch_symmetrize_half_jobs(JP(&Job::cH), JP(&Job::cX), r, q, inv2_mod(q), np, s));
   // digits of the upper triangle of H for step 9
-  LAB_HIP(c, launch_gather_upper_jobs(JP(&Job::cHup), JP(&Job::cH), r, np, s));
-  LAB_HIP(c, launch_decompose_jobs(JP(&Job::cHdec), JP(&Job::cHup), pairs, q, (uint64_t)in->b1, t1, 1, np, s, dig16));
-  if ((rc = to_hat_jobs(JP(&Job::cHdec), hHdec, pairs * t1, true, (uint64_t)in->b1, dig16))) return rc;
+  LAB_HIPC(c, launch_gather_upper_jobs(JP(&Job::cHup), JP(&Job::cH), r, np, s));
+  LAB_HIPC(c, launch_decompose_jobs(JP(&Job::cHdec), JP(&Job::cHup), pairs, q, (uint64_t)in->b1, t1, 1, np, s, dig16));
+  if ((rc = to_hat_jobs(JP(&Job::cHdec), hHdec, pairs * t1, true, (uint64_t)in->b1, dig16))) co_return rc;
 
   // ================= step 9 (:364-378): u_2 = sum_{i<=j,k} h_ij^(k) D_ijk ; D streamed once per group
-  if ((rc = commit_digits(d8, in->Dm, in->d_off, hu2, hHdec, pairs * t1))) return rc;
-  if ((rc = from_hat_jobs(hu2, k2, JP(&Job::cu2), true))) return rc;
+  if ((rc = commit_digits(d8, in->Dm, in->d_off, hu2, hHdec, pairs * t1))) co_return rc;
+  if ((rc = from_hat_jobs(hu2, k2, JP(&Job::cu2), true))) co_return rc;
 
   // ================= step 10 (:380-399): z = sum_i c_i s_i
   if (sd_only) {
-    if ((rc = to_hat_jobs(JP(&Job::dc), hcd, r, true))) return rc;
-    LAB_HIP(c, launch_matvec_partial(HD(0, hzd), HD(0, hSd), HD(0, hcd), 1, n, r, Ld, tabsd, s, np, jsd));
-    if ((rc = from_hat_jobs(hzd, n, JP(&Job::cz), true))) return rc;
+    if ((rc = to_hat_jobs(JP(&Job::dc), hcd, r, true))) co_return rc;
+    LAB_HIPC(c, launch_matvec_partial(HD(0, hzd), HD(0, hSd), HD(0, hcd), 1, n, r, Ld, tabsd, s, np, jsd));
+    if ((rc = from_hat_jobs(hzd, n, JP(&Job::cz), true))) co_return rc;
   } else {
-    LAB_HIP(c, launch_matvec_partial(HV(0, hz), HV(0, hS), HV(0, hc), 1, n, r, L, tabs, s, np, js));
-    if ((rc = from_hat_jobs(hz, n, JP(&Job::cz), false))) return rc;
+    LAB_HIPC(c, launch_matvec_partial(HV(0, hz), HV(0, hS), HV(0, hc), 1, n, r, L, tabs, s, np, js));
+    if ((rc = from_hat_jobs(hz, n, JP(&Job::cz), false))) co_return rc;
   }
 
   // ================= copy-out and the two verifier callbacks that can reject
@@ -576,15 +620,15 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   if (c->pinned_words < hst_words) {   // page-locked: the copy is one DMA, not a staged pageable transfer
     if (c->pinned) (void)hipHostFree(c->pinned);
     c->pinned = nullptr; c->pinned_words = 0;
-    LAB_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->pinned), hst_words * 8, hipHostMallocDefault));
+    LAB_HIPC(c, hipHostMalloc(reinterpret_cast<void**>(&c->pinned), hst_words * 8, hipHostMallocDefault));
     c->pinned_words = hst_words;
   }
   uint64_t* const hst = c->pinned;
   const int64_t* hproj = reinterpret_cast<const int64_t*>(hst);
   const uint64_t* homega = hst + np * 256;
   const uint64_t* hbpp_st = hst + np * 512;
-  LAB_HIP(c, launch_gather_jobs(host_stage + np * 256, JP(&Job::domega), 256, np, s));
-  LAB_HIP(c, launch_gather_jobs(host_stage + np * 512, JP(&Job::cbpp), D, np, s));
+  LAB_HIPC(c, launch_gather_jobs(host_stage + np * 256, JP(&Job::domega), 256, np, s));
+  LAB_HIPC(c, launch_gather_jobs(host_stage + np * 512, JP(&Job::cbpp), D, np, s));
   {  // integer projections to device-resident caller buffers (host ones are filled from the staged copy below)
     JobPtrs pi;
     bool any = false;
@@ -593,7 +637,7 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
       pi.p[j] = (u && is_device_pointer(u)) ? u : nullptr;
       any = any || pi.p[j];
     }
-    if (any) LAB_HIP(c, launch_scatter_jobs(pi, host_stage, 256, np, s));
+    if (any) LAB_HIPC(c, launch_scatter_jobs(pi, host_stage, 256, np, s));
   }
   for (size_t j = 0; j < np; j++) {
     Job& J = jobs[j];
@@ -602,18 +646,22 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
         {o->u_1, J.cu1, k1 * D}, {o->projection, J.dproj, 256}, {o->b_prime_prime, J.cbpp, D}, {o->u_2, J.cu2, k2 * D},
         {o->z, J.cz, n * D}, {o->t_i_all, J.cT, rk * D}, {o->g_mat, J.cG, rr * D}, {o->h_mat, J.cH, rr * D}};
     for (auto& e : cp)   // results produced in place (device-resident caller buffers) need no copy
-      if (e.dst && e.dst != e.src) LAB_HIP(c, hipMemcpyAsync(e.dst, e.src, e.words * 8, hipMemcpyDefault, s));
+      if (e.dst && e.dst != e.src) LAB_HIPC(c, hipMemcpyAsync(e.dst, e.src, e.words * 8, hipMemcpyDefault, s));
   }
-  LAB_HIP(c, hipMemcpyAsync(hst, host_stage, hst_words * 8, hipMemcpyDeviceToHost, s));
-  LAB_HIP(c, hipStreamSynchronize(s));
+  LAB_HIPC(c, hipMemcpyAsync(hst, host_stage, hst_words * 8, hipMemcpyDeviceToHost, s));
+  LAB_HIPC(c, hipStreamSynchronize(s));
   if (a8d) {   // a witness above the declared norm bound: step 1 may have left the CRT range; redo the batch in the main basis
     const uint64_t* hnorm = hst + np * (256 + 256 + D);
     bool over = false;
     for (size_t j = 0; j < np; j++) over = over || hnorm[j] > norm_limit;
     if (over) {
-      const int e = prove_batch_impl(c, np, ins, outs, status, false);
+      // (a sub-batch that shares the scratch allocation with others leaves the redo to the driver: the main-basis run needs more
+      // workspace than its region, and the others are still using theirs)
+      if (!own_scratch) co_return REDO_IN_MAIN_BASIS;
+      ProveTask redo = prove_batch_co(c, np, ins, outs, status, false, nullptr, true, 0, nullptr);
+      const int e = redo.done() ? redo.rc() : fail(c, LAB_ERR_HIP, "lab_prove_core: internal: the main-basis run did not finish");
       c->prove_flags |= 2;
-      return e;
+      co_return e;
     }
   }
   c->prove_flags = a8d ? 1 : 0;
@@ -649,7 +697,97 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     if (status) status[j] = stj;
     if (stj != LAB_OK && first_fail == LAB_OK) first_fail = stj;
   }
-  return status ? LAB_OK : first_fail;
+  co_return status ? LAB_OK : first_fail;
+}
+
+static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const* ins, lab_transcript* const* outs, int* status,
+                            bool allow_digit_ajtai) {
+  if (!c) return LAB_ERR_ARG;
+  if (np == 0) return LAB_OK;
+  PtrCacheScope ptr_cache;
+  if (np <= (size_t)MAX_JOBS) {
+    ProveTask t = prove_batch_co(c, np, ins, outs, status, allow_digit_ajtai, nullptr, true, 0, nullptr);
+    return t.done() ? t.rc() : fail(c, LAB_ERR_HIP, "lab_prove_core: internal: the call did not finish");
+  }
+  const size_t nsub = (np + MAX_JOBS - 1) / MAX_JOBS;
+  auto sub_np = [&](size_t k) { return k + 1 < nsub ? (size_t)MAX_JOBS : np - k * MAX_JOBS; };
+  const lab_prove_input* in = ins ? ins[0] : nullptr;
+  const bool shared = in && !in->B8 && !in->B && in->crs_seed && (in->C || in->C8) && nsub <= (size_t)CRS_MAX_GROUPS;
+  if (!shared) {   // B resident: every sub-batch streams it from HBM itself
+    int first = LAB_OK;
+    for (size_t k = 0; k < nsub; k++) {
+      const size_t j0 = k * MAX_JOBS;
+      ProveTask t = prove_batch_co(c, sub_np(k), ins + j0, outs + j0, status ? status + j0 : nullptr, allow_digit_ajtai, nullptr, true, 0, nullptr);
+      const int e = t.done() ? t.rc() : LAB_ERR_HIP;
+      if (e != LAB_OK && first == LAB_OK) first = e;
+      if (e != LAB_OK && e != LAB_ERR_JL_REJECTED && e != LAB_ERR_BPP_CHECK) return e;
+    }
+    return first;
+  }
+  // ---- B streamed: one pass over the regenerated rows for all sub-batches
+  std::vector<size_t> off(nsub + 1, 0);
+  for (size_t k = 0; k < nsub; k++) {
+    const size_t j0 = k * MAX_JOBS;
+    size_t need = 0;
+    ProveTask t = prove_batch_co(c, sub_np(k), ins + j0, outs + j0, nullptr, allow_digit_ajtai, nullptr, false, 0, &need);
+    if (!t.done() || t.rc() != LAB_OK) return t.done() ? t.rc() : LAB_ERR_HIP;
+    off[k + 1] = off[k] + ((need + 255) & ~(size_t)255);
+  }
+  int rc = ensure_scratch(c, off[nsub]);
+  if (rc) return rc;
+  ProveShared sh;
+  sh.groups.reserve(nsub);
+  std::vector<ProveTask> tasks;
+  tasks.reserve(nsub);
+  for (size_t k = 0; k < nsub; k++) {   // steps 1-2 of every sub-batch
+    const size_t j0 = k * MAX_JOBS;
+    tasks.emplace_back(prove_batch_co(c, sub_np(k), ins + j0, outs + j0, status ? status + j0 : nullptr, allow_digit_ajtai, &sh, false, off[k], nullptr));
+    if (tasks.back().done()) {           // failed before step 3: let the suspended ones leave
+      sh.rc = tasks.back().rc() != LAB_OK ? tasks.back().rc() : LAB_ERR_ARG;
+      for (size_t i = 0; i + 1 < tasks.size(); i++) tasks[i].resume();
+      return sh.rc;
+    }
+  }
+  {
+    const size_t r = in->r, kappa = in->kappa, k1 = in->kappa1, nmat = r * (size_t)in->t1, pairs = r * (r + 1) / 2;
+    std::vector<uint64_t> offs(2 * nmat);
+    for (size_t m = 0; m < nmat; m++) {   // CRS::fetch_B_ik_row (src/structs.rs:78-82), as in the body
+      const u128 o = (u128)kappa * in->n * D + (u128)m * k1 * kappa;
+      offs[2 * m] = (uint64_t)o; offs[2 * m + 1] = (uint64_t)(o >> 64);
+    }
+    int ns_max = 8;
+    for (const CrsGroup& g : sh.groups) ns_max = g.ns > ns_max ? g.ns : ns_max;
+    CrsStream* cs = nullptr;
+    rc = crs_stream_create(c, in->C ? in->C->basis : mat8_basis(in->C8), nmat, k1, kappa, ns_max, &cs, (uint64_t)pairs * in->t2, sh.groups.size());
+    if (rc == LAB_OK) {
+      rc = crs_stream_run(cs, in->crs_seed, offs.data(), nmat, sh.groups.data(), sh.groups.size());
+      if (rc == LAB_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, LAB_ERR_HIP, "lab_prove_core: streamed outer commitment failed");
+      crs_stream_destroy(cs);
+    }
+    sh.rc = rc;
+  }
+  int first = LAB_OK, flags = 0;
+  std::vector<size_t> redo;
+  for (size_t k = 0; k < nsub; k++) {     // steps 4-10 of every sub-batch
+    tasks[k].resume();
+    const int e = tasks[k].done() ? tasks[k].rc() : LAB_ERR_HIP;
+    if (e == REDO_IN_MAIN_BASIS) { redo.push_back(k); continue; }
+    flags |= c->prove_flags;
+    if (e != LAB_OK && first == LAB_OK) first = e;
+  }
+  tasks.clear();
+  // a sub-batch with a witness above its norm bound: once more on the main-basis kernels, alone (B regenerated for it alone), now
+  // that nobody else holds a region of the scratch allocation
+  for (size_t k : redo) {
+    if (sh.rc) break;
+    const size_t j0 = k * MAX_JOBS;
+    ProveTask t = prove_batch_co(c, sub_np(k), ins + j0, outs + j0, status ? status + j0 : nullptr, false, nullptr, true, 0, nullptr);
+    const int e = t.done() ? t.rc() : LAB_ERR_HIP;
+    flags |= 2;
+    if (e != LAB_OK && first == LAB_OK) first = e;
+  }
+  c->prove_flags = flags;
+  return sh.rc ? sh.rc : first;
 }
 
 extern "C" int lab_prove_core(lab_ctx* c, const lab_prove_input* in, lab_transcript* out) {

@@ -96,11 +96,12 @@ class ResidentCRS:
         self.A.load(A); self.B.load(B); self.C.load(Cm); self.Dm.load(Dm)
         return self
 
-    def pack_mfma(self, drop_B=False, main_basis_A=True):
+    def pack_mfma(self, drop_B=False, main_basis_A=True, drop_CD=False):
         """Re-stores the B matrices for the matrix cores (lab_mat8_pack): step 3 of prove_core[_batch] then runs as exact
         int8 GEMMs over up to 64 proofs per pass over B.  drop_B=True frees the original B (the verifier and
         single-proof VALU path need it; a prover-only service does not).  main_basis_A=False skips A8 (12 bytes per
-        coefficient of A): step 1 then has the digit-basis A8d, and the multiply-add kernel for a witness above its norm bound."""
+        coefficient of A): step 1 then has the digit-basis A8d, and the multiply-add kernel for a witness above its norm bound.
+        drop_CD=True frees C and Dm after packing them (prover-only, like drop_B)."""
         from .api import Mat8
         k = self.constants
         self.B8 = Mat8(self.ctx, self.B, k.R * k.T_1, k.KAPPA_1, k.KAPPA) if self.B is not None else None
@@ -125,6 +126,10 @@ class ResidentCRS:
             self.ctx.synchronize()
             self.B.close()
             self.B = None
+        if drop_CD:      # the prover reads C8 / D8 only (the verifier needs the residues): 46 GB at kappa = 2^14
+            self.ctx.synchronize()
+            self.C.close(); self.Dm.close()
+            self.C = self.Dm = None
         return self
 
     def close(self):
@@ -318,7 +323,8 @@ def _io_template(k, crs):
     pin.struct_size = C.sizeof(_lib.lab_prove_input)
     pin.n, pin.r, pin.kappa, pin.kappa1, pin.kappa2 = k.N, k.R, k.KAPPA, k.KAPPA_1, k.KAPPA_2
     pin.b1, pin.b2, pin.t1, pin.t2, pin.beta_bound = k.B_1, k.B_2, k.T_1, k.T_2, k.BETA_BOUND
-    pin.A, pin.B, pin.C, pin.Dm = crs.A._h, (crs.B._h if crs.B is not None else None), crs.C._h, crs.Dm._h
+    pin.A, pin.B = crs.A._h, (crs.B._h if crs.B is not None else None)
+    pin.C, pin.Dm = (crs.C._h if crs.C is not None else None), (crs.Dm._h if crs.Dm is not None else None)
     for name in ("B8", "A8", "C8", "D8", "A8d"):
         m = getattr(crs, name, None)
         setattr(pin, name, m._h if m is not None else None)
@@ -515,7 +521,8 @@ def verify_core(ctx, k, st, b_poly, crs, T, tape=None):
     pin.S = None
     pin.phi, pin.a = p64(st.phi), p64(st.a)
     pin.b_prime = st.b_prime
-    pin.A, pin.B, pin.C, pin.Dm = crs.A._h, (crs.B._h if crs.B is not None else None), crs.C._h, crs.Dm._h
+    pin.A, pin.B = crs.A._h, (crs.B._h if crs.B is not None else None)
+    pin.C, pin.Dm = (crs.C._h if crs.C is not None else None), (crs.Dm._h if crs.Dm is not None else None)
     pin.B8 = crs.B8._h if getattr(crs, "B8", None) is not None else None
     pin.A8 = crs.A8._h if getattr(crs, "A8", None) is not None else None
     pin.C8 = crs.C8._h if getattr(crs, "C8", None) is not None else None

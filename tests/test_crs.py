@@ -218,7 +218,9 @@ def test_streamed_crs_matvec_equals_materialise_then_multiply(mfma_basis, nmat, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nproofs", [1, 3])
+# 70 and 130 proofs: more than one call's 64 — the sub-batches run steps 1-2, suspend, share ONE pass over the regenerated rows
+# (one group of vector sets each: 64 + 6, 64 + 64 + 2) and resume for steps 4-10
+@pytest.mark.parametrize("nproofs", [1, 3, 70, 130])
 def test_prover_with_B_streamed_from_the_seed(nproofs):
     # lab_prove_input.crs_seed with B == B8 == NULL: step 3 regenerates the B_ik rows from the seed inside the call
     # (fetch_B_ik_row's literal offsets) — same transcripts as with the materialised CRS, and as the oracle on its own
@@ -335,8 +337,7 @@ def test_streamed_crs_matvec_with_k_chunks(basis, nmat, rows, cols, ns):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nproofs", [2, 9])
-@pytest.mark.parametrize("chunk_basis", [False, True])
+@pytest.mark.parametrize("nproofs,chunk_basis", [(2, False), (9, False), (2, True), (9, True), (67, True)])
 def test_prover_streamed_with_k_chunks(nproofs, chunk_basis):
     # the streamed prover in the configuration of the kappa = 2^14 bench run, scaled down in kappa1 only: kappa = 16384 columns
     # per B_ik (MC = 7 matrices per K chunk, r*t1 = 9 matrices -> two chunks), A8d in the basis of the CRS.
@@ -362,7 +363,9 @@ def test_prover_streamed_with_k_chunks(nproofs, chunk_basis):
         ctx = ref
     streamed = lab.CRS(ctx, k, base).materialize(mfma_basis=True, stream_B=True)
     assert len(ctx.digit_primes) == (3 if chunk_basis else 4)
-    streamed.pack_mfma(main_basis_A=not chunk_basis)              # A8d, C8, D8 in the CRS basis; B stays a seed
+    # A8d, C8, D8 in the CRS basis; B stays a seed; in the bench's configuration no main-basis A8 and no C / D residues either
+    streamed.pack_mfma(main_basis_A=not chunk_basis, drop_CD=chunk_basis)
+    assert (streamed.C is None) == chunk_basis
     assert streamed.B is None and getattr(streamed, "B8", None) is None and streamed.A8d.nbytes > 0
     ws, sts, tapes = [], [], []
     for j in range(nproofs):
@@ -399,7 +402,9 @@ def test_prover_streamed_with_k_chunks(nproofs, chunk_basis):
     bad = [sts[0], lab.State(sts[1].phi, sts[1].a, 0)] + sts[2:]
     want2, codes_ref = lab.prove_core_batch(ref, k, big, bad, full, tapes, raise_on_reject=False)
     got2, codes = lab.prove_core_batch(ctx, k, big, bad, streamed, tapes, raise_on_reject=False)
-    assert ctx.prove_flags() == 2 and list(codes) == list(codes_ref)
+    # (more than 64 proofs: the sub-batch with the big witness is redone in place — flag 2 — while the other one keeps its
+    # digit-basis run — flag 1: the call reports both)
+    assert ctx.prove_flags() == (2 if nproofs <= 64 else 3) and list(codes) == list(codes_ref)
     for j in range(nproofs):
         for f in ("t_i_all", "g_mat", "h_mat", "u_1", "u_2", "z"):
             assert np.array_equal(getattr(got2[j], f), getattr(want2[j], f)), (j, f)
