@@ -354,7 +354,7 @@ def host_chacha_rate(q, seconds=4.0):
     return cores * reps * n0 / dt, cores, dt
 
 
-def config3_streamed(lab, dev, q, n, r, kappa, inputs, b1_s_per_proof_k1024=None, with_cpu=True, proofs=(160, 128, 96, 64)):
+def config3_streamed(lab, dev, q, n, r, kappa, inputs, b1_s_per_proof_k1024=None, with_cpu=True, proofs=(192, 160, 128, 96, 64)):
     """SURVEY section 8(d) config 3 at the contract's commitment rank: kappa = kappa1 = kappa2 = 2^14 (the floor BASELINE.md names;
     the reference hard-wires n*d = 2^16, src/constants.rs:237-239).  One B_ik is 2^28 ring elements, the 96 of them 6 TiB as byte
     planes: B is STREAMED — regenerated from the ChaCha20 seed inside the step (CRS::fetch_B_ik_row, src/structs.rs:74-88,

@@ -207,7 +207,7 @@ struct MfmaGramOut { uint32_t* out; size_t plane_stride, job_stride, r; bool don
 int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_mat8* m, ConstHatView V, size_t v_set_stride, int ns,
                      int ns_valid, void* scratch, size_t v_k_stride, size_t njobs, size_t out_job_stride, size_t v_job_stride,
                      bool timed = false, MfmaCoefOut* coef = nullptr, const int8_t* prepacked = nullptr,
-                     MfmaGramOut* gram = nullptr, int8_t* keep_tiles = nullptr);
+                     MfmaGramOut* gram = nullptr, int8_t* keep_tiles = nullptr, size_t keep_limb_stride = 0);
 // X_a = P_a^T S per proof on the matrix cores (mfma_api.hip): P_a as [n][r] coefficient matrices, the witness as the tiles
 // matvec_mfma_impl(keep_tiles) made of it for the Ajtai product
 bool gram_mfma_ok(const lab_mat8* m, size_t n, size_t r);

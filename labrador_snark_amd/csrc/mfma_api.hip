@@ -128,7 +128,7 @@ int gram_mfma_impl(lab_ctx* c, const lab_mat8* m, int nops, const HatView* outs,
 // limbs are bracketed by events.
 int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_mat8* m, ConstHatView V, size_t v_set_stride, int ns,
                      int ns_valid, void* scratch, size_t v_k_stride, size_t njobs, size_t out_job_stride, size_t v_job_stride,
-                     bool timed, MfmaCoefOut* coef, const int8_t* prepacked, MfmaGramOut* gram, int8_t* keep_tiles) {
+                     bool timed, MfmaCoefOut* coef, const int8_t* prepacked, MfmaGramOut* gram, int8_t* keep_tiles, size_t keep_limb_stride) {
   const uint32_t* primes = m->basis ? c->dg_primes : c->primes;
   const size_t ktotal = m->nmat * m->cols;
   // Many 32-set jobs sharing the matrix (the Ajtai product of a batch): two source jobs are multiplied as ONE 64-set job,
@@ -152,7 +152,8 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
   for (int l = 0; l < m->nlimbs; l++) {
     const int pl = m->planes[l];
     const size_t nt = nt_for(ns, pl);
-    if (keep_tiles) v8 = keep_tiles + (size_t)l * v8_stride * njobs;    // the caller wants the tiles of every limb afterwards
+    // the caller wants the tiles of every limb afterwards (keep_limb_stride: this call packs a slice of the jobs of a larger array)
+    if (keep_tiles) v8 = keep_tiles + (size_t)l * (keep_limb_stride ? keep_limb_stride : v8_stride * njobs);
     if (prepacked) v8 = const_cast<int8_t*>(prepacked) + (size_t)l * v8_stride * njobs;   // digits_to_v8_impl made every limb's tiles
     else
       LAB_HIP(c, launch_pack_vectors_i8(ns, ns_valid, v8, V.base + (size_t)l * V.plane_stride, v_set_stride, v_k_stride, ktotal,

@@ -252,10 +252,16 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
   const LimbTable* tabsd = basis_tabs(c, bdig);
   const size_t per = ha.total, perd = hd.total;
   const size_t hat_words = np * per * D, hatd_words = np * perd * D;
-  size_t tmp_elems = rk;
-  if (nr > tmp_elems) tmp_elems = nr;
-  if (k1 > tmp_elems) tmp_elems = k1;
-  if (rr > tmp_elems) tmp_elems = rr;
+  size_t tmp_small = nr;
+  if (k1 > tmp_small) tmp_small = k1;
+  if (rr > tmp_small) tmp_small = rr;
+  // The chain t = A S -> inverse transform -> CRT runs `t_chunk` proofs at a time when the dense inverse-transform output of all
+  // proofs at once would be large (0.4 GB per proof at kappa = 2^14: with it, fewer proofs fit one streamed pass over B)
+  const size_t Lmax = (size_t)(c->nlimbs > basis_nlimbs(c, bdig) ? c->nlimbs : basis_nlimbs(c, bdig));
+  size_t t_chunk = np;
+  if (t_coef_only && a8d && r <= 32 && in->b1 <= 65536 && in->b2 <= 65536)   // (the slices finish with the CRT pass that writes 16-bit digits)
+    while (t_chunk % 4 == 0 && t_chunk > 16 && t_chunk * Lmax * rk * D * 4 > ((size_t)6 << 30)) t_chunk /= 2;
+  const size_t tmp_elems = t_coef_only ? tmp_small : (rk > tmp_small ? rk : tmp_small);   // from_hat scratch per job
 
   // decomposition digits travel between k_decompose / the CRT pass and the transforms as 16-bit words when both bases allow it
   const bool dig16 = in->b1 <= 65536 && in->b2 <= 65536;
@@ -264,8 +270,10 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
                             nr /*cW*/ + rr /*capp*/ + 2 * rr /*cX1, cX2*/ + rr /*cX*/ + rr /*cH*/ +
                             pairs /*cHup*/ + pairs * t1 /*cHdec*/ + k1 /*cu1*/ + k2 /*cu2*/ + n /*cz*/ + 1 /*cbpp*/ +
                             2 /*cab*/;
+  size_t dense_words = np * Lmax * tmp_elems * D;
+  if (t_coef_only && t_chunk * Lmax * rk * D > dense_words) dense_words = t_chunk * Lmax * rk * D;
   size_t bytes = Carver::padded((size_t)L * hat_words * 4) + Carver::padded((size_t)Ld * hatd_words * 4) +
-                 Carver::padded(np * (size_t)(L > Ld ? L : Ld) * tmp_elems * D * 4) +
+                 Carver::padded(dense_words * 4) +
                  np * (coef_elems * (D * 8) + 32 * 256 /*alignment padding of the carves*/ + 3 * 4096 /*proj*/);
   for (size_t j = 0; j < np; j++) {   // t produced in place in a device-resident caller buffer needs no copy here (268 MB per proof at kappa = 2^14)
     if (outs[j]->t_i_all && is_device_pointer(outs[j]->t_i_all)) bytes -= rk * (size_t)(D * 8);
@@ -285,7 +293,7 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
   if (fuse_t && b8 && mfma_prepacked_bytes(b8, mf_ns) + 4096 > mf_bytes) mf_bytes = mfma_prepacked_bytes(b8, mf_ns) + 4096;
   const int a8_ns = r <= 8 ? 8 : r <= 16 ? 16 : 32;       // witness columns per Ajtai GEMM pass
   if (a8 && mfma_scratch_bytes(a8, a8_ns, np) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(a8, a8_ns, np) + 4096;
-  if (a8d && mfma_scratch_bytes(a8d, a8_ns, np) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(a8d, a8_ns, np) + 4096;
+  if (a8d && mfma_scratch_bytes(a8d, a8_ns, t_chunk) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(a8d, a8_ns, t_chunk) + 4096;
   if (sd_only && gram_mfma_scratch_bytes(a8d, np) + 4096 > mf_bytes) mf_bytes = gram_mfma_scratch_bytes(a8d, np) + 4096;
   const size_t stile_bytes = sd_only ? gram_mfma_tile_bytes(a8d, np) + 4096 : 0;   // the witness tiles of every limb, kept from step 1 to step 7
   bytes += stile_bytes;
@@ -300,7 +308,7 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
   uint32_t* hat_base = cv.take<uint32_t>((size_t)L * hat_words);
   uint32_t* hatd_base = cv.take<uint32_t>((size_t)Ld * hatd_words);
   // from_hat scratch: a dense [L][count][64] buffer (its plane stride is count*64, not the arena's)
-  uint32_t* dense_tmp = cv.take<uint32_t>(np * (size_t)(L > Ld ? L : Ld) * tmp_elems * D);   // job j: + j * max(L, Ld)*tmp_elems*64 words
+  uint32_t* dense_tmp = cv.take<uint32_t>(dense_words);   // job j: + j * max(L, Ld)*tmp_elems*64 words (the t chain: + j * max(L, Ld)*rk*64)
   auto HV = [&](size_t j, size_t off) { return HatView{hat_base + (j * per + off) * D, hat_words}; };
   auto HD = [&](size_t j, size_t off) { return HatView{hatd_base + (j * perd + off) * D, hatd_words}; };
   auto CO = [&](size_t elems) { return cv.take<uint64_t>(elems * D); };
@@ -340,7 +348,8 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
   // Every per-proof kernel below is launched ONCE for all np proofs (a "job" grid dimension): transform-domain operands
   // are addressed with the arena's job stride, coefficient arrays through per-job pointers passed by value.
   const size_t js = per * D, jsd = perd * D;                       // job strides (words inside a plane) of the two arenas
-  const size_t tmp_js = (size_t)(L > Ld ? L : Ld) * tmp_elems * D;   // per-job slice of the from_hat scratch
+  const size_t tmp_js = Lmax * tmp_elems * D;   // per-job slice of the from_hat scratch
+  const size_t tmp_js_t = Lmax * rk * D;        // ... of the t chain (t_chunk jobs at a time)
   auto JP = [&](auto member) {
     JobPtrs t;
     for (size_t j = 0; j < np; j++) t.p[j] = const_cast<void*>(static_cast<const void*>(jobs[j].*member));
@@ -401,20 +410,38 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
     // (coefficients above beta_bound are caught by the norm sum and the batch is redone: the transform may assume the bound)
     LAB_HIPC(c, launch_to_hat_fused(JP(&Job::dS), HD(0, hSd), jsd, nr, Ld, tabsd, np, s, (uint64_t)in->beta_bound + 1,
                                    reinterpret_cast<unsigned long long*>(norm_sums), norm_limit, false, above16));
-    for (size_t i0 = 0; i0 < r; i0 += 32) {
-      const int valid = (int)(r - i0 < 32 ? r - i0 : 32);
-      MfmaCoefOut co{dense_tmp + i0 * kappa * D, rk * D, tmp_js, kappa, false};   // t is only wanted as coefficients
-      MfmaGramOut go{HD(0, hGd).base, hatd_words, perd * D, r, false};            // step 2 (G = S^T S) from the same tiles
-      if ((rc = matvec_mfma_impl(c, HD(0, hTd + i0 * kappa), kappa * D, a8d, HD(0, hSd + i0), D, a8_ns, valid, mf_scratch, r * D, np,
-                                 perd * D, perd * D, false, &co, nullptr, r <= 32 ? &go : nullptr, s_tiles))) co_return rc;
-      t_in_dense = co.done;
-      g_in_digit = go.done;
+    // the witness tiles of every limb are kept for steps 6-8 as one array over all proofs of the call: [limb][job]
+    const bool tiles_paired = np >= 2 && np % 2 == 0 && a8_ns == 32;
+    const size_t tile_jobs = tiles_paired ? np / 2 : np;
+    const size_t tile_job_bytes = s_tiles ? gram_mfma_tile_bytes(a8d, np) / ((size_t)Ld * tile_jobs) : 0;
+    for (size_t jb = 0; jb < np; jb += t_chunk) {       // t_chunk proofs at a time (all of them unless the dense output would be large)
+      for (size_t i0 = 0; i0 < r; i0 += 32) {
+        const int valid = (int)(r - i0 < 32 ? r - i0 : 32);
+        MfmaCoefOut co{dense_tmp + i0 * kappa * D, rk * D, tmp_js_t, kappa, false};   // t is only wanted as coefficients
+        MfmaGramOut go{HD(jb, hGd).base, hatd_words, perd * D, r, false};            // step 2 (G = S^T S) from the same tiles
+        int8_t* keep = s_tiles ? s_tiles + (jb / (tiles_paired ? 2 : 1)) * tile_job_bytes : nullptr;
+        if ((rc = matvec_mfma_impl(c, HD(jb, hTd + i0 * kappa), kappa * D, a8d, HD(jb, hSd + i0), D, a8_ns, valid, mf_scratch, r * D, t_chunk,
+                                   perd * D, perd * D, false, &co, nullptr, r <= 32 ? &go : nullptr, keep, tile_job_bytes * tile_jobs))) co_return rc;
+        t_in_dense = co.done;
+        g_in_digit = go.done;
+      }
+      if (t_chunk < np) {   // a slice of the proofs: its CRT (with the digits of t) before the next slice reuses the dense array
+        if (!t_in_dense || !dig16) co_return fail(c, LAB_ERR_ARG, "lab_prove_core: internal: sliced t chain without the dense path");
+        JobPtrs pt, pd;
+        for (size_t i = 0; i < (size_t)MAX_JOBS; i++) {
+          pt.p[i] = i < t_chunk ? jobs[jb + i].cT : nullptr;
+          pd.p[i] = i < t_chunk ? jobs[jb + i].cTdec : nullptr;
+        }
+        CrtDigits dg{pd, (uint32_t)in->b1, t1, kappa, q};
+        LAB_HIPC(c, launch_crt_to_u64_jobs(HatView{dense_tmp, rk * D}, tmp_js_t, pt, rk, basis_crt(c, bdig), Ld, t_chunk, s, &dg));
+        t_digits_done = true;
+      }
     }
   } else if (a8) {   // matrix cores: per proof, its r witness columns as the vector sets (element x of column i at S[x][i])
     // one launch per limb and 32 columns: the proofs are the kernel's jobs and share the A stream through L2
     for (size_t i0 = 0; i0 < r; i0 += 32) {
       const int valid = (int)(r - i0 < 32 ? r - i0 : 32);
-      MfmaCoefOut co{dense_tmp + i0 * kappa * D, rk * D, tmp_js, kappa, false};
+      MfmaCoefOut co{dense_tmp + i0 * kappa * D, rk * D, tmp_js_t, kappa, false};
       if ((rc = matvec_mfma_impl(c, HV(0, hT + i0 * kappa), kappa * D, a8, HV(0, hS + i0), D, a8_ns, valid, mf_scratch, r * D, np,
                                  per * D, per * D, false, &co))) co_return rc;
       t_in_dense = co.done;
@@ -429,16 +456,18 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
       LAB_HIPC(c, e);
     }
   }
-  if (t_in_dense) {   // the inverse transform already ran from the GEMM's staging array: only the CRT is left
+  if (t_in_dense && t_chunk < np) {
+    // (every slice was finished above)
+  } else if (t_in_dense) {   // the inverse transform already ran from the GEMM's staging array: only the CRT is left
     const int basis = a8d ? bdig : 0;
     // ... and the decomposition of t (its digits in [i][k][rho] order), in the same pass when they have the 16-bit form
     CrtDigits dg{JP(&Job::cTdec), (uint32_t)in->b1, t1, kappa, q};
-    hipError_t e = dig16 ? launch_crt_to_u64_jobs(HatView{dense_tmp, rk * D}, tmp_js, JP(&Job::cT), rk, basis_crt(c, basis),
+    hipError_t e = dig16 ? launch_crt_to_u64_jobs(HatView{dense_tmp, rk * D}, tmp_js_t, JP(&Job::cT), rk, basis_crt(c, basis),
                                                   basis_nlimbs(c, basis), np, s, &dg)
                          : hipErrorNotSupported;
     if (e == hipSuccess) t_digits_done = true;
     else if (e == hipErrorNotSupported)
-      LAB_HIPC(c, launch_crt_to_u64_jobs(HatView{dense_tmp, rk * D}, tmp_js, JP(&Job::cT), rk, basis_crt(c, basis), basis_nlimbs(c, basis), np, s));
+      LAB_HIPC(c, launch_crt_to_u64_jobs(HatView{dense_tmp, rk * D}, tmp_js_t, JP(&Job::cT), rk, basis_crt(c, basis), basis_nlimbs(c, basis), np, s));
     else LAB_HIPC(c, e);
   } else if ((rc = a8d ? from_hat_jobs(hTd, rk, JP(&Job::cT), true) : from_hat_jobs(hT, rk, JP(&Job::cT), false))) {
     co_return rc;

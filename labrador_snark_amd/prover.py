@@ -104,7 +104,10 @@ class ResidentCRS:
         drop_CD=True frees C and Dm after packing them (prover-only, like drop_B)."""
         from .api import Mat8
         k = self.constants
-        self.B8 = Mat8(self.ctx, self.B, k.R * k.T_1, k.KAPPA_1, k.KAPPA) if self.B is not None else None
+        # (sums longer than the int32 bound of one int8 GEMM stay on the multiply-add kernels when B is resident; streamed B is
+        # cut into K chunks instead)
+        fits = k.R * k.T_1 * k.KAPPA < (1 << 17) - 1
+        self.B8 = Mat8(self.ctx, self.B, k.R * k.T_1, k.KAPPA_1, k.KAPPA) if self.B is not None and fits else None
         # (a single-limb strict-32 context — q its own NTT prime in [2^30, 2^32) — has no main-basis matrix-core form: step 1
         # then has the digit-basis A8d or the multiply-add kernel)
         self.A8 = Mat8(self.ctx, self.A, 1, k.KAPPA, k.N) if main_basis_A and not self.ctx.wide else None

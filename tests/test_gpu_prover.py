@@ -365,6 +365,39 @@ def test_ajtai_product_on_persistent_blocks(nb, kappa):
     ctx.close()
 
 
+def test_t_chain_in_slices_of_the_batch():
+    # kappa = 8320, r = 32, 32 proofs: the dense inverse-transform output of t for all proofs at once would be 6.5 GB, so the chain
+    # Ajtai GEMM -> inverse transform -> CRT (+ digits) runs 16 proofs at a time (what keeps 160 proofs per streamed pass in memory at
+    # kappa = 2^14); the witness tiles of the slices land in one array for steps 6-8.  Every field of every proof == the
+    # multiply-add path on unpacked matrices; entries of t and G == the oracle.
+    import labrador_snark_amd as lab
+    from oracle import coracle as co
+    q, n, r, kappa, kappa1, nb = Q_REF33, 2, 32, 8320, 2, 32
+    ctx = lab.Context(q, 0)
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
+    crs = lab.ResidentCRS(ctx, k, mfma_basis=True).fill_synthetic(1000)
+    ws, sts, tapes = [], [], []
+    for j in range(nb):
+        S, phi, a, tape = cases.make_inputs(p, seed=3100 + j)
+        ws.append(S); tapes.append(tape)
+        sts.append(lab.State(phi, a, int(lab.gen_f_b(ctx, S, phi, a, n, r)[0])))
+    ref, c_ref = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes, raise_on_reject=False)
+    crs.pack_mfma(main_basis_A=False)
+    got, c_got = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes, raise_on_reject=False)
+    assert ctx.prove_flags() == 1 and c_ref == c_got
+    for j in range(nb):
+        for f in ("t_i_all", "g_mat", "h_mat", "u_1", "u_2", "z", "b_prime_prime", "projection_int"):
+            assert np.array_equal(getattr(got[j], f), getattr(ref[j], f)), (j, f)
+    A = co.synth_fill(1000, 0, kappa * n * D, q).reshape(kappa, n, D)
+    for j, i, row in ((0, 0, 0), (15, 31, kappa - 1), (16, 7, 4097), (31, 31, 8319)):
+        assert np.array_equal(got[j].t_i_all[i, row], co.inner_product(q, A[row], ws[j][:, i])), (j, i, row)
+    for j, i, kk in ((0, 0, 0), (17, 5, 31), (31, 31, 31)):
+        assert np.array_equal(got[j].g_mat[i, kk], co.inner_product(q, ws[j][:, i], ws[j][:, kk])), (j, i, kk)
+    crs.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("mfma_basis", [False, True])
 @pytest.mark.parametrize("nb", [2, 4, 5])
 def test_prove_core_batch_matrix_cores_r32(nb, mfma_basis):
