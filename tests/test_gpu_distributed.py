@@ -67,3 +67,30 @@ def test_ik_sharded_outer_commitment_two_ranks_one_gpu(use_mfma, ns):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, (1 << 32) + 15, 3, 3, 40, 96, ns, use_mfma, ret), nprocs=world, join=True)
     assert ret["ok"] is True
+
+
+def test_bench_line_of_two_ranks_and_of_one_without_extras():
+    # bench.py itself with N = 2 (its own launcher, two ranks sharing this box's GPU over gloo — on the 8-GPU node the same code
+    # runs over RCCL): rank 0 prints exactly ONE JSON line whose collective really saw both ranks and summed the folded commitment
+    # vectors; and the single-rank line without extras (a run that once printed nothing).  Small shapes: kappa = 256, 8 proofs.
+    import json
+    import subprocess
+    common = ["--batch", "8", "--kappa", "256", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+    env = dict(os.environ, LAB_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    recs = {}
+    for n in (1, 2):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + common, env=env, capture_output=True,
+                             text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        recs[n] = json.loads(lines[0])
+    one, two = recs[1], recs[2]
+    assert one["n_gpus"] == 1 and one["ranks_seen"] == 1 and one["collective_backend"] is None
+    assert two["n_gpus"] == 2 and two["ranks_seen"] == 2 and two["collective_backend"] == "gloo" and two["scaling"] == "weak"
+    assert len(two["aggregate_commitment_vector"]) == 128 and two["value"] > 0 and two["steps"] == 2
+    # rank 0 proves the same instances in both runs (seeds 50..57): its share of the summed vector is the single-rank vector
+    assert all(a >= b for a, b in zip(two["aggregate_commitment_vector"], one["aggregate_commitment_vector"]))
+    assert two["aggregate_commitment_vector"] != one["aggregate_commitment_vector"]

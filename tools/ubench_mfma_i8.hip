@@ -50,7 +50,10 @@ __global__ void k_fill(uint32_t* p, size_t n) {
 // 4: twice that)
 // HOT: the streamed operands come from a 1-MiB region every wave shares (L2 hits, like the A tiles of the Ajtai product that 32
 // jobs share) and every group's second MFMA takes its B operand from LDS (one ds_read_b128 per 3 MFMAs, the product kernels' ratio)
-template <int MODE, bool ZERO, bool HOT = false>
+// MIX (with HOT): every other streamed operand comes from the wave's own HBM region, the others from the shared hot region — the
+// traffic of a step-3 launch that multiplies 128 sets per pass over B: half of a wave's A operands are HBM misses (85 B per MFMA),
+// the other half were just fetched by the wave that shares its row tile (L2 hits), and a B fragment from LDS feeds 3 MFMAs
+template <int MODE, bool ZERO, bool HOT = false, bool MIX = false>
 __global__ void __launch_bounds__(256) k_mfma(uint64_t* __restrict__ stamps, int* __restrict__ sink, const v4i* __restrict__ stream,
                                               size_t stream_words_per_wave, int iters, uint32_t seed) {
   __shared__ v4i lds[HOT ? 256 * 4 : 1];
@@ -75,6 +78,9 @@ __global__ void __launch_bounds__(256) k_mfma(uint64_t* __restrict__ stamps, int
   for (int n = 0; n < NACC; n++)
 #pragma unroll
     for (int j = 0; j < 16; j++) acc[n][j] = 0;
+  const size_t cold_words = stream_words_per_wave;
+  const v4i* cold = stream + (size_t)wave * cold_words + lane;   // MIX: this wave's own region
+  size_t cpos = 0;
   if (HOT) stream_words_per_wave = 4096;   // 64 KiB per wave slot, 16 slots: 1 MiB shared by all waves
   const v4i* src = stream + (size_t)(HOT ? wave % 16 : wave) * stream_words_per_wave + lane;
   // MODE 1: 16 one-KiB wave loads in flight (the product kernel keeps 72 KB per CU = 18 KB per wave in flight): a load is used 48
@@ -99,9 +105,15 @@ __global__ void __launch_bounds__(256) k_mfma(uint64_t* __restrict__ stamps, int
           const int slot = tt * LPT + g / (4 / LPT);
           WAIT_OLDEST_OF_16(ring[slot]);
           bs = ring[slot];
-          GLOAD(ring[slot], src + pos);
-          pos += 64;
-          if (pos + 64 > stream_words_per_wave) pos = 0;
+          if (MIX && slot % 2 == 0) {
+            GLOAD(ring[slot], cold + cpos);
+            cpos += 64;
+            if (cpos + 64 > cold_words) cpos = 4096 * 16 / 16;   // stay clear of the hot region at the start of the buffer
+          } else {
+            GLOAD(ring[slot], src + pos);
+            pos += 64;
+            if (pos + 64 > stream_words_per_wave) pos = 0;
+          }
         }
         acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[g % NOPS], bs, acc[0], 0, 0, 0);
         v4i bl = b[(g + 1) % NOPS];
@@ -133,16 +145,16 @@ __global__ void __launch_bounds__(256) k_mfma(uint64_t* __restrict__ stamps, int
 
 struct Result { double ms, pops, shader_ghz, busy; };
 
-template <int MODE, bool ZERO, bool HOT = false>
+template <int MODE, bool ZERO, bool HOT = false, bool MIX = false>
 static int run(int blocks, int iters, uint64_t* dstamps, int* dsink, const v4i* dstream, size_t words_per_wave, Result* res) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
   const int waves = blocks * 4;
-  hipLaunchKernelGGL((k_mfma<MODE, ZERO, HOT>), dim3(blocks), dim3(256), 0, 0, dstamps, dsink, dstream, words_per_wave, iters / 8, 1u);   // warm-up
+  hipLaunchKernelGGL((k_mfma<MODE, ZERO, HOT, MIX>), dim3(blocks), dim3(256), 0, 0, dstamps, dsink, dstream, words_per_wave, iters / 8, 1u);   // warm-up
   CHECK(hipDeviceSynchronize());
   CHECK(hipEventRecord(e0));
-  hipLaunchKernelGGL((k_mfma<MODE, ZERO, HOT>), dim3(blocks), dim3(256), 0, 0, dstamps, dsink, dstream, words_per_wave, iters, 7u);
+  hipLaunchKernelGGL((k_mfma<MODE, ZERO, HOT, MIX>), dim3(blocks), dim3(256), 0, 0, dstamps, dsink, dstream, words_per_wave, iters, 7u);
   CHECK(hipEventRecord(e1));
   CHECK(hipDeviceSynchronize());
   float ms = 0;
@@ -180,7 +192,8 @@ int main(int argc, char** argv) {
       {"registers_zero_1_wave_per_simd", 256, 0, true},
       {"hbm_stream_171B_per_mfma_1_wave_per_simd", 256, 2, false}, {"hbm_stream_171B_per_mfma_2_waves_per_simd", 512, 2, false},
       {"hbm_stream_341B_per_mfma_1_wave_per_simd", 256, 4, false},
-      {"l2_hot_171B_per_mfma_plus_lds_operand_per_3_mfma_1_wave_per_simd", 256, 5, false}};
+      {"l2_hot_171B_per_mfma_plus_lds_operand_per_3_mfma_1_wave_per_simd", 256, 5, false},
+      {"hbm_85B_plus_l2_hot_85B_per_mfma_plus_lds_operand_per_3_mfma_1_wave_per_simd", 256, 6, false}};
   for (size_t i = 0; i < sizeof(cases) / sizeof(cases[0]); i++) {
     Result r{};
     int rc;
@@ -189,9 +202,10 @@ int main(int argc, char** argv) {
     else if (c.mode == 0) rc = run<0, true>(c.blocks, iters, dstamps, dsink, dstream, words_per_wave, &r);
     else if (c.mode == 2) rc = run<2, false>(c.blocks, iters, dstamps, dsink, dstream, words_per_wave, &r);
     else if (c.mode == 5) rc = run<2, false, true>(c.blocks, iters, dstamps, dsink, dstream, words_per_wave, &r);
+    else if (c.mode == 6) rc = run<2, false, true, true>(c.blocks, iters, dstamps, dsink, dstream, words_per_wave, &r);
     else rc = run<4, false>(c.blocks, iters, dstamps, dsink, dstream, words_per_wave, &r);
     if (rc) return rc;
-    const double stream_gbs = c.mode == 5 ? 0.0 : (double)c.blocks * 4 * ((double)c.mode * iters) * 1024.0 / (r.ms * 1e-3) / 1e9;
+    const double stream_gbs = c.mode == 5 ? 0.0 : (double)c.blocks * 4 * ((double)(c.mode == 6 ? 1 : c.mode) * iters) * 1024.0 / (r.ms * 1e-3) / 1e9;
     printf("  {\"case\": \"%s\", \"waves\": %d, \"ms\": %.3f, \"POPs\": %.3f, \"frac_of_datasheet\": %.3f, \"in_loop_shader_clock_GHz\": %.3f, "
            "\"matrix_pipe_busy\": %.3f, \"hbm_stream_GBps\": %.0f}%s\n",
            c.name, c.blocks * 4, r.ms, r.pops, r.pops / 5.0, r.shader_ghz, r.busy, stream_gbs, i + 1 < sizeof(cases) / sizeof(cases[0]) ? "," : "");
