@@ -204,10 +204,16 @@ struct MfmaCoefOut { uint32_t* dense; size_t plane_stride, job_stride, set_strid
 // G[i][k] = sum_x V_i[x] V_k[x] per source job from the packed tiles (transform domain, basis of m): element i*r + k of
 // gram->out + job * gram->job_stride, plane l at + l * gram->plane_stride; gram->done tells whether that happened
 struct MfmaGramOut { uint32_t* out; size_t plane_stride, job_stride, r; bool done; };
+// `jb`: the prepacked tiles of job b live in a buffer of their own at prepacked + b * job_stride (each laid out [limb] as
+// digits_to_v8_impl writes it for one job) and the slot-major staging array of the results is `stage`
+// (mfma_stage_bytes(m, ns, njobs)) — the groups of a streamed pass, whose tiles sit in their sub-batches' workspaces
+struct MfmaJobBuffers { size_t job_stride; uint32_t* stage; };
+size_t mfma_stage_bytes(const lab_mat8* m, int ns, size_t njobs);
 int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_mat8* m, ConstHatView V, size_t v_set_stride, int ns,
                      int ns_valid, void* scratch, size_t v_k_stride, size_t njobs, size_t out_job_stride, size_t v_job_stride,
                      bool timed = false, MfmaCoefOut* coef = nullptr, const int8_t* prepacked = nullptr,
-                     MfmaGramOut* gram = nullptr, int8_t* keep_tiles = nullptr, size_t keep_limb_stride = 0);
+                     MfmaGramOut* gram = nullptr, int8_t* keep_tiles = nullptr, size_t keep_limb_stride = 0,
+                     const MfmaJobBuffers* jb = nullptr);
 // X_a = P_a^T S per proof on the matrix cores (mfma_api.hip): P_a as [n][r] coefficient matrices, the witness as the tiles
 // matvec_mfma_impl(keep_tiles) made of it for the Ajtai product
 bool gram_mfma_ok(const lab_mat8* m, size_t n, size_t r);

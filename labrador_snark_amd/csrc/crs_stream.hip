@@ -19,6 +19,7 @@ using namespace lab;
 typedef unsigned __int128 u128;
 
 namespace lab {
+int mfma_planes(uint32_t p);
 int mat8_alloc(lab_ctx* c, int basis, size_t nmat_max, size_t rows, size_t cols, lab_mat8** out);
 int mat8_repack(lab_ctx* c, lab_mat8* m, const uint32_t* hat_planes, size_t plane_stride, size_t nmat, size_t rows_valid);
 bool mat8_can_fill_rows(const lab_mat8* m);
@@ -39,7 +40,9 @@ struct CrsStream {
   uint64_t* coefs = nullptr;      // [chunk][64]
   // One pass over the regenerated rows serves up to CRS_MAX_GROUPS groups of vector sets (64 proofs each: the prover's batches of
   // more than 64 proofs share the expansion); per group:
-  uint32_t* tmp[CRS_MAX_GROUPS] = {};   // [L][ns*R][64] (twice that with `reduce`: the inverse transform's scratch behind it)
+  uint32_t* tmp_all = nullptr;          // [L][group][ns*R][64]: the (chunk, slab) results of every group
+  uint32_t* tmp2 = nullptr;             // reduce: [L][ns*R][64] scratch of the inverse transform
+  uint32_t* stage = nullptr;            // several groups in one GEMM launch: its slot-major staging array
   uint64_t* acc[CRS_MAX_GROUPS] = {};   // reduce: [ns][rows][64] coefficients mod q — the running sum over the K chunks
   uint64_t* cur = nullptr;              // reduce: [ns*R][64] the current (chunk, slab)'s sums mod q (shared: used and consumed in turn)
   size_t ngroups = 1;
@@ -50,10 +53,11 @@ struct CrsStream {
     if (m8) lab_mat8_destroy(m8);
     if (slab) (void)hipFree(slab);
     if (coefs) (void)hipFree(coefs);
-    for (size_t g = 0; g < CRS_MAX_GROUPS; g++) {
-      if (tmp[g]) (void)hipFree(tmp[g]);
+    for (size_t g = 0; g < CRS_MAX_GROUPS; g++)
       if (acc[g]) (void)hipFree(acc[g]);
-    }
+    if (tmp_all) (void)hipFree(tmp_all);
+    if (tmp2) (void)hipFree(tmp2);
+    if (stage) (void)hipFree(stage);
     if (cur) (void)hipFree(cur);
   }
 };
@@ -68,9 +72,12 @@ size_t crs_stream_rows(lab_ctx* c, int basis, size_t rows, size_t mc, size_t col
   const size_t kt = ((mc * cols + 31) / 32 + 11) / 12 * 12;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+  const uint32_t* primes = basis ? c->dg_primes : c->primes;
+  size_t planes_total = 0;                      // signed byte planes of all limbs (3 per 23-bit prime, 4 per 30-bit one)
+  for (int l = 0; l < L; l++) planes_total += (size_t)std::min(4, mfma_planes(primes[l]));
   for (size_t R = 512; R > 128; R /= 2) {
     if (rows < R) continue;
-    const size_t slab = (size_t)L * D * 4 /* planes, at most */ * (R / 32) * kt * 1024;
+    const size_t slab = (size_t)planes_total * D * (R / 32) * kt * 1024;
     if (slab <= ((size_t)40 << 30) && slab + other_bytes + ((size_t)1 << 30) <= free_b) return R;
   }
   return 128;
@@ -128,12 +135,13 @@ int crs_stream_create(lab_ctx* c, int basis, size_t nmat, size_t rows, size_t co
     e = hipMalloc(reinterpret_cast<void**>(&st->slab), (size_t)L * slab_elems * D * 4);
   }
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&st->coefs), st->chunk * D * 8);
-  for (size_t g = 0; g < ngroups; g++) {
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&st->tmp[g]), (size_t)(st->reduce ? 2 : 1) * L * ns * st->R * D * 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&st->tmp_all), (size_t)L * ngroups * ns * st->R * D * 4);
+  // (rows past a ragged slab and sets past ns_valid are never stored by the GEMM but are read by the chunk reduction)
+  if (e == hipSuccess) e = hipMemsetAsync(st->tmp_all, 0, (size_t)L * ngroups * ns * st->R * D * 4, c->stream);
+  if (e == hipSuccess && st->reduce) e = hipMalloc(reinterpret_cast<void**>(&st->tmp2), (size_t)L * ns * st->R * D * 4);
+  if (e == hipSuccess && ngroups > 1) e = hipMalloc(reinterpret_cast<void**>(&st->stage), mfma_stage_bytes(st->m8, ns, ngroups));
+  for (size_t g = 0; g < ngroups; g++)
     if (e == hipSuccess && st->reduce) e = hipMalloc(reinterpret_cast<void**>(&st->acc[g]), (size_t)ns * rows * D * 8);
-    // (rows past a ragged slab and sets past ns_valid are never stored by the GEMM but are read by the chunk reduction)
-    if (e == hipSuccess && st->reduce) e = hipMemsetAsync(st->tmp[g], 0, (size_t)2 * L * ns * st->R * D * 4, c->stream);
-  }
   if (e == hipSuccess && st->reduce) e = hipMalloc(reinterpret_cast<void**>(&st->cur), (size_t)ns * st->R * D * 8);
   if (e != hipSuccess) { delete st; return fail(c, LAB_ERR_HIP, "streamed commitment: hipMalloc of the slab: %s", hipGetErrorString(e)); }
   *out = st;
@@ -206,6 +214,22 @@ int crs_stream_run(CrsStream* st, const uint8_t seed[32], const uint64_t* mat_of
     if ((size_t)groups[g].ns > st->ns || groups[g].ns_valid > groups[g].ns) return fail(c, LAB_ERR_ARG, "streamed commitment: group %zu has more sets than the engine was created for", g);
   if (st->reduce)
     for (size_t g = 0; g < ngroups; g++) LAB_HIP(c, hipMemsetAsync(st->acc[g], 0, (size_t)groups[g].ns * rows * D * 8, c->stream));
+  // every group's (chunk, slab) results land in its slice of tmp_all ([L][group][ns*R][64])
+  const size_t gstride = st->ns * st->R * D, tplane = st->ngroups * gstride;
+  auto tmp_view = [&](size_t gi) { return HatView{st->tmp_all + gi * gstride, tplane}; };
+  // Several groups (the sub-batches of a call of more than 64 proofs) go through ONE GEMM launch per limb as its jobs when they
+  // can: the slab is then read from HBM once for all of them (the other jobs' blocks of a slot and row group hit L2) instead of
+  // once per group.  Needs digit tiles (each group's in its own scratch, equally spaced), equal padded set counts, and the
+  // coefficient-domain accumulation (nothing is written straight into a group's output).
+  bool multi = ngroups >= 2 && st->stage && st->reduce;
+  int ns_valid_max = 0;
+  for (size_t g = 0; g < ngroups && multi; g++) {
+    multi = groups[g].dig && (size_t)groups[g].ns == st->ns &&
+            static_cast<char*>(groups[g].scratch) - static_cast<char*>(groups[0].scratch) ==
+                (ptrdiff_t)g * (static_cast<char*>(groups[1].scratch) - static_cast<char*>(groups[0].scratch)) &&
+            static_cast<char*>(groups[1].scratch) > static_cast<char*>(groups[0].scratch);
+    ns_valid_max = groups[g].ns_valid > ns_valid_max ? groups[g].ns_valid : ns_valid_max;
+  }
   for (size_t m0 = 0; m0 < nmat; m0 += st->MC) {
     const size_t mc = nmat - m0 < st->MC ? nmat - m0 : st->MC;
     const bool first = m0 == 0;
@@ -214,20 +238,30 @@ int crs_stream_run(CrsStream* st, const uint8_t seed[32], const uint64_t* mat_of
       const size_t nr = rows - rho0 < st->R ? rows - rho0 : st->R;
       int rc = fill_slab(st, seed, mat_offsets, m0, mc, rho0, nr);
       if (rc) return rc;
+      if (!tiles_made)
+        for (size_t gi = 0; gi < ngroups; gi++) {
+          const CrsGroup& G = groups[gi];
+          if (!G.dig) continue;
+          JobPtrs d;
+          for (int s = 0; s < MAX_JOBS; s++)
+            d.p[s] = (s < G.ns_valid && G.dig->p[s]) ? static_cast<void*>(static_cast<uint16_t*>(G.dig->p[s]) + m0 * cols * D) : nullptr;
+          PhaseSample ps(c, PH_DIGITS, (double)G.ns_valid * mc * cols * D);
+          if ((rc = digits_to_v8_impl(c, st->m8, d, G.ns, G.ns_valid, static_cast<int8_t*>(G.scratch)))) return rc;
+        }
+      if (multi) {
+        const MfmaJobBuffers jb{(size_t)(static_cast<char*>(groups[1].scratch) - static_cast<char*>(groups[0].scratch)), st->stage};
+        PhaseSample ps(c, PH_GEMM, mfma_gemm_bytes(st->m8, (int)st->ns, ns_valid_max) * (double)ngroups);
+        if ((rc = matvec_mfma_impl(c, tmp_view(0), st->R * D, st->m8, ConstHatView(), 0, (int)st->ns, ns_valid_max, groups[0].scratch, D, ngroups,
+                                   gstride, 0, false, nullptr, static_cast<const int8_t*>(groups[0].scratch), nullptr, nullptr, 0, &jb))) return rc;
+      }
       for (size_t gi = 0; gi < ngroups; gi++) {
         const CrsGroup& G = groups[gi];
         const int ns = G.ns, ns_valid = G.ns_valid;
         const bool direct = first && !st->reduce;
-        HatView dst = direct ? HatView{G.out.base + rho0 * D, G.out.plane_stride} : HatView{st->tmp[gi], (size_t)ns * st->R * D};
+        // (a group's slice of tmp_all has the engine's set count st->ns as its set pitch only through R * D: sets are R * D apart)
+        HatView dst = direct ? HatView{G.out.base + rho0 * D, G.out.plane_stride} : tmp_view(gi);
         const size_t dst_ss = direct ? G.out_set_stride : st->R * D;
-        if (G.dig && !tiles_made) {
-          JobPtrs d;
-          for (int s = 0; s < MAX_JOBS; s++)
-            d.p[s] = (s < ns_valid && G.dig->p[s]) ? static_cast<void*>(static_cast<uint16_t*>(G.dig->p[s]) + m0 * cols * D) : nullptr;
-          PhaseSample ps(c, PH_DIGITS, (double)ns_valid * mc * cols * D);
-          if ((rc = digits_to_v8_impl(c, st->m8, d, ns, ns_valid, static_cast<int8_t*>(G.scratch)))) return rc;
-        }
-        {
+        if (!multi) {
           PhaseSample ps(c, PH_GEMM, mfma_gemm_bytes(st->m8, ns, ns_valid));
           if (G.dig || tiles_made) {
             if ((rc = matvec_mfma_impl(c, dst, dst_ss, st->m8, ConstHatView(), 0, ns, ns_valid, G.scratch, D, 1, 0, 0, false, nullptr,
@@ -242,7 +276,7 @@ int crs_stream_run(CrsStream* st, const uint8_t seed[32], const uint64_t* mat_of
           // this (chunk, slab)'s exact sums -> coefficients mod q, added mod q to the rows of the running sum
           const size_t cnt = (size_t)ns * st->R;
           uint64_t* cur = st->cur;
-          if ((rc = from_hat(c, ConstHatView(st->tmp[gi], cnt * D), cnt, st->tmp[gi] + (size_t)L * cnt * D, cur, st->basis))) return rc;
+          if ((rc = from_hat(c, ConstHatView(tmp_view(gi)), cnt, st->tmp2, cur, st->basis))) return rc;
           JobPtrs o, b;
           JobU64 zero;
           for (int s = 0; s < MAX_JOBS; s++) {
@@ -253,8 +287,7 @@ int crs_stream_run(CrsStream* st, const uint8_t seed[32], const uint64_t* mat_of
           LAB_HIP(c, launch_coef_elementwise_jobs(o, o, b, nr, c->q, zero, 2, (size_t)ns_valid, c->stream));
         } else if (!first)
           LAB_HIP(c, launch_pointwise(PW_ADD, HatView{G.out.base + rho0 * D, G.out.plane_stride}, HatView{G.out.base + rho0 * D, G.out.plane_stride},
-                                      HatView{st->tmp[gi], (size_t)ns * st->R * D}, nr, L, tabs, c->stream, (size_t)ns_valid, G.out_set_stride,
-                                      G.out_set_stride, st->R * D));
+                                      tmp_view(gi), nr, L, tabs, c->stream, (size_t)ns_valid, G.out_set_stride, G.out_set_stride, st->R * D));
       }
       tiles_made = true;
     }

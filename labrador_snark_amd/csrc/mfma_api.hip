@@ -48,6 +48,7 @@ static size_t v8_job_bytes(const lab_mat8* m, int ns) {
 static size_t stage_bytes(const lab_mat8* m, int ns, size_t njobs) {
   return njobs > 1 ? Carver::padded(njobs * (size_t)D * m->rt_count * 32 * ns * 4) : 0;
 }
+size_t mfma_stage_bytes(const lab_mat8* m, int ns, size_t njobs) { return Carver::padded(njobs * (size_t)D * m->rt_count * 32 * ns * 4); }
 size_t mfma_scratch_bytes(const lab_mat8* m, int ns, size_t njobs) { return v8_job_bytes(m, ns) * njobs + stage_bytes(m, ns, njobs); }
 double mfma_gemm_bytes(const lab_mat8* m, int ns, int ns_valid) {
   const double kt_real = (double)((m->nmat * m->cols + 31) / 32);
@@ -128,7 +129,8 @@ int gram_mfma_impl(lab_ctx* c, const lab_mat8* m, int nops, const HatView* outs,
 // limbs are bracketed by events.
 int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_mat8* m, ConstHatView V, size_t v_set_stride, int ns,
                      int ns_valid, void* scratch, size_t v_k_stride, size_t njobs, size_t out_job_stride, size_t v_job_stride,
-                     bool timed, MfmaCoefOut* coef, const int8_t* prepacked, MfmaGramOut* gram, int8_t* keep_tiles, size_t keep_limb_stride) {
+                     bool timed, MfmaCoefOut* coef, const int8_t* prepacked, MfmaGramOut* gram, int8_t* keep_tiles, size_t keep_limb_stride,
+                     const MfmaJobBuffers* jb) {
   const uint32_t* primes = m->basis ? c->dg_primes : c->primes;
   const size_t ktotal = m->nmat * m->cols;
   // Many 32-set jobs sharing the matrix (the Ajtai product of a batch): two source jobs are multiplied as ONE 64-set job,
@@ -149,18 +151,22 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
   int8_t* v8 = static_cast<int8_t*>(scratch);
   const size_t v8_stride = v8_job_bytes(m, ns);
   uint32_t* stage = (njobs > 1 || paired) ? reinterpret_cast<uint32_t*>(v8 + v8_stride * njobs) : nullptr;
+  if (jb) {   // every job's tiles in a buffer of its own ([limb] each), the staging array elsewhere
+    if (!prepacked || paired || njobs < 2) return fail(c, LAB_ERR_ARG, "matvec_mfma_impl: per-job tile buffers need prepacked tiles of several unpaired jobs");
+    stage = jb->stage;
+  }
   for (int l = 0; l < m->nlimbs; l++) {
     const int pl = m->planes[l];
     const size_t nt = nt_for(ns, pl);
     // the caller wants the tiles of every limb afterwards (keep_limb_stride: this call packs a slice of the jobs of a larger array)
     if (keep_tiles) v8 = keep_tiles + (size_t)l * (keep_limb_stride ? keep_limb_stride : v8_stride * njobs);
-    if (prepacked) v8 = const_cast<int8_t*>(prepacked) + (size_t)l * v8_stride * njobs;   // digits_to_v8_impl made every limb's tiles
+    if (prepacked) v8 = const_cast<int8_t*>(prepacked) + (size_t)l * v8_stride * (jb ? 1 : njobs);   // digits_to_v8_impl made every limb's tiles
     else
       LAB_HIP(c, launch_pack_vectors_i8(ns, ns_valid, v8, V.base + (size_t)l * V.plane_stride, v_set_stride, v_k_stride, ktotal,
                                         m->kt_count, nt, pl, njobs, v_job_stride, v8_stride, nsub, sub_stride_v, c->stream));
     Gemm8Args g;
     g.out = out.base + (size_t)l * out.plane_stride; g.out_set_stride = out_set_stride; g.out_job_stride = out_job_stride;
-    g.M8 = m->d[l]; g.V8 = v8; g.v8_job_stride = v8_stride;
+    g.M8 = m->d[l]; g.V8 = v8; g.v8_job_stride = jb ? jb->job_stride : v8_stride;
     g.planes = (unsigned)pl; g.rt_count = (unsigned)m->rt_count; g.kt_count = (unsigned)m->kt_count;
     g.kt_real = (unsigned)((ktotal + 31) / 32);
     const int waves = gemm_i8_waves(pl, m->rt_count, nt);

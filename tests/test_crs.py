@@ -412,3 +412,53 @@ def test_prover_streamed_with_k_chunks(nproofs, chunk_basis):
     if ctx is not ref:
         ctx.close()
     ref.close()
+
+
+@pytest.mark.gpu
+def test_streamed_groups_share_one_gemm_launch():
+    # 128 proofs = two full sub-batches: their digit tiles sit in the two sub-batches' workspaces (equally spaced) and go through ONE
+    # GEMM launch per limb and (chunk, slab) as its two jobs — the slab is read from HBM once for both.  kappa1 = 130 rows (five row
+    # tiles: the assembly K loop, ragged), kappa = 64, a digit basis that holds four of the nine B_ik per K chunk (chunks reduced mod q).
+    # Every field of every proof == the resident CRS on the multiply-add kernels; u_1 rows of the first and the last proof == the oracle.
+    import labrador_snark_amd as lab
+    import cases
+    q, n, r, kappa, kappa1, nproofs = Q_REF33, 2, 3, 64, 130, 128
+    ref = lab.Context(q, 0, **ctx_kw(q))
+    ctx = lab.Context(q, 0, **ctx_kw(q))
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, kappa1)
+    primes, _, _ = ctx.enable_digit_basis(300, max(k.B_1, k.B_2), mfma=True)
+    assert len(primes) == 3 and r * k.T_1 * kappa > 300
+    base = bytes((i * 53 + 7) % 256 for i in range(32))
+    full = lab.CRS(ref, k, base).materialize(mfma_basis=True)
+    streamed = lab.CRS(ctx, k, base).materialize(mfma_basis=True, stream_B=True)
+    streamed.pack_mfma(main_basis_A=False, drop_CD=True)
+    ws, sts, tapes = [], [], []
+    for j in range(nproofs):
+        S, phi, a, tape = cases.make_inputs(p, seed=4000 + j)
+        ws.append(S); tapes.append(tape)
+        sts.append(lab.State(phi, a, int(lab.gen_f_b(ref, S, phi, a, n, r)[0])))
+    want, c1 = lab.prove_core_batch(ref, k, ws, sts, full, tapes, raise_on_reject=False)
+    got, c2 = lab.prove_core_batch(ctx, k, ws, sts, streamed, tapes, raise_on_reject=False)
+    assert c1 == c2
+    for j in range(nproofs):
+        for f in ("u_1", "u_2", "t_i_all", "g_mat", "h_mat", "z", "b_prime_prime", "projection_int"):
+            assert np.array_equal(getattr(got[j], f), getattr(want[j], f)), (j, f)
+    off = lambda which, **kw: co.crs_offset(which, n, r, kappa, kappa1, kappa1, p.t1, **kw)
+    pairs = [(i, j) for i in range(r) for j in range(i, r)]
+    for jj, rho in ((0, 0), (nproofs - 1, kappa1 - 1), (64, 128)):
+        T = got[jj]
+        acc = np.zeros(D, np.uint64)
+        for i in range(r):
+            dec = co.decompose_vec(q, T.t_i_all[i], k.B_1, k.T_1)
+            for kk in range(k.T_1):
+                b_row = co.crs_fill(base, off("B", i=i, k=kk, row=rho), kappa * D, q).reshape(kappa, D)
+                acc = co.poly_add(q, acc, co.inner_product(q, b_row, dec[kk]))
+        for (i, j) in pairs:
+            gdec = co.decompose(q, T.g_mat[i, j], k.B_2, k.T_2)
+            for kk in range(k.T_2):
+                c_vec = co.crs_fill(base, off("C", i=i, j=j, k=kk), kappa1 * D, q).reshape(kappa1, D)
+                acc = co.poly_add(q, acc, co.polymul(q, gdec[kk], c_vec[rho]))
+        assert np.array_equal(T.u_1[rho], acc), (jj, rho)
+    full.close(); streamed.close()
+    ctx.close(); ref.close()
