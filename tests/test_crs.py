@@ -220,7 +220,8 @@ def test_streamed_crs_matvec_equals_materialise_then_multiply(mfma_basis, nmat, 
 @pytest.mark.gpu
 # 70 and 130 proofs: more than one call's 64 — the sub-batches run steps 1-2, suspend, share ONE pass over the regenerated rows
 # (one group of vector sets each: 64 + 6, 64 + 64 + 2) and resume for steps 4-10
-@pytest.mark.parametrize("nproofs", [1, 3, 70, 130])
+# 260 proofs: more sub-batches (5) than one shared pass takes (4): every sub-batch then streams B for itself
+@pytest.mark.parametrize("nproofs", [1, 3, 70, 130, 260])
 def test_prover_with_B_streamed_from_the_seed(nproofs):
     # lab_prove_input.crs_seed with B == B8 == NULL: step 3 regenerates the B_ik rows from the seed inside the call
     # (fetch_B_ik_row's literal offsets) — same transcripts as with the materialised CRS, and as the oracle on its own
