@@ -77,7 +77,9 @@ size_t crs_stream_rows(lab_ctx* c, int basis, size_t rows, size_t mc, size_t col
   for (int l = 0; l < L; l++) planes_total += (size_t)std::min(4, mfma_planes(primes[l]));
   for (size_t R = 512; R > 128; R /= 2) {
     if (rows < R) continue;
-    const size_t slab = (size_t)planes_total * D * (R / 32) * kt * 1024;
+    size_t slab = (size_t)planes_total * D * (R / 32) * kt * 1024;
+    // without the one-pass coefficients -> tiles kernel (3-plane limbs, cols % 64 == 0) the slab also exists as residues
+    if (planes_total != (size_t)3 * L || cols % 64) slab += (size_t)L * mc * R * cols * D * 4;
     if (slab <= ((size_t)40 << 30) && slab + other_bytes + ((size_t)1 << 30) <= free_b) return R;
   }
   return 128;

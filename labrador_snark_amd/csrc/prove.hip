@@ -101,6 +101,12 @@ struct ProveShared {           // the streamed step 3 the sub-batches of one cal
     if (_e != hipSuccess) co_return lab::fail(ctx, LAB_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
   } while (0)
 
+// the 32-byte seed of two proofs names the same CRS (by content: callers marshal it per proof)
+static bool same_seed(const uint8_t* a, const uint8_t* b) {
+  if (a == b) return true;
+  return a && b && memcmp(a, b, 32) == 0;
+}
+
 static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const* ins, lab_transcript* const* outs, int* status,
                             bool allow_digit_ajtai = true);
 
@@ -134,7 +140,7 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
     if ((x->Pi2 != nullptr) != (in->Pi2 != nullptr))
       co_return fail(c, LAB_ERR_ARG, "lab_prove_core_batch: either every proof of a batch hands over Pi2 (2 bits per entry) or none");
     if (x->n != n || x->r != r || x->kappa != kappa || x->kappa1 != k1 || x->kappa2 != k2 || x->t1 != t1 || x->t2 != t2 ||
-        x->b1 != in->b1 || x->b2 != in->b2 || x->beta_bound != in->beta_bound || x->A != in->A || x->B != in->B || x->crs_seed != in->crs_seed || x->B8 != in->B8 || x->A8 != in->A8 || x->C8 != in->C8 || x->D8 != in->D8 || x->A8d != in->A8d ||
+        x->b1 != in->b1 || x->b2 != in->b2 || x->beta_bound != in->beta_bound || x->A != in->A || x->B != in->B || !same_seed(x->crs_seed, in->crs_seed) || x->B8 != in->B8 || x->A8 != in->A8 || x->C8 != in->C8 || x->D8 != in->D8 || x->A8d != in->A8d ||
         x->C != in->C || x->Dm != in->Dm || x->a_off != in->a_off || x->b_off != in->b_off || x->c_off != in->c_off ||
         x->d_off != in->d_off)
       co_return fail(c, LAB_ERR_ARG, "lab_prove_core_batch: all proofs of a batch must share dimensions, constants and the CRS");
@@ -741,6 +747,17 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   const size_t nsub = (np + MAX_JOBS - 1) / MAX_JOBS;
   auto sub_np = [&](size_t k) { return k + 1 < nsub ? (size_t)MAX_JOBS : np - k * MAX_JOBS; };
   const lab_prove_input* in = ins ? ins[0] : nullptr;
+  // (every sub-batch checks that its own proofs share dimensions, constants and the CRS; across sub-batches:)
+  for (size_t k = 1; k < nsub && in; k++) {
+    const lab_prove_input* x = ins[k * MAX_JOBS];
+    if (!x) return fail(c, LAB_ERR_ARG, "lab_prove_core: null argument");
+    if (x->n != in->n || x->r != in->r || x->kappa != in->kappa || x->kappa1 != in->kappa1 || x->kappa2 != in->kappa2 || x->t1 != in->t1 ||
+        x->t2 != in->t2 || x->b1 != in->b1 || x->b2 != in->b2 || x->beta_bound != in->beta_bound || x->A != in->A || x->B != in->B ||
+        !same_seed(x->crs_seed, in->crs_seed) || x->B8 != in->B8 || x->A8 != in->A8 || x->C8 != in->C8 || x->D8 != in->D8 ||
+        x->A8d != in->A8d || x->C != in->C || x->Dm != in->Dm || x->a_off != in->a_off || x->b_off != in->b_off ||
+        x->c_off != in->c_off || x->d_off != in->d_off)
+      return fail(c, LAB_ERR_ARG, "lab_prove_core_batch: all proofs of a batch must share dimensions, constants and the CRS");
+  }
   const bool shared = in && !in->B8 && !in->B && in->crs_seed && (in->C || in->C8) && nsub <= (size_t)CRS_MAX_GROUPS;
   if (!shared) {   // B resident: every sub-batch streams it from HBM itself
     int first = LAB_OK;

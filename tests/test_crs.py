@@ -218,6 +218,42 @@ def test_streamed_crs_matvec_equals_materialise_then_multiply(mfma_basis, nmat, 
 
 
 @pytest.mark.gpu
+def test_batch_refuses_sub_batches_with_different_constants():
+    # more than 64 proofs are proved in sub-batches that share the commitment pass: a later sub-batch that names
+    # another seed or another norm bound than proof 0 is refused as a whole (LAB_ERR_ARG), nothing is proved
+    import labrador_snark_amd as lab
+    import cases
+    from labrador_snark_amd import prover
+    q, n, r, kappa, kappa1 = Q_REF33, 2, 2, 5, 4
+    ctx = lab.Context(q, 0, **ctx_kw(q))
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, kappa1)
+    base = bytes((i * 37 + 11) % 256 for i in range(32))
+    streamed = lab.CRS(ctx, k, base).materialize(mfma_basis=True, stream_B=True)
+    ws, sts, tapes = [], [], []
+    for j in range(65):
+        S, phi, a, tape = cases.make_inputs(p, seed=41 + j)
+        ws.append(S); tapes.append(tape)
+        sts.append(lab.State(phi, a, int(lab.gen_f_b(ctx, S, phi, a, n, r)[0])))
+    plan = prover.BatchPlan(ctx, k, ws, sts, streamed, tapes, device_outputs=False)
+    plan.run(raise_on_reject=False)
+    pin = plan._ios[64][0]
+    kept = pin.beta_bound
+    pin.beta_bound = kept + 1
+    with pytest.raises(lab.LabradorError, match="share dimensions"):
+        plan.run(raise_on_reject=False)
+    pin.beta_bound = kept
+    other = bytes(range(1, 33))
+    pin.crs_seed = other
+    with pytest.raises(lab.LabradorError, match="share dimensions"):
+        plan.run(raise_on_reject=False)
+    pin.crs_seed = base
+    plan.run(raise_on_reject=False)
+    streamed.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
 # 70 and 130 proofs: more than one call's 64 — the sub-batches run steps 1-2, suspend, share ONE pass over the regenerated rows
 # (one group of vector sets each: 64 + 6, 64 + 64 + 2) and resume for steps 4-10
 # 260 proofs: more sub-batches (5) than one shared pass takes (4): every sub-batch then streams B for itself
