@@ -199,7 +199,14 @@ double mfma_gemm_bytes(const lab_mat8* m, int ns, int ns_valid);
 // (several jobs) the inverse transform reads it directly and writes plane l of the dense array `coef->dense`
 // ([limb][count][64] words, job stride coef->job_stride, set s -> polynomial s * coef->set_stride + row) instead of `out`;
 // coef->done tells whether that happened (else `out` holds the transform-domain results as usual)
-struct MfmaCoefOut { uint32_t* dense; size_t plane_stride, job_stride, set_stride; bool done; };
+struct MfmaCoefOut {
+  uint32_t* dense; size_t plane_stride, job_stride, set_stride; bool done;
+  // optional: room for the staging array of EVERY limb (stage_ps words each).  When the call goes through staging arrays that fit,
+  // it leaves them there (staged = true, their geometry below) and runs no inverse transform: the caller finishes with
+  // launch_stage_to_coeffs (transform + CRT in one pass, no dense copy)
+  uint32_t* stage_planes = nullptr; size_t stage_ps = 0;
+  bool staged = false; size_t st_rows_pad = 0, st_ns = 0, st_nsub = 0, st_jobs = 0;
+};
 // `gram`: the sets are the (at most 32) witness columns of each job and every limb has 3 planes — also produce
 // G[i][k] = sum_x V_i[x] V_k[x] per source job from the packed tiles (transform domain, basis of m): element i*r + k of
 // gram->out + job * gram->job_stride, plane l at + l * gram->plane_stride; gram->done tells whether that happened

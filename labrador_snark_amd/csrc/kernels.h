@@ -92,6 +92,10 @@ hipError_t launch_crt_to_u64(ConstHatView src, uint64_t* coeffs, size_t count, c
 struct CrtDigits { JobPtrs out16; uint32_t base; int exp; size_t group; uint64_t q; };
 hipError_t launch_crt_to_u64_jobs(ConstHatView src, size_t src_js, const JobPtrs& coeffs, size_t count, const CrtTable* crt,
                                   int nlimbs, size_t njobs, hipStream_t s, const CrtDigits* dg = nullptr);
+// inverse transform of every limb + CRT (+ digits) straight from the staging arrays of a multi-job GEMM (see k_stage_to_coeffs)
+hipError_t launch_stage_to_coeffs(const uint32_t* stage, size_t stage_ps, size_t rows, size_t rows_pad, size_t ns, size_t ns_valid,
+                                  size_t nsub, size_t gemm_jobs, const JobPtrs& coeffs, size_t set_stride, const LimbTable* tabs,
+                                  const CrtTable* crt, int nlimbs, hipStream_t s, const CrtDigits* dg = nullptr);
 hipError_t launch_synth_fill_u64(uint64_t* coeffs, size_t count, uint64_t seed, uint64_t first_elem, uint64_t bound,
                                  hipStream_t s);
 

@@ -155,9 +155,13 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
     if (!prepacked || paired || njobs < 2) return fail(c, LAB_ERR_ARG, "matvec_mfma_impl: per-job tile buffers need prepacked tiles of several unpaired jobs");
     stage = jb->stage;
   }
+  // results wanted as coefficients only, with room for every limb's staging array: keep them all (see MfmaCoefOut)
+  const bool keep_stages = stage && !jb && coef && coef->stage_planes && m->nlimbs >= 2 && m->nlimbs <= 3 &&
+                           coef->stage_ps >= njobs * D * (m->rt_count * 32) * (size_t)ns;
   for (int l = 0; l < m->nlimbs; l++) {
     const int pl = m->planes[l];
     const size_t nt = nt_for(ns, pl);
+    if (keep_stages) stage = coef->stage_planes + (size_t)l * coef->stage_ps;
     // the caller wants the tiles of every limb afterwards (keep_limb_stride: this call packs a slice of the jobs of a larger array)
     if (keep_tiles) v8 = keep_tiles + (size_t)l * (keep_limb_stride ? keep_limb_stride : v8_stride * njobs);
     if (prepacked) v8 = const_cast<int8_t*>(prepacked) + (size_t)l * v8_stride * (jb ? 1 : njobs);   // digits_to_v8_impl made every limb's tiles
@@ -203,6 +207,7 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
                                 gram->out + (size_t)l * gram->plane_stride, nullptr, gram->job_stride, primes[l], g.pw, g.bias,
                                 (m->basis ? c->dg_tabs : c->d_tabs) + l, c->stream));
     else if (gram) gram_ok = false;
+    if (keep_stages) continue;
     if (stage && coef)
       LAB_HIP(c, launch_intt_from_stage(stage, m->rows, m->rt_count * 32, ns, ns_valid, nsub, njobs, coef->dense + (size_t)l * coef->plane_stride,
                                         coef->job_stride, coef->set_stride, (m->basis ? c->dg_tabs : c->d_tabs) + l, c->stream));
@@ -211,6 +216,7 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
                                        nsub, c->stream));
   }
   if (coef) coef->done = stage != nullptr;
+  if (keep_stages) { coef->staged = true; coef->st_rows_pad = m->rt_count * 32; coef->st_ns = (size_t)ns; coef->st_nsub = nsub; coef->st_jobs = njobs; }
   if (gram) gram->done = gram_ok;
   return LAB_OK;
 }

@@ -444,6 +444,110 @@ k_crt_to_u64(const uint32_t* __restrict__ src, size_t src_ps, const JobPtrs dstp
   }
 }
 
+// k_intt_from_stage + k_crt_to_u64 in one pass, for results a multi-job GEMM left in slot-major staging arrays of EVERY limb
+// (stage + l * stage_ps: [gemm job][slot j][row][set s]) that are only wanted as coefficients mod q (t = A s, src/proofgen.rs:41-49):
+// the dense inverse-transform output ([L][count][64] words written and read back, as much traffic as the staging arrays
+// themselves) never exists.  Block = 4 waves = 64 neighbouring (row, s).  Wave l < L: thread (row, s) reads its 64 slots of limb l
+// (coalesced: 256 B per slot and wave), inverse-transforms them in registers and parks the polynomial in LDS ([limb][polynomial]
+// [64 + 4]); then thread (polynomial, quad) of all four waves reconstructs four neighbouring coefficients (crt_one) and the block
+// stores whole polynomials: 512 B of t, 128 B of every digit.  (All limbs in the registers of one wave — 192 of them — is slower:
+// it spills at two waves per SIMD and waits on its loads at one.)  DIG as in k_crt_to_u64.
+// Polynomial (s % nsub) * set_stride + row of proof job * (ns / nsub) + s / nsub.
+template <int L, bool DIG>
+__global__ void __launch_bounds__(256)
+k_stage_to_coeffs(const uint32_t* __restrict__ stage, size_t stage_ps, unsigned rows, unsigned rows_pad, unsigned ns, unsigned ns_valid,
+                  unsigned nsub, const JobPtrs dstp, size_t set_stride, const LimbTable* __restrict__ tabs,
+                  const CrtTable* __restrict__ crt, const CrtDigits dg) {
+  static_assert(L >= 2 && L <= 3, "a wave per limb, at most 3 x 17 KB of LDS");
+  __shared__ __attribute__((aligned(16))) uint32_t lds[L * TILE_WORDS];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const size_t per_slot = (size_t)rows_pad * ns;
+  const size_t f0 = (size_t)blockIdx.x * 64;
+  if (w < L) {
+    const uint32_t* src = stage + (size_t)w * stage_ps + (size_t)blockIdx.y * D * per_slot + f0 + lane;
+    uint32_t x[D];
+#pragma unroll
+    for (int j = 0; j < D; j++) x[j] = __builtin_nontemporal_load(src + (size_t)j * per_slot);
+    ntt64_inverse(x, tabs + w, 0);
+#pragma unroll
+    for (int c = 0; c < 16; c++)
+      *reinterpret_cast<uint4*>(lds + w * TILE_WORDS + lane * TILE_PITCH + c * 4) = make_uint4(x[c * 4 + 0], x[c * 4 + 1], x[c * 4 + 2], x[c * 4 + 3]);
+  }
+  __syncthreads();
+  const uint64_t q = crt->q;
+  const double inv_q = crt->inv_q;
+  const uint32_t b32 = dg.base, bm = DIG ? (uint32_t)(0x100000000ull / dg.base) : 0;
+  const uint64_t half = DIG ? (dg.base / 2) % q : 0;
+  const unsigned sub = ns / nsub;
+#pragma unroll 1
+  for (int i = 0; i < 4; i++) {
+    const int pl = i * 16 + (t >> 4), quad = t & 15;
+    const size_t f = f0 + pl;
+    const unsigned row = (unsigned)(f / ns), s = (unsigned)(f % ns), sl = s % nsub;
+    if (row >= rows || sl >= ns_valid) continue;
+    uint32_t r[4][L];
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      const uint4 v = *reinterpret_cast<const uint4*>(lds + l * TILE_WORDS + pl * TILE_PITCH + quad * 4);
+      r[0][l] = v.x; r[1][l] = v.y; r[2][l] = v.z; r[3][l] = v.w;
+    }
+    uint64_t v[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) v[c] = crt_one<L>(r[c], crt, q, inv_q);
+    const unsigned proof = blockIdx.y * sub + s / nsub;
+    const size_t e = (size_t)sl * set_stride + row;          // polynomial of the proof's result
+    const unsigned w0 = quad * 4;                           // first of the four coefficients
+    uint64_t* const o64 = static_cast<uint64_t*>(dstp.p[proof]) + e * D + w0;
+    ulonglong2 o0, o1;
+    o0.x = v[0]; o0.y = v[1]; o1.x = v[2]; o1.y = v[3];
+    reinterpret_cast<ulonglong2*>(o64)[0] = o0;
+    reinterpret_cast<ulonglong2*>(o64)[1] = o1;
+    if constexpr (DIG) {
+      const size_t g = dg.group, eg = e / g;
+      uint16_t* const o = static_cast<uint16_t*>(dg.out16.p[proof]) + (eg * dg.exp * g + (e - eg * g)) * D + w0;
+      for (int k = 0; k < dg.exp; k++) {
+        uint32_t d[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {   // (see k_crt_to_u64)
+          uint64_t qq;
+          const uint32_t r0 = divmod_u40_u16((uint32_t)(v[c] >> 32), (uint32_t)v[c], b32, bm, &qq);
+          d[c] = r0 > half ? b32 - r0 : r0;
+          v[c] = qq;
+        }
+        *reinterpret_cast<uint2*>(o + (size_t)k * g * D) = make_uint2(d[0] | (d[1] << 16), d[2] | (d[3] << 16));
+      }
+    }
+  }
+}
+
+// `stage`: nlimbs staging arrays stage_ps words apart, gemm_jobs jobs of ns sets each; coeffs.p[proof] (and dg->out16.p[proof])
+// for proof = gemm job * (ns / nsub) + s / nsub.  hipErrorNotSupported when the digits do not have the 16-bit fast form.
+hipError_t launch_stage_to_coeffs(const uint32_t* stage, size_t stage_ps, size_t rows, size_t rows_pad, size_t ns, size_t ns_valid,
+                                  size_t nsub, size_t gemm_jobs, const JobPtrs& coeffs, size_t set_stride, const LimbTable* tabs,
+                                  const CrtTable* crt, int nlimbs, hipStream_t s, const CrtDigits* dg) {
+  if (rows == 0 || gemm_jobs == 0) return hipSuccess;
+  if ((rows_pad * ns) % 64 || ns % nsub || gemm_jobs * (ns / nsub) > (size_t)MAX_JOBS || gemm_jobs > 65535) return hipErrorInvalidValue;
+  if (dg && (dg->base >= 65536 || dg->base < 2 || (uint64_t)dg->base > dg->q || dg->q >= (1ull << 40) || dg->group == 0 || dg->exp <= 0 ||
+             dg->group >> 32))
+    return hipErrorNotSupported;
+  const dim3 g((unsigned)(rows_pad * ns / 64), (unsigned)gemm_jobs);
+  CrtDigits none{};
+#define LAB_STC_CASE(LL)                                                                                                             \
+  case LL:                                                                                                                           \
+    if (dg) hipLaunchKernelGGL((k_stage_to_coeffs<LL, true>), g, dim3(256), 0, s, stage, stage_ps, (unsigned)rows, (unsigned)rows_pad, \
+                               (unsigned)ns, (unsigned)ns_valid, (unsigned)nsub, coeffs, set_stride, tabs, crt, *dg);                  \
+    else hipLaunchKernelGGL((k_stage_to_coeffs<LL, false>), g, dim3(256), 0, s, stage, stage_ps, (unsigned)rows, (unsigned)rows_pad, \
+                            (unsigned)ns, (unsigned)ns_valid, (unsigned)nsub, coeffs, set_stride, tabs, crt, none);                    \
+    break;
+  switch (nlimbs) {
+    LAB_STC_CASE(2) LAB_STC_CASE(3)
+    default: return hipErrorNotSupported;
+  }
+#undef LAB_STC_CASE
+  return hipGetLastError();
+}
+
 // dg (optional): also write the decomposition digits of every value (see CrtDigits in kernels.h); returns
 // hipErrorNotSupported when the digits do not have the 16-bit fast form
 hipError_t launch_crt_to_u64_jobs(ConstHatView src, size_t src_js, const JobPtrs& coeffs, size_t count, const CrtTable* crt,

@@ -278,6 +278,15 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
                             2 /*cab*/;
   size_t dense_words = np * Lmax * tmp_elems * D;
   if (t_coef_only && t_chunk * Lmax * rk * D > dense_words) dense_words = t_chunk * Lmax * rk * D;
+  // t = A S of up to 32 columns per proof leaves the matrix cores in one slot-major staging array per limb; with room for all of
+  // them the inverse transform and the CRT (with the digits of t) are ONE pass over them (launch_stage_to_coeffs): the dense
+  // array is that room ([limb][gemm job][slot][row, padded to 32][set])
+  const int a8_ns = r <= 8 ? 8 : r <= 16 ? 16 : 32;       // witness columns per Ajtai GEMM pass
+  const size_t t_stage_ps = t_chunk * (size_t)a8_ns * D * ((kappa + 31) / 32 * 32);
+  const int t_limbs = a8d ? basis_nlimbs(c, bdig) : c->nlimbs;
+  const bool t_staged = t_coef_only && r <= 32 && t_limbs >= 2 && t_limbs <= 3 && c->q < (1ull << 40) && kappa < ((size_t)1 << 32) &&
+                        (!(in->b1 <= 65536 && in->b2 <= 65536) || (in->b1 >= 2 && in->b1 < 65536 && (uint64_t)in->b1 <= c->q));
+  if (t_staged && (size_t)t_limbs * t_stage_ps > dense_words) dense_words = (size_t)t_limbs * t_stage_ps;
   size_t bytes = Carver::padded((size_t)L * hat_words * 4) + Carver::padded((size_t)Ld * hatd_words * 4) +
                  Carver::padded(dense_words * 4) +
                  np * (coef_elems * (D * 8) + 32 * 256 /*alignment padding of the carves*/ + 3 * 4096 /*proj*/);
@@ -297,7 +306,6 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
   if (stream_b && crs_stream_scratch_bytes(c, bdig, r * (size_t)t1, k1, kappa, mf_ns, rhs_terms) + 4096 > mf_bytes)
     mf_bytes = crs_stream_scratch_bytes(c, bdig, r * (size_t)t1, k1, kappa, mf_ns, rhs_terms) + 4096;
   if (fuse_t && b8 && mfma_prepacked_bytes(b8, mf_ns) + 4096 > mf_bytes) mf_bytes = mfma_prepacked_bytes(b8, mf_ns) + 4096;
-  const int a8_ns = r <= 8 ? 8 : r <= 16 ? 16 : 32;       // witness columns per Ajtai GEMM pass
   if (a8 && mfma_scratch_bytes(a8, a8_ns, np) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(a8, a8_ns, np) + 4096;
   if (a8d && mfma_scratch_bytes(a8d, a8_ns, t_chunk) + 4096 > mf_bytes) mf_bytes = mfma_scratch_bytes(a8d, a8_ns, t_chunk) + 4096;
   if (sd_only && gram_mfma_scratch_bytes(a8d, np) + 4096 > mf_bytes) mf_bytes = gram_mfma_scratch_bytes(a8d, np) + 4096;
@@ -409,7 +417,21 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
   // ================= step 1 (src/proofgen.rs:41-49): t_i = A s_i for every column of every proof; A is shared, so the
   // whole batch is one (kappa x n)(n x np*r) product (falls back to one launch per proof for shapes it does not take)
   uint64_t* norm_sums = host_stage + np * (256 + 256 + D);
-  bool t_in_dense = false, g_in_digit = false, t_digits_done = false;
+  bool t_in_dense = false, g_in_digit = false, t_digits_done = false, t_done = false;
+  // t (and its digits) of proofs jb .. jb + cnt - 1 from the staging arrays the product left in the dense array
+  auto t_from_stages = [&](const MfmaCoefOut& co, size_t jb, size_t cnt, int valid, int basis) -> int {
+    JobPtrs pt, pd;
+    for (size_t i = 0; i < (size_t)MAX_JOBS; i++) {
+      pt.p[i] = i < cnt ? jobs[jb + i].cT : nullptr;
+      pd.p[i] = i < cnt ? jobs[jb + i].cTdec : nullptr;
+    }
+    CrtDigits dg{pd, (uint32_t)in->b1, t1, kappa, q};
+    LAB_HIP(c, launch_stage_to_coeffs(co.stage_planes, co.stage_ps, kappa, co.st_rows_pad, co.st_ns, (size_t)valid, co.st_nsub, co.st_jobs, pt, kappa,
+                                      basis_tabs(c, basis), basis_crt(c, basis), basis_nlimbs(c, basis), s, dig16 ? &dg : nullptr));
+    t_done = true;
+    if (dig16) t_digits_done = true;
+    return LAB_OK;
+  };
   if (a8d) {  // matrix cores, in the basis of B, C, D (see a8d above): S once more into that basis, its norm summed on the way
     LAB_HIPC(c, hipMemsetAsync(norm_sums, 0, np * 8, s));
     LAB_HIPC(c, hipMemsetAsync(above16, 0, np * 4, s));
@@ -424,14 +446,16 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
       for (size_t i0 = 0; i0 < r; i0 += 32) {
         const int valid = (int)(r - i0 < 32 ? r - i0 : 32);
         MfmaCoefOut co{dense_tmp + i0 * kappa * D, rk * D, tmp_js_t, kappa, false};   // t is only wanted as coefficients
+        if (t_staged) { co.stage_planes = dense_tmp; co.stage_ps = t_stage_ps; }
         MfmaGramOut go{HD(jb, hGd).base, hatd_words, perd * D, r, false};            // step 2 (G = S^T S) from the same tiles
         int8_t* keep = s_tiles ? s_tiles + (jb / (tiles_paired ? 2 : 1)) * tile_job_bytes : nullptr;
         if ((rc = matvec_mfma_impl(c, HD(jb, hTd + i0 * kappa), kappa * D, a8d, HD(jb, hSd + i0), D, a8_ns, valid, mf_scratch, r * D, t_chunk,
                                    perd * D, perd * D, false, &co, nullptr, r <= 32 ? &go : nullptr, keep, tile_job_bytes * tile_jobs))) co_return rc;
         t_in_dense = co.done;
         g_in_digit = go.done;
+        if (co.staged && (rc = t_from_stages(co, jb, t_chunk, valid, bdig))) co_return rc;
       }
-      if (t_chunk < np) {   // a slice of the proofs: its CRT (with the digits of t) before the next slice reuses the dense array
+      if (t_chunk < np && !t_done) {   // a slice of the proofs: its CRT (with the digits of t) before the next slice reuses the dense array
         if (!t_in_dense || !dig16) co_return fail(c, LAB_ERR_ARG, "lab_prove_core: internal: sliced t chain without the dense path");
         JobPtrs pt, pd;
         for (size_t i = 0; i < (size_t)MAX_JOBS; i++) {
@@ -448,9 +472,11 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
     for (size_t i0 = 0; i0 < r; i0 += 32) {
       const int valid = (int)(r - i0 < 32 ? r - i0 : 32);
       MfmaCoefOut co{dense_tmp + i0 * kappa * D, rk * D, tmp_js_t, kappa, false};
+      if (t_staged) { co.stage_planes = dense_tmp; co.stage_ps = t_stage_ps; }
       if ((rc = matvec_mfma_impl(c, HV(0, hT + i0 * kappa), kappa * D, a8, HV(0, hS + i0), D, a8_ns, valid, mf_scratch, r * D, np,
                                  per * D, per * D, false, &co))) co_return rc;
       t_in_dense = co.done;
+      if (co.staged && (rc = t_from_stages(co, 0, np, valid, 0))) co_return rc;
     }
   } else {
     hipError_t e = launch_matmul_bcast(HV(0, hT), kappa * D, per * D, in->A->view(in->a_off), HV(0, hS), D, r * D, per * D, np,
@@ -462,8 +488,8 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
       LAB_HIPC(c, e);
     }
   }
-  if (t_in_dense && t_chunk < np) {
-    // (every slice was finished above)
+  if (t_done || (t_in_dense && t_chunk < np)) {
+    // (finished above: from the staging arrays, or slice by slice)
   } else if (t_in_dense) {   // the inverse transform already ran from the GEMM's staging array: only the CRT is left
     const int basis = a8d ? bdig : 0;
     // ... and the decomposition of t (its digits in [i][k][rho] order), in the same pass when they have the 16-bit form

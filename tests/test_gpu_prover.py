@@ -398,6 +398,37 @@ def test_t_chain_in_slices_of_the_batch():
     ctx.close()
 
 
+@pytest.mark.parametrize("nb,r,kappa", [(3, 17, 37), (2, 5, 33), (4, 20, 70), (6, 32, 96), (2, 9, 64)])
+def test_t_from_the_staging_arrays_of_every_limb(nb, r, kappa):
+    # t = A S of a batch leaves the matrix cores in one slot-major staging array per limb; k_stage_to_coeffs turns them into t mod q
+    # and its digits in one pass (inverse transform of each limb by a wave of its own, CRT from LDS).  Ragged cases: rows not a
+    # multiple of 32 (padded staging rows), fewer valid sets than the padded 8 / 16 / 32, unpaired (odd, or fewer than 32 columns) and
+    # paired jobs.  Every field == the multiply-add path; t and u_1 of the last proof == the oracle.
+    import labrador_snark_amd as lab
+    q, n, kappa1 = Q_REF33, 3, 7
+    ctx = lab.Context(q, 0, **ctx_kw(q))
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
+    crs = lab.ResidentCRS(ctx, k, compact=True, mfma_basis=True).fill_synthetic(1000)
+    ws, sts, tapes = [], [], []
+    want_last = None
+    for j in range(nb):
+        case, (S, phi, a, tape) = cases.oracle_case(p, seed=900 + j)
+        ws.append(S); sts.append(lab.State(phi, a, case.b_prime)); tapes.append(tape)
+        if j == nb - 1:
+            want_last = case.prove()
+    ref = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes)
+    crs.pack_mfma()
+    got = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes)
+    assert ctx.prove_flags() & 1
+    for j in range(nb):
+        for f in ("t_i_all", "g_mat", "h_mat", "u_1", "u_2", "z", "b_prime_prime", "projection_int"):
+            assert np.array_equal(getattr(got[j], f), getattr(ref[j], f)), (j, f)
+    assert np.array_equal(got[-1].t_i_all, want_last["t"]) and np.array_equal(got[-1].u_1, want_last["u1"])
+    crs.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("mfma_basis", [False, True])
 @pytest.mark.parametrize("nb", [2, 4, 5])
 def test_prove_core_batch_matrix_cores_r32(nb, mfma_basis):
