@@ -5,7 +5,10 @@ multiply-add kernels on unpacked matrices, packed matrices in the main or in the
 seed inside the call — and compares every transcript field of every proof with the multiply-add run and the whole
 transcript of one proof with the oracle's Prover::proof_gen restatement (src/proofgen.rs:30-427).
 
-    python tools/fuzz_prover.py [seed] [iterations]
+    python tools/fuzz_prover.py [seed] [iterations] [large]
+
+`large`: shapes that span several row tiles / k-tiles / row groups of the matrix-core kernels (n up to 70, kappa up to 300,
+kappa1 up to 150), bounded so that the oracle's proof of one instance stays within a second or two.
 """
 import os
 import sys
@@ -25,6 +28,7 @@ ORACLE = {"t_i_all": "t", "g_mat": "G", "h_mat": "H", "u_1": "u1", "u_2": "u2", 
 def main():
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    large = len(sys.argv) > 3
     rng = np.random.default_rng(seed)
     qs = [(1 << 32) + 15, 1073738753, 4294966657, 1073741953, 8191]   # three limbs; one 30-bit limb; single-limb strict-32 (two); the default Q
     bad = 0
@@ -33,6 +37,13 @@ def main():
         n, r = int(rng.integers(1, 7)), int(rng.choice([1, 2, 5, 8, 9, 16, 17, 24, 32, 33, 40]))
         kappa, kappa1 = int(rng.integers(1, 100)), int(rng.integers(1, 40))
         nb = int(rng.choice([1, 2, 3, 4, 5, 8, 66, 70]))
+        if large:
+            while True:
+                n, r = int(rng.integers(1, 71)), int(rng.choice([2, 8, 17, 32]))
+                kappa, kappa1 = int(rng.integers(1, 301)), int(rng.integers(1, 151))
+                if r * 3 * kappa1 * kappa + kappa * n * r + r * r * n < 1200000:
+                    break
+            nb = int(rng.choice([1, 2, 3, 5]))
         if nb > 8:                       # several sub-batches: keep the instances small
             n, r, kappa, kappa1 = min(n, 2), min(r, 5), min(kappa, 9), min(kappa1, 6)
         mode = int(rng.integers(0, 4))   # 0: packed, main basis; 1: packed, digit basis; 2: digit basis, no main-basis A; 3: B from the seed
