@@ -186,6 +186,13 @@ static void build_crt_table(uint64_t q, int nlimbs, const uint32_t* primes, CrtT
   u128 worst = primes[0];
   for (int a = 1; a < nlimbs; a++) worst += (u128)(primes[a] - 1) * (q - 1);
   t->lazy_sum = worst < ((u128)1 << 63) ? 1u : 0u;
+  bool one_size = nlimbs == 3 && t->lazy_sum && q >= (1ull << 24);
+  for (int a = 0; a < nlimbs && one_size; a++) {
+    if (primes[a] >= (1u << 30)) one_size = false;
+    for (int b = 0; b < a; b++)
+      if (primes[b] >= 2 * (uint64_t)primes[a]) one_size = false;
+  }
+  t->fast3 = one_size ? 1u : 0u;
 }
 
 // ------------------------------------------------------------- context

@@ -48,6 +48,8 @@ struct CrtTable {
   double inv_p[MAX_LIMBS];
   // sum_a (p_a - 1) * (q - 1) + max p < 2^63: the mixed-radix digits times the prefixes can be summed in 64 bits before the one mod q
   uint32_t lazy_sum;
+  // three limbs of one size (p_b < 2 p_a, all below 2^30), lazy_sum and q >= 2^24: the straight-line form crt3_fast (ntt_kernels.hip)
+  uint32_t fast3;
 };
 
 // ---- ntt_kernels.hip

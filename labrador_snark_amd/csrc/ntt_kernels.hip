@@ -392,6 +392,95 @@ __device__ __forceinline__ uint64_t crt_one(const uint32_t (&r)[L], const CrtTab
   return acc;
 }
 
+// crt_one<3> for limbs of one size (CrtTable.fast3), straight-line: the differences of the Garner recurrence are kept positive by
+// adding 2p (every digit of an earlier limb is below 2p of a later one, and Shoup's product takes any 32-bit operand), the
+// mixed-radix sum is below 2^63 with a quotient by q below 2^32 (one double multiply, off by one at most in either direction).
+struct Crt3K {
+  uint32_t p1, p2, g10, g10s, g20, g20s, g21, g21s, h0, h1, h2;
+  uint64_t P1, P2, q, mm;
+  double inv_q;
+};
+__device__ __forceinline__ Crt3K crt3_load(const CrtTable* __restrict__ crt) {
+  Crt3K k;
+  k.p1 = crt->p[1]; k.p2 = crt->p[2];
+  k.g10 = crt->ginv[1][0][0]; k.g10s = crt->ginv[1][0][1];
+  k.g20 = crt->ginv[2][0][0]; k.g20s = crt->ginv[2][0][1];
+  k.g21 = crt->ginv[2][1][0]; k.g21s = crt->ginv[2][1][1];
+  k.h0 = crt->half_digits[0]; k.h1 = crt->half_digits[1]; k.h2 = crt->half_digits[2];
+  k.P1 = crt->prefix_mod_q[1]; k.P2 = crt->prefix_mod_q[2]; k.q = crt->q; k.mm = crt->m_mod_q; k.inv_q = crt->inv_q;
+  return k;
+}
+__device__ __forceinline__ uint64_t crt3_fast(uint32_t r0, uint32_t r1, uint32_t r2, const Crt3K& k) {
+  const uint32_t d0 = r0;
+  const uint32_t d1 = csub(mul_shoup_lazy(r1 + 2 * k.p1 - d0, k.g10, k.g10s, k.p1), k.p1);
+  const uint32_t t = mul_shoup_lazy(r2 + 2 * k.p2 - d0, k.g20, k.g20s, k.p2);              // [0, 2 p2)
+  const uint32_t d2 = csub(mul_shoup_lazy(t + 2 * k.p2 - d1, k.g21, k.g21s, k.p2), k.p2);
+  const bool neg = d2 > k.h2 || (d2 == k.h2 && (d1 > k.h1 || (d1 == k.h1 && d0 > k.h0)));
+  const uint64_t acc = (uint64_t)d0 + (uint64_t)d1 * k.P1 + (uint64_t)d2 * k.P2;
+  const uint32_t qh = (uint32_t)((double)acc * k.inv_q);
+  int64_t r = (int64_t)(acc - (uint64_t)qh * k.q);
+  r += r < 0 ? (int64_t)k.q : 0;
+  r -= r >= (int64_t)k.q ? (int64_t)k.q : 0;
+  uint64_t v = (uint64_t)r;
+  if (neg) v = v >= k.mm ? v - k.mm : v + k.q - k.mm;
+  return v;
+}
+// one step of the decomposition when the quotient fits 32 bits: v = quot * b + r0, by one double multiply (off by one at most)
+__device__ __forceinline__ uint32_t divmod_by_double(uint64_t v, uint32_t b, double inv_b, uint32_t* quot) {
+  uint32_t qh = (uint32_t)((double)v * inv_b);
+  uint32_t r0 = (uint32_t)v - qh * b;                      // the true remainder lies in [-b, 2b): 32-bit wrap-around is harmless
+  { const bool f = (int32_t)r0 < 0; r0 += f ? b : 0; qh -= f; }
+  { const bool f = r0 >= b; r0 -= f ? b : 0; qh += f; }
+  *quot = qh;
+  return r0;
+}
+__device__ __forceinline__ uint32_t divmod_by_double(uint32_t v, uint32_t b, double inv_b, uint32_t* quot) {
+  uint32_t qh = (uint32_t)((double)v * inv_b);
+  uint32_t r0 = v - qh * b;
+  { const bool f = (int32_t)r0 < 0; r0 += f ? b : 0; qh -= f; }
+  { const bool f = r0 >= b; r0 -= f ? b : 0; qh += f; }
+  *quot = qh;
+  return r0;
+}
+// the digits of four values (decompose_polynomial_vec, src/util.rs:360-442, as in k_decompose_u16x4) to o + k * kstride, k < exp.
+// fdiv: every quotient fits 32 bits ((q >> 32) < base).
+__device__ __forceinline__ void digits_of_quad(uint64_t (&v)[4], uint16_t* __restrict__ o, size_t kstride, int exp, uint32_t b32, uint32_t bm,
+                                               uint64_t half, bool fdiv) {
+  if (fdiv) {
+    const double inv_b = 1.0 / (double)b32;
+    const uint32_t h32 = (uint32_t)half;
+    uint32_t w[4], d[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const uint32_t r0 = divmod_by_double(v[c], b32, inv_b, &w[c]);
+      d[c] = r0 > h32 ? b32 - r0 : r0;
+    }
+    *reinterpret_cast<uint2*>(o) = make_uint2(d[0] | (d[1] << 16), d[2] | (d[3] << 16));
+    for (int k = 1; k < exp; k++) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const uint32_t r0 = divmod_by_double(w[c], b32, inv_b, &w[c]);
+        d[c] = r0 > h32 ? b32 - r0 : r0;
+      }
+      *reinterpret_cast<uint2*>(o + (size_t)k * kstride) = make_uint2(d[0] | (d[1] << 16), d[2] | (d[3] << 16));
+    }
+    return;
+  }
+  for (int k = 0; k < exp; k++) {
+    uint32_t d[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      // v = qq*b + r0.  The reference continues with (v - r) / b, r = r0 or b - r0: that is qq in both cases (r0 > b/2 gives
+      // (qq - 1)*b + 2*r0 with b < 2*r0 < 2b), and v - r never wraps mod q here (base <= q): one division per digit
+      uint64_t qq;
+      const uint32_t r0 = divmod_u40_u16((uint32_t)(v[c] >> 32), (uint32_t)v[c], b32, bm, &qq);
+      d[c] = r0 > half ? b32 - r0 : r0;
+      v[c] = qq;
+    }
+    *reinterpret_cast<uint2*>(o + (size_t)k * kstride) = make_uint2(d[0] | (d[1] << 16), d[2] | (d[3] << 16));
+  }
+}
+
 // Four coefficients per thread (16-byte loads per limb, 32 bytes out).  DIG: the value is also decomposed on the spot
 // (decompose_polynomial_vec, src/util.rs:360-442, in the library-internal form of k_decompose_u16x4: 16-bit digits, base below
 // 2^16 and not above q) — the digits of t = A s leave with t itself, its coefficients are not read back.
@@ -406,6 +495,9 @@ k_crt_to_u64(const uint32_t* __restrict__ src, size_t src_ps, const JobPtrs dstp
   const double inv_q = crt->inv_q;
   const uint32_t b32 = dg.base, bm = DIG ? (uint32_t)(0x100000000ull / dg.base) : 0;
   const uint64_t half = DIG ? (dg.base / 2) % q : 0;
+  const bool fast3 = L == 3 && crt->fast3 != 0, fdiv = DIG && (q >> 32) < dg.base;   // (uniform)
+  Crt3K k3{};
+  if (L == 3 && fast3) k3 = crt3_load(crt);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < nquads; i += stride) {
@@ -417,8 +509,18 @@ k_crt_to_u64(const uint32_t* __restrict__ src, size_t src_ps, const JobPtrs dstp
       r[0][l] = v.x; r[1][l] = v.y; r[2][l] = v.z; r[3][l] = v.w;
     }
     uint64_t v[4];
+    if constexpr (L == 3) {
+      if (fast3) {
 #pragma unroll
-    for (int c = 0; c < 4; c++) v[c] = crt_one<L>(r[c], crt, q, inv_q);
+        for (int c = 0; c < 4; c++) v[c] = crt3_fast(r[c][0], r[c][1], r[c][2], k3);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; c++) v[c] = crt_one<L>(r[c], crt, q, inv_q);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; c++) v[c] = crt_one<L>(r[c], crt, q, inv_q);
+    }
     ulonglong2 o0, o1;
     o0.x = v[0]; o0.y = v[1]; o1.x = v[2]; o1.y = v[3];
     reinterpret_cast<ulonglong2*>(coeffs)[2 * i] = o0;
@@ -427,19 +529,7 @@ k_crt_to_u64(const uint32_t* __restrict__ src, size_t src_ps, const JobPtrs dstp
       const size_t w0 = i * 4;
       const uint32_t e = (uint32_t)(w0 / D), g = (uint32_t)dg.group, eg = e / g;
       uint16_t* const o = digits + ((size_t)eg * dg.exp * g + (e - eg * g)) * D + w0 % D;
-      for (int k = 0; k < dg.exp; k++) {
-        uint32_t d[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          // v = qq*b + r0.  The reference continues with (v - r) / b, r = r0 or b - r0: that is qq in both cases (r0 > b/2 gives
-          // (qq - 1)*b + 2*r0 with b < 2*r0 < 2b), and v - r never wraps mod q here (base <= q): one division per digit
-          uint64_t qq;
-          const uint32_t r0 = divmod_u40_u16((uint32_t)(v[c] >> 32), (uint32_t)v[c], b32, bm, &qq);
-          d[c] = r0 > half ? b32 - r0 : r0;
-          v[c] = qq;
-        }
-        *reinterpret_cast<uint2*>(o + (size_t)k * g * D) = make_uint2(d[0] | (d[1] << 16), d[2] | (d[3] << 16));
-      }
+      digits_of_quad(v, o, (size_t)g * D, dg.exp, b32, bm, half, fdiv);
     }
   }
 }
@@ -479,6 +569,9 @@ k_stage_to_coeffs(const uint32_t* __restrict__ stage, size_t stage_ps, unsigned 
   const double inv_q = crt->inv_q;
   const uint32_t b32 = dg.base, bm = DIG ? (uint32_t)(0x100000000ull / dg.base) : 0;
   const uint64_t half = DIG ? (dg.base / 2) % q : 0;
+  const bool fast3 = L == 3 && crt->fast3 != 0, fdiv = DIG && (q >> 32) < dg.base;   // (uniform)
+  Crt3K k3{};
+  if (L == 3 && fast3) k3 = crt3_load(crt);
   const unsigned sub = ns / nsub;
 #pragma unroll 1
   for (int i = 0; i < 4; i++) {
@@ -493,8 +586,18 @@ k_stage_to_coeffs(const uint32_t* __restrict__ stage, size_t stage_ps, unsigned 
       r[0][l] = v.x; r[1][l] = v.y; r[2][l] = v.z; r[3][l] = v.w;
     }
     uint64_t v[4];
+    if constexpr (L == 3) {
+      if (fast3) {
 #pragma unroll
-    for (int c = 0; c < 4; c++) v[c] = crt_one<L>(r[c], crt, q, inv_q);
+        for (int c = 0; c < 4; c++) v[c] = crt3_fast(r[c][0], r[c][1], r[c][2], k3);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; c++) v[c] = crt_one<L>(r[c], crt, q, inv_q);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; c++) v[c] = crt_one<L>(r[c], crt, q, inv_q);
+    }
     const unsigned proof = blockIdx.y * sub + s / nsub;
     const size_t e = (size_t)sl * set_stride + row;          // polynomial of the proof's result
     const unsigned w0 = quad * 4;                           // first of the four coefficients
@@ -506,17 +609,7 @@ k_stage_to_coeffs(const uint32_t* __restrict__ stage, size_t stage_ps, unsigned 
     if constexpr (DIG) {
       const size_t g = dg.group, eg = e / g;
       uint16_t* const o = static_cast<uint16_t*>(dg.out16.p[proof]) + (eg * dg.exp * g + (e - eg * g)) * D + w0;
-      for (int k = 0; k < dg.exp; k++) {
-        uint32_t d[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {   // (see k_crt_to_u64)
-          uint64_t qq;
-          const uint32_t r0 = divmod_u40_u16((uint32_t)(v[c] >> 32), (uint32_t)v[c], b32, bm, &qq);
-          d[c] = r0 > half ? b32 - r0 : r0;
-          v[c] = qq;
-        }
-        *reinterpret_cast<uint2*>(o + (size_t)k * g * D) = make_uint2(d[0] | (d[1] << 16), d[2] | (d[3] << 16));
-      }
+      digits_of_quad(v, o, g * D, dg.exp, b32, bm, half, fdiv);
     }
   }
 }
