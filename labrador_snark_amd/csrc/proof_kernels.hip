@@ -803,8 +803,9 @@ k_pi_mfma(const JobPtrs projp, const JobPtrs Wp, const JobPtrs Pip, const JobPtr
     if (kq < 2) {
 #pragma unroll
       for (int c = 0; c < CT; c++) {
-        const long long part = kq == 0 ? (long long)acc[c][0] + (long long)acc[c][1] * 128 + (long long)acc[c][2] * 16384 + (long long)acc[c][3] * 2097152
-                                       : (long long)acc[c][0] * 268435456LL + (long long)acc[c][1] * 34359738368LL;
+        // |acc| <= 256 * 127 < 2^15: three limbs (kq = 0) and two limbs (kq = 1) combine in 32 bits
+        const int low = acc[c][0] + (acc[c][1] << 7) + (kq == 0 ? acc[c][2] << 14 : 0);
+        const long long part = kq == 0 ? (long long)low + ((long long)acc[c][3] << 21) : (long long)low << 28;
         wpart[(c * 2 + kq) * 16 + cc] = part;
       }
     }
@@ -816,9 +817,10 @@ k_pi_mfma(const JobPtrs projp, const JobPtrs Wp, const JobPtrs Pip, const JobPtr
       if (ct0 + c < ctiles) {
         const long long v = wpart[(c * 2) * 16 + c16] + wpart[(c * 2 + 1) * 16 + c16];     // sum_m omega[m] * Pi[m][col], |v| < 2^49
         const uint64_t mag = mod_u64_near((uint64_t)(v < 0 ? -v : v), q, inv_q);
-        const uint64_t u = v < 0 ? (mag == 0 ? 0 : q - mag) : mag;
         const size_t col = (ct0 + c) * 16 + c16, x = col / D, k = col % D;
-        W[(x * r + i) * D + (k == 0 ? 0 : D - k)] = k == 0 ? u : (u == 0 ? 0 : q - u);
+        // coefficient k of the column lands at D - k with its sign flipped (k = 0 stays): one sign for both
+        const bool minus = (v < 0) != (k != 0);
+        W[(x * r + i) * D + (k == 0 ? 0 : D - k)] = (minus && mag != 0) ? q - mag : mag;
       }
     }
   }
