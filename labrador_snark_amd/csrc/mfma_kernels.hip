@@ -1007,12 +1007,12 @@ k_gemm_i8_w3(const Gemm8Args a) {
   }
 }
 
-// recombination of one job's 18 accumulator tiles (see k_gemm_i8_w3p) into the slot-major staging array (the kernel is only
-// launched for many jobs, which always go through it).  SMALL: sums of at most 2^15 terms over a 23-bit prime — the equal-weight
-// tiles add up in 32 bits, the five weights carry the Montgomery factor (pwm[e] = 256^e * 2^32 mod p), so ONE reduction of the
-// lifted 64-bit sum gives the residue.
+// recombination of one job's accumulator tiles (see k_gemm_i8_w3p) into the slot-major staging array (the kernel is only
+// launched for many jobs, which always go through it).  SMALL: sums of at most 2^15 terms over a 23-bit prime — the products of
+// equal weight were added up by the matrix instructions themselves (10 tiles: weight w, half h), the five weights carry the
+// Montgomery factor (pwm[e] = 256^e * 2^32 mod p), so ONE reduction of the lifted 64-bit sum gives the residue.
 template <int NT, bool SMALL>
-__device__ __forceinline__ void w3p_recombine(const i32x16_t (&acc)[3 * NT], const Gemm8Args& a, unsigned job, unsigned j, unsigned rt, int lane,
+__device__ __forceinline__ void w3p_recombine(const i32x16_t (&acc)[SMALL ? 5 * (NT / 3) : 3 * NT], const Gemm8Args& a, unsigned job, unsigned j, unsigned rt, int lane,
                                               uint32_t p, uint32_t p2, uint32_t pinv, uint32_t r2, const uint32_t (&pw)[5], uint64_t lift) {
   constexpr int HALVES = NT / 3;
   const unsigned ns = a.ns, rt_count = a.rt_count;
@@ -1026,14 +1026,10 @@ __device__ __forceinline__ void w3p_recombine(const i32x16_t (&acc)[3 * NT], con
 #pragma unroll
     for (int e = 0; e < 16; e++) {
       if constexpr (SMALL) {
-        const int32_t d00 = acc[0 * NT + 0 * HALVES + h][e], d01 = acc[0 * NT + 1 * HALVES + h][e], d02 = acc[0 * NT + 2 * HALVES + h][e];
-        const int32_t d10 = acc[1 * NT + 0 * HALVES + h][e], d11 = acc[1 * NT + 1 * HALVES + h][e], d12 = acc[1 * NT + 2 * HALVES + h][e];
-        const int32_t d20 = acc[2 * NT + 0 * HALVES + h][e], d21 = acc[2 * NT + 1 * HALVES + h][e], d22 = acc[2 * NT + 2 * HALVES + h][e];
-        int64_t s64 = (int64_t)lift + (int64_t)d00 * (int32_t)pw[0];
-        s64 += (int64_t)(d01 + d10) * (int32_t)pw[1];
-        s64 += (int64_t)(d02 + d11 + d20) * (int32_t)pw[2];
-        s64 += (int64_t)(d12 + d21) * (int32_t)pw[3];
-        s64 += (int64_t)d22 * (int32_t)pw[4];
+        // tile (w, h) already holds the sum of the products of weight 256^w (the matrix instructions added them up)
+        int64_t s64 = (int64_t)lift;
+#pragma unroll
+        for (int w = 0; w < 5; w++) s64 += (int64_t)acc[w * HALVES + h][e] * (int32_t)pw[w];
         // 0 <= s64 < 2^57: the high word is below 2^25 < 8p
         uint32_t hi = (uint32_t)((uint64_t)s64 >> 32);
         hi = min(hi, hi - 4 * p); hi = min(hi, hi - p2); hi = min(hi, hi - p);
@@ -1043,7 +1039,7 @@ __device__ __forceinline__ void w3p_recombine(const i32x16_t (&acc)[3 * NT], con
 #pragma unroll
         for (int i = 0; i < 3; i++)
 #pragma unroll
-          for (int iv = 0; iv < 3; iv++) s64 += (uint64_t)((uint32_t)acc[i * NT + iv * HALVES + h][e] ^ 0x80000000u) * pw[i + iv];
+          for (int iv = 0; iv < 3; iv++) s64 += (uint64_t)((uint32_t)acc[SMALL ? 0 : i * NT + iv * HALVES + h][e] ^ 0x80000000u) * pw[i + iv];
         uint32_t hi = (uint32_t)(s64 >> 32);
         hi = min(hi, hi - 8 * p); hi = min(hi, hi - 4 * p); hi = min(hi, hi - p2); hi = min(hi, hi - p);
         const uint32_t v = mont_mul(redc64(((uint64_t)hi << 32) | (uint32_t)s64, p, pinv), r2, p, pinv);
@@ -1074,8 +1070,9 @@ __device__ __forceinline__ void w3p_recombine(const i32x16_t (&acc)[3 * NT], con
 //     results of job b are recombined, the A operands (L2 hits: the matrix is shared) are issued at the top of its loop;
 //   * the first k-tile's matrix instructions take 0 as their C operand: the accumulators are never zeroed;
 //   * dispatch, argument loads and address set-up are paid once per block;
-//   * sums of at most 2^15 terms (|D| <= K * 2^14 < 2^29: equal-weight tiles add up in 32 bits) recombine with 4 signed
-//     multiply-adds instead of 9 unsigned ones.
+//   * sums of at most 2^15 terms (|D| <= K * 2^14 < 2^29: three of them add up in 32 bits): the products (plane i, plane i') of
+//     equal weight 256^(i+i') accumulate into ONE tile (the loop variant `merged` of the generator: 10 accumulator tiles
+//     instead of 18, all in accumulation registers), and five signed multiply-adds recombine them instead of 9 unsigned ones.
 // DIAG (lab_ctx_gemm_diag mode 4): every block records shader / constant clock ticks of its whole life and of its K loops alone
 // in diag_buf[4 * block .. + 3]
 template <int NT, bool SMALL, bool DIAG = false>
@@ -1123,13 +1120,22 @@ k_gemm_i8_w3p(const Gemm8Args a) {
   uint64_t bg = bg_of(job0);
   asm volatile(W3P_BISSUE_ASM_NT6 : "+v"(bg) : "s"(m0b), "s"(nstages) : W3P_BISSUE_CLOBBERS);
   for (unsigned job = job0; job < job1; job++) {
-    i32x16_t acc[3 * NT];
+    // SMALL: the products of equal weight add up inside the matrix instructions — tile (i + i', h) instead of (i, i', h), 10 instead of 18
+    i32x16_t acc[SMALL ? 5 * (NT / 3) : 3 * NT];
     uint64_t lt0 = 0, lr0 = 0;
     if constexpr (DIAG) { lt0 = __builtin_amdgcn_s_memtime(); lr0 = __builtin_amdgcn_s_memrealtime(); }
+    if constexpr (SMALL)
+      asm volatile(W3PM_LOOP_ASM_NT6
+                   : "=&a"(acc[0]), "=&a"(acc[1]), "=&a"(acc[2]), "=&a"(acc[3]), "=&a"(acc[4]), "=&a"(acc[5]), "=&a"(acc[6]), "=&a"(acc[7]),
+                     "=&a"(acc[8]), "=&a"(acc[9]), "+v"(bg)
+                   : "s"(a0), "s"(a1), "s"(a2), "v"(voff), "v"(vlds), "s"(m0b), "s"(nstages)
+                   : W3_LOOP_CLOBBERS_NT6_PLAIN);
+    else
     asm volatile(W3P_LOOP_ASM_NT6
                  : "=&a"(acc[0]), "=&a"(acc[1]), "=&a"(acc[2]), "=&a"(acc[3]), "=&a"(acc[4]), "=&a"(acc[5]), "=&a"(acc[6]), "=&a"(acc[7]),
-                   "=&a"(acc[8]), "=&a"(acc[9]), "=&a"(acc[10]), "=&a"(acc[11]), "=&a"(acc[12]), "=&a"(acc[13]), "=&a"(acc[14]),
-                   "=&a"(acc[15]), "=&v"(acc[16]), "=&v"(acc[17]), "+v"(bg)
+                   "=&a"(acc[8]), "=&a"(acc[9]), "=&a"(acc[SMALL ? 0 : 10]), "=&a"(acc[SMALL ? 0 : 11]), "=&a"(acc[SMALL ? 0 : 12]),
+                   "=&a"(acc[SMALL ? 0 : 13]), "=&a"(acc[SMALL ? 0 : 14]), "=&a"(acc[SMALL ? 0 : 15]), "=&v"(acc[SMALL ? 0 : 16]),
+                   "=&v"(acc[SMALL ? 0 : 17]), "+v"(bg)
                  : "s"(a0), "s"(a1), "s"(a2), "v"(voff), "v"(vlds), "s"(m0b), "s"(nstages)
                  : W3_LOOP_CLOBBERS_NT6_PLAIN);
     if constexpr (DIAG) { d_loop_t += __builtin_amdgcn_s_memtime() - lt0; d_loop_r += __builtin_amdgcn_s_memrealtime() - lr0; }

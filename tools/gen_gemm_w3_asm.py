@@ -31,14 +31,25 @@ KS, RING, PF = 2, 4, 3
 RING0, FR0 = 120, 216
 
 
-def gen(NT, nt_loads, mode="full", persistent=False):
+def gen(NT, nt_loads, mode="full", persistent=False, merged=False):
     """mode: "full"; the diagnostic variants "noload" (no global loads / LDS-DMA: the multiply side alone) and "nomfma"
     (no matrix instructions or LDS reads: the load side alone) keep everything else — waits, barriers, address updates.
     persistent: the loop of a block that works off several jobs (k_gemm_i8_w3p) — the B stages 0..2 of the job were issued by
     gen_bissue()'s block BEFORE the previous job's results were recombined (LDS-DMA: no register is in flight while the
     compiler's code runs), so the prologue here issues the A operands only; the first k-tile's matrix instructions take 0 as
-    their C operand (the accumulators are never zeroed)."""
-    nacc = 3 * NT
+    their C operand (the accumulators are never zeroed).
+    merged (persistent only): products of equal weight share an accumulator tile — (matrix plane i, vector plane i') adds into tile
+    (i + i', half h), operand (i + i') * NT/3 + h: 5 * NT/3 tiles instead of 3 * NT.  For sums short enough that three tile entries
+    add up in 32 bits (the caller checks); the recombination then has five terms instead of nine."""
+    halves = NT // 3
+    nacc = 5 * halves if merged else 3 * NT
+
+    def acc_of(i, n):
+        if not merged:
+            return i * NT + n
+        iv, h = divmod(n, halves)
+        return (i + iv) * halves + h
+    fresh = set()                  # merged + first: tiles that have received their first product
     pieces = KS * NT
     ppw = (pieces + 3) // 4
     slot_bytes = pieces * 1024
@@ -108,8 +119,12 @@ def gen(NT, nt_loads, mode="full", persistent=False):
             emit("s_waitcnt lgkmcnt(%d)" % (PF - 1))
             for i in range(3):
                 if mode != "nomfma":
-                    c_op = "0" if (first and ks == 0) else "%%%d" % (i * NT + n)
-                    emit("v_mfma_i32_32x32x32_i8 %%%d, %s, %s, %s" % (i * NT + n, ring(k, ks, i), fr(f % PF), c_op))
+                    t_ = acc_of(i, n)
+                    zero_c = first and ks == 0 and (not merged or t_ not in fresh)
+                    if first and ks == 0:
+                        fresh.add(t_)
+                    c_op = "0" if zero_c else "%%%d" % t_
+                    emit("v_mfma_i32_32x32x32_i8 %%%d, %s, %s, %s" % (t_, ring(k, ks, i), fr(f % PF), c_op))
             nxt = f + PF
             if mode == "nomfma":
                 pass
@@ -213,6 +228,12 @@ def main():
     # the persistent-block variant (k_gemm_i8_w3p: many jobs share the matrix): plain A loads, 64 sets
     L, clob = gen(6, 0, persistent=True)
     out.append("#define W3P_LOOP_ASM_NT6 \\")
+    for k, ins in enumerate(L):
+        out.append('    "%s\\n\\t"%s' % (ins, " \\" if k + 1 < len(L) else ""))
+    out.append("")
+    # ... with the products of equal weight sharing an accumulator tile (10 tiles)
+    L, clob = gen(6, 0, persistent=True, merged=True)
+    out.append("#define W3PM_LOOP_ASM_NT6 \\")
     for k, ins in enumerate(L):
         out.append('    "%s\\n\\t"%s' % (ins, " \\" if k + 1 < len(L) else ""))
     out.append("")
