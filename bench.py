@@ -354,7 +354,7 @@ def host_chacha_rate(q, seconds=4.0):
     return cores * reps * n0 / dt, cores, dt
 
 
-def config3_streamed(lab, dev, q, n, r, kappa, inputs, b1_s_per_proof_k1024=None, with_cpu=True, proofs=(192, 160, 128, 96, 64)):
+def config3_streamed(lab, dev, q, n, r, kappa, inputs, b1_s_per_proof_k1024=None, with_cpu=True, proofs=(256, 224, 192, 160, 128, 96, 64)):
     """SURVEY section 8(d) config 3 at the contract's commitment rank: kappa = kappa1 = kappa2 = 2^14 (the floor BASELINE.md names;
     the reference hard-wires n*d = 2^16, src/constants.rs:237-239).  One B_ik is 2^28 ring elements, the 96 of them 6 TiB as byte
     planes: B is STREAMED — regenerated from the ChaCha20 seed inside the step (CRS::fetch_B_ik_row, src/structs.rs:74-88,
@@ -364,7 +364,7 @@ def config3_streamed(lab, dev, q, n, r, kappa, inputs, b1_s_per_proof_k1024=None
     k = lab.RuntimeConstants(q, n, r, kappa, kappa, kappa)
     rec = None
     # as many proofs per pass over the regenerated rows as the 288 GB hold (a call of more than 64 proofs shares ONE pass among its
-    # sub-batches of 64; 1.15 GB of workspace per proof at kappa = 2^14): the first size that fits
+    # sub-batches of 64; 0.23 GB of workspace, 0.27 GB of t and 0.16 GB of inputs per proof at kappa = 2^14): the first size that fits
     failed = []
     for nbatch in proofs:
         rec = _config3_streamed_once(lab, dev, q, n, r, kappa, k, inputs, nbatch)

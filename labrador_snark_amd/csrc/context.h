@@ -231,7 +231,7 @@ int gram_mfma_impl(lab_ctx* c, const lab_mat8* m, int nops, const HatView* outs,
 // B-operand tiles of every limb straight from 16-bit decomposition digits (to_hat + packing fused, mfma_kernels.hip);
 // hand the buffer to matvec_mfma_impl as `prepacked` (njobs = 1)
 size_t mfma_prepacked_bytes(const lab_mat8* m, int ns);
-int digits_to_v8_impl(lab_ctx* c, const lab_mat8* m, const JobPtrs& src16, int ns, int ns_valid, int8_t* dst);
+int digits_to_v8_impl(lab_ctx* c, const lab_mat8* m, const JobPtrs& src16, int ns, int ns_valid, int8_t* dst, const DigitsFromT* dt = nullptr);
 uint32_t mat8_min_prime(const lab_ctx* c, const lab_mat8* m);
 // the outer commitment with the matrices streamed from the CRS seed (crs_stream.hip)
 struct CrsStream;
@@ -254,6 +254,9 @@ struct CrsGroup {
   const JobPtrs* dig; const ConstHatView* V; size_t v_set_stride;
   int ns, ns_valid;
   void* scratch;
+  // instead of dig: the sets' 64-bit coefficient vectors whose digits are the operand (t64->p[s], see DigitsFromT; dt.m0 is set per chunk)
+  const JobPtrs* t64 = nullptr;
+  DigitsFromT dt{};
 };
 int crs_stream_run(CrsStream* st, const uint8_t seed[32], const uint64_t* mat_offsets, size_t nmat, const CrsGroup* groups, size_t ngroups);
 uint32_t basis_min_prime(const lab_ctx* c, int basis);

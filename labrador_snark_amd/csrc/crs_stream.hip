@@ -226,7 +226,7 @@ int crs_stream_run(CrsStream* st, const uint8_t seed[32], const uint64_t* mat_of
   bool multi = ngroups >= 2 && st->stage && st->reduce;
   int ns_valid_max = 0;
   for (size_t g = 0; g < ngroups && multi; g++) {
-    multi = groups[g].dig && (size_t)groups[g].ns == st->ns &&
+    multi = (groups[g].dig || groups[g].t64) && (size_t)groups[g].ns == st->ns &&
             static_cast<char*>(groups[g].scratch) - static_cast<char*>(groups[0].scratch) ==
                 (ptrdiff_t)g * (static_cast<char*>(groups[1].scratch) - static_cast<char*>(groups[0].scratch)) &&
             static_cast<char*>(groups[1].scratch) > static_cast<char*>(groups[0].scratch);
@@ -243,11 +243,18 @@ int crs_stream_run(CrsStream* st, const uint8_t seed[32], const uint64_t* mat_of
       if (!tiles_made)
         for (size_t gi = 0; gi < ngroups; gi++) {
           const CrsGroup& G = groups[gi];
-          if (!G.dig) continue;
+          if (!G.dig && !G.t64) continue;
+          PhaseSample ps(c, PH_DIGITS, (double)G.ns_valid * mc * cols * D);
+          if (G.t64) {   // the digits of this chunk's matrices straight from the sets' 64-bit vectors
+            DigitsFromT dt = G.dt;
+            dt.m0 = m0;
+            if (dt.kappa != cols) return fail(c, LAB_ERR_ARG, "streamed commitment: digits on the fly need vectors of the matrices' column count");
+            if ((rc = digits_to_v8_impl(c, st->m8, *G.t64, G.ns, G.ns_valid, static_cast<int8_t*>(G.scratch), &dt))) return rc;
+            continue;
+          }
           JobPtrs d;
           for (int s = 0; s < MAX_JOBS; s++)
             d.p[s] = (s < G.ns_valid && G.dig->p[s]) ? static_cast<void*>(static_cast<uint16_t*>(G.dig->p[s]) + m0 * cols * D) : nullptr;
-          PhaseSample ps(c, PH_DIGITS, (double)G.ns_valid * mc * cols * D);
           if ((rc = digits_to_v8_impl(c, st->m8, d, G.ns, G.ns_valid, static_cast<int8_t*>(G.scratch)))) return rc;
         }
       if (multi) {
@@ -265,7 +272,7 @@ int crs_stream_run(CrsStream* st, const uint8_t seed[32], const uint64_t* mat_of
         const size_t dst_ss = direct ? G.out_set_stride : st->R * D;
         if (!multi) {
           PhaseSample ps(c, PH_GEMM, mfma_gemm_bytes(st->m8, ns, ns_valid));
-          if (G.dig || tiles_made) {
+          if (G.dig || G.t64 || tiles_made) {
             if ((rc = matvec_mfma_impl(c, dst, dst_ss, st->m8, ConstHatView(), 0, ns, ns_valid, G.scratch, D, 1, 0, 0, false, nullptr,
                                        static_cast<const int8_t*>(G.scratch)))) return rc;
           } else {   // first slab of the chunk: pack the transform-domain vectors, keep the tiles of every limb for the other slabs

@@ -184,8 +184,13 @@ hipError_t launch_gram_v8(const int8_t* P8a, const int8_t* P8b, const int8_t* S8
                           uint32_t p, const uint32_t* pw, uint32_t bias, const LimbTable* tab, hipStream_t s);
 // 16-bit decomposition digits ([ktotal][64] per set, src16.p[s]) -> transform -> B-operand tiles of every limb
 // (dst + l*limb_stride), see k_digits_to_v8; digits must be below every limb prime
+// launch_digits_to_v8 with the digits made on the fly (dt): src16.p[s] is then the set's t = A s itself ([r][kappa][64] 64-bit
+// coefficients below q), and K position x of the call stands for digit (m0 + x / kappa) % t1 of polynomial
+// ((m0 + x / kappa) / t1) * kappa + x % kappa — the [i][k][rho] order of decompose_polynomial_vec's output (src/util.rs:360-442),
+// whose 16-bit copy (6 bytes per coefficient of t) then never exists.  base below 2^16 and not above q < 2^40.
+struct DigitsFromT { uint32_t base, t1; size_t kappa, m0; uint64_t q; };
 hipError_t launch_digits_to_v8(const JobPtrs& src16, size_t ktotal, int8_t* dst, size_t limb_stride, size_t kt_count, int ns,
-                               int ns_valid, int nlimbs, const LimbTable* tabs, const int* planes, const size_t* nt, hipStream_t s);
+                               int ns_valid, int nlimbs, const LimbTable* tabs, const int* planes, const size_t* nt, hipStream_t s, const DigitsFromT* dt = nullptr);
 // the columns of [n][r] coefficient matrices (64-bit words below q < 2^40, one matrix per proof) -> B-operand tiles of every limb
 // (limb primes below 2^23), ns / 32 proofs per job
 hipError_t launch_coefs_to_v8(const JobPtrs& src64, size_t n, size_t r, int8_t* dst, size_t limb_stride, size_t job_stride, size_t kt_count,

@@ -224,14 +224,14 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
 // B-operand tiles of all limbs of `m` from 16-bit decomposition digits (one job of ns sets: set s at src16.p[s], [K][64]
 // words, K = m's sum length): dst holds mfma_prepacked_bytes(m, ns).  Digits must be below every limb prime of m's basis.
 size_t mfma_prepacked_bytes(const lab_mat8* m, int ns) { return v8_job_bytes(m, ns) * m->nlimbs; }
-int digits_to_v8_impl(lab_ctx* c, const lab_mat8* m, const JobPtrs& src16, int ns, int ns_valid, int8_t* dst) {
+int digits_to_v8_impl(lab_ctx* c, const lab_mat8* m, const JobPtrs& src16, int ns, int ns_valid, int8_t* dst, const DigitsFromT* dt) {
   size_t nt[MAX_LIMBS] = {0, 0, 0, 0};
   for (int l = 0; l < m->nlimbs; l++) nt[l] = nt_for(ns, m->planes[l]);
   const size_t ktotal = m->nmat * m->cols;
   if (m->kt_count * 32 > (ktotal + D - 1) / D * D)   // K tiles past the last 64 digits polynomials are padding: zero once
     LAB_HIP(c, hipMemsetAsync(dst, 0, mfma_prepacked_bytes(m, ns), c->stream));
   LAB_HIP(c, launch_digits_to_v8(src16, ktotal, dst, v8_job_bytes(m, ns), m->kt_count, ns, ns_valid, m->nlimbs,
-                                 m->basis ? c->dg_tabs : c->d_tabs, m->planes, nt, c->stream));
+                                 m->basis ? c->dg_tabs : c->d_tabs, m->planes, nt, c->stream, dt));
   return LAB_OK;
 }
 uint32_t basis_min_prime(const lab_ctx* c, int basis) {

@@ -229,11 +229,13 @@ struct PlaneCounts { int n[MAX_LIMBS]; unsigned nt[MAX_LIMBS]; };   // digit pla
 // columns of proof job * (ns / nsub) + s / nsub per tile set (src.p[proof]; element (x, col) at (x*r + col)*64); every limb
 // prime below 2^29 (reduce_small16).  blockIdx.z = job, its tiles at + job * job_stride of every limb.
 // NSETS = 8 or 4 sets (waves) per block: with 4, two blocks share a CU and one loads while the other transforms.
-template <bool MATRIX64, int NSETS>
+// FROM_T (with !MATRIX64): the digits are made here from the sets' t = A s (DigitsFromT, kernels.h) instead of being read.
+template <bool MATRIX64, int NSETS, bool FROM_T = false>
 __device__ __forceinline__ void digits_to_v8_body(const JobPtrs& src, size_t ktotal, int8_t* __restrict__ dst, size_t limb_stride,
                                                   unsigned kt_count, unsigned ns, unsigned ns_valid, int nlimbs,
                                                   const LimbTable* __restrict__ tabs, const PlaneCounts& planes, unsigned r, unsigned nsub,
-                                                  size_t job_stride) {
+                                                  size_t job_stride, const DigitsFromT& dt = DigitsFromT{}) {
+  static_assert(!FROM_T || !MATRIX64, "digits on the fly: the 16-bit digit form");
   constexpr int ROW = DV_ROW<NSETS>, SB = NSETS == 8 ? 3 : 2;          // log2(NSETS)
   static_assert(NSETS == 8 || NSETS == 4, "8 or 4 sets per block");
   // [slot of the pass][set][k]: writes and reads conflict-free; MATRIX64: first the load tile [set][x][16 coefficients], pitch 36 words
@@ -288,6 +290,36 @@ __device__ __forceinline__ void digits_to_v8_body(const JobPtrs& src, size_t kto
       __syncthreads();
 #pragma unroll
       for (int it = 0; it < 8; it++) cur[it] = nxt[it];
+    }
+  } else if constexpr (FROM_T) {
+    const size_t kpos = k0 + lane;
+    const bool have = s_mine < ns_valid && kpos < ktotal;
+    const size_t mt = dt.m0 + kpos / dt.kappa, rho = kpos % dt.kappa;     // matrix (i, k) = (mt / t1, mt % t1), column rho
+    const unsigned kd = (unsigned)(mt % dt.t1);                          // which digit
+    const uint64_t* p = have ? static_cast<const uint64_t*>(src.p[s_mine]) + ((mt / dt.t1) * dt.kappa + rho) * D : nullptr;
+    const uint32_t b32 = dt.base, bm = (uint32_t)(0x100000000ull / dt.base), half = dt.base / 2;
+    const bool fdiv = (dt.q >> 32) < dt.base;                             // every quotient fits 32 bits (uniform)
+    const double inv_b = 1.0 / (double)dt.base;
+    auto digit = [&](uint64_t v) -> uint32_t {   // digit kd of v (decompose_polynomial_vec: centred remainder, the quotient goes on)
+      uint32_t r0 = 0;
+      if (fdiv) {
+        uint32_t w32;
+        r0 = divmod_by_double(v, b32, inv_b, &w32);
+        for (unsigned j = 0; j < kd; j++) r0 = divmod_by_double(w32, b32, inv_b, &w32);
+      } else {
+        for (unsigned j = 0; j <= kd; j++) {
+          uint64_t qq;
+          r0 = divmod_u40_u16((uint32_t)(v >> 32), (uint32_t)v, b32, bm, &qq);
+          v = qq;
+        }
+      }
+      return r0 > half ? b32 - r0 : r0;
+    };
+#pragma unroll
+    for (int i = 0; i < D / 2; i++) {
+      ulonglong2 v = make_ulonglong2(0, 0);
+      if (have) v = *reinterpret_cast<const ulonglong2*>(p + 2 * i);
+      clo[i] = have ? (digit(v.x) | (digit(v.y) << 16)) : 0u;
     }
   } else {
     const bool have = s_mine < ns_valid && k0 + lane < ktotal;
@@ -371,13 +403,29 @@ k_digits_to_v8<true, 4>(const JobPtrs src, size_t ktotal, int8_t* __restrict__ d
   digits_to_v8_body<true, 4>(src, ktotal, dst, limb_stride, kt_count, ns, ns_valid, nlimbs, tabs, planes, r, nsub, job_stride);
 }
 
+// the digits made on the fly: two waves per SIMD (the 64-bit loads and the divisions want registers; the pass is a thousandth of
+// the streamed step it serves)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_digits_to_v8_from_t(const JobPtrs src, size_t ktotal, int8_t* __restrict__ dst, size_t limb_stride, unsigned kt_count, unsigned ns,
+                      unsigned ns_valid, int nlimbs, const LimbTable* __restrict__ tabs, const PlaneCounts planes, const DigitsFromT dt) {
+  digits_to_v8_body<false, 4, true>(src, ktotal, dst, limb_stride, kt_count, ns, ns_valid, nlimbs, tabs, planes, 0u, 1u, (size_t)0, dt);
+}
+
 // one launch for every limb; sets past ns_valid and polynomials past ktotal come out as zero columns / rows.  K tiles past
 // ceil(ktotal / 64) * 2 (kt_count padding) are NOT written: the caller clears the buffer once.
 hipError_t launch_digits_to_v8(const JobPtrs& src16, size_t ktotal, int8_t* dst, size_t limb_stride, size_t kt_count, int ns,
-                               int ns_valid, int nlimbs, const LimbTable* tabs, const int* planes, const size_t* nt, hipStream_t s) {
+                               int ns_valid, int nlimbs, const LimbTable* tabs, const int* planes, const size_t* nt, hipStream_t s,
+                               const DigitsFromT* dt) {
   if (ns % 8 || ns > 64 || nlimbs > MAX_LIMBS) return hipErrorInvalidValue;
   PlaneCounts pc;
   for (int l = 0; l < MAX_LIMBS; l++) { pc.n[l] = l < nlimbs ? planes[l] : 0; pc.nt[l] = l < nlimbs ? (unsigned)nt[l] : 0; }
+  if (dt) {
+    if (dt->base < 2 || dt->base >= 65536 || (uint64_t)dt->base > dt->q || dt->q >= (1ull << 40) || dt->t1 == 0 || dt->kappa == 0)
+      return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_digits_to_v8_from_t, dim3((unsigned)((ktotal + D - 1) / D), (unsigned)(ns / 4)), dim3(256), 0, s, src16, ktotal, dst,
+                       limb_stride, (unsigned)kt_count, (unsigned)ns, (unsigned)ns_valid, nlimbs, tabs, pc, *dt);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL((k_digits_to_v8<false, 4>), dim3((unsigned)((ktotal + D - 1) / D), (unsigned)(ns / 4)), dim3(256), 0, s, src16, ktotal, dst,
                      limb_stride, (unsigned)kt_count, (unsigned)ns, (unsigned)ns_valid, nlimbs, tabs, pc, 0u, 1u, (size_t)0);
   return hipGetLastError();

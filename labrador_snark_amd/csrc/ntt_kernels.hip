@@ -425,23 +425,6 @@ __device__ __forceinline__ uint64_t crt3_fast(uint32_t r0, uint32_t r1, uint32_t
   if (neg) v = v >= k.mm ? v - k.mm : v + k.q - k.mm;
   return v;
 }
-// one step of the decomposition when the quotient fits 32 bits: v = quot * b + r0, by one double multiply (off by one at most)
-__device__ __forceinline__ uint32_t divmod_by_double(uint64_t v, uint32_t b, double inv_b, uint32_t* quot) {
-  uint32_t qh = (uint32_t)((double)v * inv_b);
-  uint32_t r0 = (uint32_t)v - qh * b;                      // the true remainder lies in [-b, 2b): 32-bit wrap-around is harmless
-  { const bool f = (int32_t)r0 < 0; r0 += f ? b : 0; qh -= f; }
-  { const bool f = r0 >= b; r0 -= f ? b : 0; qh += f; }
-  *quot = qh;
-  return r0;
-}
-__device__ __forceinline__ uint32_t divmod_by_double(uint32_t v, uint32_t b, double inv_b, uint32_t* quot) {
-  uint32_t qh = (uint32_t)((double)v * inv_b);
-  uint32_t r0 = v - qh * b;
-  { const bool f = (int32_t)r0 < 0; r0 += f ? b : 0; qh -= f; }
-  { const bool f = r0 >= b; r0 -= f ? b : 0; qh += f; }
-  *quot = qh;
-  return r0;
-}
 // the digits of four values (decompose_polynomial_vec, src/util.rs:360-442, as in k_decompose_u16x4) to o + k * kstride, k < exp.
 // fdiv: every quotient fits 32 bits ((q >> 32) < base).
 __device__ __forceinline__ void digits_of_quad(uint64_t (&v)[4], uint16_t* __restrict__ o, size_t kstride, int exp, uint32_t b32, uint32_t bm,

@@ -94,6 +94,10 @@ constexpr int REDO_IN_MAIN_BASIS = 1 << 20;   // internal result of a sub-batch 
 struct ProveShared {           // the streamed step 3 the sub-batches of one call share
   std::vector<CrsGroup> groups;
   int rc = LAB_OK;
+  // ... and the dense inverse-transform scratch: the sub-batches enqueue their kernels one after the other on one stream and
+  // nothing in it outlives a launch sequence, so ONE area (the largest any of them needs) at dense_off of the allocation serves
+  // all of them (6 GB per sub-batch at kappa = 2^14)
+  size_t dense_bytes = 0, dense_off = 0;
 };
 #define LAB_HIPC(ctx, expr)                                                                           \
   do {                                                                                                \
@@ -271,7 +275,10 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
 
   // decomposition digits travel between k_decompose / the CRT pass and the transforms as 16-bit words when both bases allow it
   const bool dig16 = in->b1 <= 65536 && in->b2 <= 65536;
-  const size_t tdec_elems = dig16 ? (rk * t1 + 3) / 4 : rk * t1;   // in units of 64 64-bit words
+  // B streamed: the digit tiles of a K chunk are made from t itself (DigitsFromT, kernels.h) — the 16-bit copy of all digits
+  // (6 bytes per coefficient of t: 0.2 GB per proof at kappa = 2^14) is never written, and more proofs fit one pass over B
+  const bool t_digits_lazy = stream_b && fuse_t && dig16 && in->b1 >= 2 && in->b1 < 65536 && (uint64_t)in->b1 <= c->q && c->q < (1ull << 40);
+  const size_t tdec_elems = t_digits_lazy ? 0 : dig16 ? (rk * t1 + 3) / 4 : rk * t1;   // in units of 64 64-bit words
   const size_t coef_elems = rk /*cT*/ + tdec_elems /*cTdec*/ + rr /*cG*/ + pairs /*cGup*/ + pairs * t2 /*cGdec*/ +
                             nr /*cW*/ + rr /*capp*/ + 2 * rr /*cX1, cX2*/ + rr /*cX*/ + rr /*cH*/ +
                             pairs /*cHup*/ + pairs * t1 /*cHdec*/ + k1 /*cu1*/ + k2 /*cu2*/ + n /*cz*/ + 1 /*cbpp*/ +
@@ -287,8 +294,12 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
   const bool t_staged = t_coef_only && r <= 32 && t_limbs >= 2 && t_limbs <= 3 && c->q < (1ull << 40) && kappa < ((size_t)1 << 32) &&
                         (!(in->b1 <= 65536 && in->b2 <= 65536) || (in->b1 >= 2 && in->b1 < 65536 && (uint64_t)in->b1 <= c->q));
   if (t_staged && (size_t)t_limbs * t_stage_ps > dense_words) dense_words = (size_t)t_limbs * t_stage_ps;
+  if (sh && Carver::padded(dense_words * 4) > sh->dense_bytes) {
+    if (!size_only) co_return fail(c, LAB_ERR_ARG, "lab_prove_core: internal: the shared scratch was sized for less");
+    sh->dense_bytes = Carver::padded(dense_words * 4);
+  }
   size_t bytes = Carver::padded((size_t)L * hat_words * 4) + Carver::padded((size_t)Ld * hatd_words * 4) +
-                 Carver::padded(dense_words * 4) +
+                 (sh ? 0 : Carver::padded(dense_words * 4)) +
                  np * (coef_elems * (D * 8) + 32 * 256 /*alignment padding of the carves*/ + 3 * 4096 /*proj*/);
   for (size_t j = 0; j < np; j++) {   // t produced in place in a device-resident caller buffer needs no copy here (268 MB per proof at kappa = 2^14)
     if (outs[j]->t_i_all && is_device_pointer(outs[j]->t_i_all)) bytes -= rk * (size_t)(D * 8);
@@ -322,7 +333,7 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
   uint32_t* hat_base = cv.take<uint32_t>((size_t)L * hat_words);
   uint32_t* hatd_base = cv.take<uint32_t>((size_t)Ld * hatd_words);
   // from_hat scratch: a dense [L][count][64] buffer (its plane stride is count*64, not the arena's)
-  uint32_t* dense_tmp = cv.take<uint32_t>(dense_words);   // job j: + j * max(L, Ld)*tmp_elems*64 words (the t chain: + j * max(L, Ld)*rk*64)
+  uint32_t* dense_tmp = sh ? reinterpret_cast<uint32_t*>(static_cast<char*>(c->scratch) + sh->dense_off) : cv.take<uint32_t>(dense_words);   // job j: + j * max(L, Ld)*tmp_elems*64 words (the t chain: + j * max(L, Ld)*rk*64)
   auto HV = [&](size_t j, size_t off) { return HatView{hat_base + (j * per + off) * D, hat_words}; };
   auto HD = [&](size_t j, size_t off) { return HatView{hatd_base + (j * perd + off) * D, hatd_words}; };
   auto CO = [&](size_t elems) { return cv.take<uint64_t>(elems * D); };
@@ -427,9 +438,9 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
     }
     CrtDigits dg{pd, (uint32_t)in->b1, t1, kappa, q};
     LAB_HIP(c, launch_stage_to_coeffs(co.stage_planes, co.stage_ps, kappa, co.st_rows_pad, co.st_ns, (size_t)valid, co.st_nsub, co.st_jobs, pt, kappa,
-                                      basis_tabs(c, basis), basis_crt(c, basis), basis_nlimbs(c, basis), s, dig16 ? &dg : nullptr));
+                                      basis_tabs(c, basis), basis_crt(c, basis), basis_nlimbs(c, basis), s, dig16 && !t_digits_lazy ? &dg : nullptr));
     t_done = true;
-    if (dig16) t_digits_done = true;
+    if (dig16 && !t_digits_lazy) t_digits_done = true;
     return LAB_OK;
   };
   if (a8d) {  // matrix cores, in the basis of B, C, D (see a8d above): S once more into that basis, its norm summed on the way
@@ -463,7 +474,7 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
           pd.p[i] = i < t_chunk ? jobs[jb + i].cTdec : nullptr;
         }
         CrtDigits dg{pd, (uint32_t)in->b1, t1, kappa, q};
-        LAB_HIPC(c, launch_crt_to_u64_jobs(HatView{dense_tmp, rk * D}, tmp_js_t, pt, rk, basis_crt(c, bdig), Ld, t_chunk, s, &dg));
+        LAB_HIPC(c, launch_crt_to_u64_jobs(HatView{dense_tmp, rk * D}, tmp_js_t, pt, rk, basis_crt(c, bdig), Ld, t_chunk, s, t_digits_lazy ? nullptr : &dg));
         t_digits_done = true;
       }
     }
@@ -494,7 +505,7 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
     const int basis = a8d ? bdig : 0;
     // ... and the decomposition of t (its digits in [i][k][rho] order), in the same pass when they have the 16-bit form
     CrtDigits dg{JP(&Job::cTdec), (uint32_t)in->b1, t1, kappa, q};
-    hipError_t e = dig16 ? launch_crt_to_u64_jobs(HatView{dense_tmp, rk * D}, tmp_js_t, JP(&Job::cT), rk, basis_crt(c, basis),
+    hipError_t e = dig16 && !t_digits_lazy ? launch_crt_to_u64_jobs(HatView{dense_tmp, rk * D}, tmp_js_t, JP(&Job::cT), rk, basis_crt(c, basis),
                                                   basis_nlimbs(c, basis), np, s, &dg)
                          : hipErrorNotSupported;
     if (e == hipSuccess) t_digits_done = true;
@@ -513,7 +524,7 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
     if ((rc = from_hat_jobs(hG, rr, JP(&Job::cG), false))) co_return rc;
   }
   // digits of t in [i][k][rho] order, into the basis of B
-  if (!t_digits_done) LAB_HIPC(c, launch_decompose_jobs(JP(&Job::cTdec), JP(&Job::cT), rk, q, (uint64_t)in->b1, t1, kappa, np, s, dig16));
+  if (!t_digits_done && !t_digits_lazy) LAB_HIPC(c, launch_decompose_jobs(JP(&Job::cTdec), JP(&Job::cT), rk, q, (uint64_t)in->b1, t1, kappa, np, s, dig16));
   if (!fuse_t && (rc = to_hat_jobs(JP(&Job::cTdec), hTdec, rk * t1, true, (uint64_t)in->b1, dig16))) co_return rc;
 
   // ================= step 3 (:101-132) for the whole batch: lhs_j = sum_{i,k} B_ik t_{j,i}^(k); B streamed once per group
@@ -540,8 +551,9 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
     // (np <= MAX_JOBS: one group of vector sets)
     const int ns = np > 32 ? 64 : np > 16 ? 32 : np > 8 ? 16 : 8, valid = (int)np;
     JobPtrs dig;
-    for (int i = 0; i < MAX_JOBS; i++) dig.p[i] = i < valid ? jobs[i].cTdec : nullptr;
-    const CrsGroup grp{HD(0, hlhs), perd * D, &dig, nullptr, 0, ns, valid, mf_scratch};
+    for (int i = 0; i < MAX_JOBS; i++) dig.p[i] = i < valid ? (t_digits_lazy ? jobs[i].cT : jobs[i].cTdec) : nullptr;
+    CrsGroup grp{HD(0, hlhs), perd * D, t_digits_lazy ? nullptr : &dig, nullptr, 0, ns, valid, mf_scratch};
+    if (t_digits_lazy) { grp.t64 = &dig; grp.dt = DigitsFromT{(uint32_t)in->b1, (uint32_t)t1, kappa, 0, q}; }
     if (sh) {   // the driver streams B once for every sub-batch of the call
       sh->groups.push_back(grp);
       co_await std::suspend_always{};
@@ -798,16 +810,17 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
   }
   // ---- B streamed: one pass over the regenerated rows for all sub-batches
   std::vector<size_t> off(nsub + 1, 0);
+  ProveShared sh;
   for (size_t k = 0; k < nsub; k++) {
     const size_t j0 = k * MAX_JOBS;
     size_t need = 0;
-    ProveTask t = prove_batch_co(c, sub_np(k), ins + j0, outs + j0, nullptr, allow_digit_ajtai, nullptr, false, 0, &need);
+    ProveTask t = prove_batch_co(c, sub_np(k), ins + j0, outs + j0, nullptr, allow_digit_ajtai, &sh, false, 0, &need);
     if (!t.done() || t.rc() != LAB_OK) return t.done() ? t.rc() : LAB_ERR_HIP;
     off[k + 1] = off[k] + ((need + 255) & ~(size_t)255);
   }
-  int rc = ensure_scratch(c, off[nsub]);
+  sh.dense_off = off[nsub];
+  int rc = ensure_scratch(c, off[nsub] + sh.dense_bytes);
   if (rc) return rc;
-  ProveShared sh;
   sh.groups.reserve(nsub);
   std::vector<ProveTask> tasks;
   tasks.reserve(nsub);

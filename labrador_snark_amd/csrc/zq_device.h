@@ -411,4 +411,22 @@ __device__ __forceinline__ uint32_t divmod_u40_u16(uint32_t hi, uint32_t lo, uin
 }
 
 
+// one step of the decomposition when the quotient fits 32 bits: v = quot * b + r0, by one double multiply (off by one at most)
+__device__ __forceinline__ uint32_t divmod_by_double(uint64_t v, uint32_t b, double inv_b, uint32_t* quot) {
+  uint32_t qh = (uint32_t)((double)v * inv_b);
+  uint32_t r0 = (uint32_t)v - qh * b;                      // the true remainder lies in [-b, 2b): 32-bit wrap-around is harmless
+  { const bool f = (int32_t)r0 < 0; r0 += f ? b : 0; qh -= f; }
+  { const bool f = r0 >= b; r0 -= f ? b : 0; qh += f; }
+  *quot = qh;
+  return r0;
+}
+__device__ __forceinline__ uint32_t divmod_by_double(uint32_t v, uint32_t b, double inv_b, uint32_t* quot) {
+  uint32_t qh = (uint32_t)((double)v * inv_b);
+  uint32_t r0 = v - qh * b;
+  { const bool f = (int32_t)r0 < 0; r0 += f ? b : 0; qh -= f; }
+  { const bool f = r0 >= b; r0 -= f ? b : 0; qh += f; }
+  *quot = qh;
+  return r0;
+}
+
 }  // namespace lab
