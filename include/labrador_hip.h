@@ -131,7 +131,8 @@ const char *lab_ctx_profile_kernel(const lab_ctx *ctx);
 int lab_ctx_gemm_diag(lab_ctx *ctx, int mode, uint64_t *ticks, size_t words);
 /* how the most recent lab_prove_core[_batch] call ran: 1 = step 1 in the digit basis (lab_prove_input.A8d), 2 = that was tried,
  * a witness exceeded beta_bound and the batch was redone in the main basis; 0 = main basis from the start.  A call with more than
- * 64 proofs runs in sub-batches of 64 and reports the OR of theirs (3: one was redone, another was not). */
+ * 64 proofs runs in sub-batches of 64 and reports the OR of theirs (3: one was redone, another was not), plus 4 when sub-batches
+ * shared ONE pass over B in step 3 (B streamed from the seed, or resident as B8: their digit tiles were the jobs of one launch). */
 int lab_ctx_prove_flags(const lab_ctx *ctx);
 
 /* Digit basis (no reference counterpart; a storage/bandwidth optimisation).  The outer commitments multiply CRS
@@ -374,8 +375,11 @@ int lab_prove_core(lab_ctx *ctx, const lab_prove_input *in, lab_transcript *out)
  * (crs_seed) the B matrices — is issued once per group of proofs: up to 64 per pass over B on the matrix cores (exact int8
  * GEMMs), up to 8 with the multi-set multiply-add kernel when B is only present as residues.  More than 64 proofs run as
  * sub-batches of 64; with B streamed from crs_seed (up to 256 proofs) the sub-batches SHARE one pass over the regenerated rows:
- * each runs steps 1-2, then one streamed step 3 serves all of them, then each finishes — the expansion, ~80 % of such a step,
- * is paid once per call.  Every transcript is bit-identical to what lab_prove_core returns for that proof alone.
+ * each runs steps 1-2, then one streamed step 3 serves all of them, then each finishes — the expansion, ~75 % of such a step,
+ * is paid once per call.  With B resident as B8 (up to 1024 proofs) the full sub-batches share the pass over B the same way:
+ * their digit tiles are the jobs of ONE launch per limb, B comes from HBM once and from L2 for the other jobs (+8 % proofs/s at
+ * 256 proofs per call; lab_ctx_prove_flags() & 4).  Every transcript is bit-identical to what lab_prove_core returns for that
+ * proof alone.
  * status[j] (if status != NULL) receives LAB_OK / LAB_ERR_JL_REJECTED / LAB_ERR_BPP_CHECK for proof j and the call
  * returns LAB_OK; with status == NULL the first failing proof's code is returned. */
 int lab_prove_core_batch(lab_ctx *ctx, size_t nproofs, const lab_prove_input *const *in, lab_transcript *const *out,

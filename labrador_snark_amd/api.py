@@ -109,7 +109,8 @@ class Context:
         return primes, small, (4 * (len(primes) - 1) + 2 if small else 4 * len(primes))
 
     def prove_flags(self):
-        """How the last prove_core[_batch] ran: 1 = step 1 in the digit basis, 2 = tried and redone in the main basis, 0 = main basis."""
+        """How the last prove_core[_batch] ran: 1 = step 1 in the digit basis, 2 = tried and redone in the main basis, 0 = main basis;
+        + 4: sub-batches of a call of more than 64 proofs shared one pass over B."""
         return int(self._lib.lab_ctx_prove_flags(self._h))
 
     def profile_begin(self):

@@ -195,12 +195,16 @@ int matvec_mfma_impl(lab_ctx* c, HatView out, size_t out_set_stride, const lab_m
     if (prof) {
       LAB_HIP(c, hipEventRecord(c->prof_events[c->prof_used++].second, c->stream));
       char kname[48];
-      if (pl == 3 && waves == 4) snprintf(kname, sizeof kname, "k_gemm_i8_w3<%d, %d>", (int)nt, nt == 6 && njobs == 1 ? g.diag : 0);
+      const bool persistent = pl == 3 && waves == 4 && nt == 6 && njobs >= 4;      // (launch_gemm_i8's choice)
+      const bool small = (uint64_t)g.kt_real * 32 * 3 * 16384 < (1ull << 31) && g.p > (1u << 22);
+      if (persistent) snprintf(kname, sizeof kname, "k_gemm_i8_w3p<6, %s, false>", small ? "true" : "false");
+      else if (pl == 3 && waves == 4) snprintf(kname, sizeof kname, "k_gemm_i8_w3<%d, %d>", (int)nt, nt == 6 && njobs == 1 ? g.diag : 0);
       else snprintf(kname, sizeof kname, "k_gemm_i8<%d, %d>", (int)nt, waves);
       c->prof_kernel = kname;
-      // the matrix digit planes once, the B-operand tiles once per 32-row block (from L2), the residues out
-      c->prof_bytes += (double)D * pl * m->rt_count * m->kt_count * 1024 + (double)D * m->kt_count * nt * 1024 +
-                       (double)ns_valid * m->rows * D * 4;
+      // the matrix digit planes once (the other jobs of a launch find them in L2), every job's B-operand tiles (once per 32-row
+      // block, from L2) and residues
+      c->prof_bytes += (double)D * pl * m->rt_count * m->kt_count * 1024 +
+                       (double)njobs * ((double)D * m->kt_count * nt * 1024 + (double)ns_valid * m->rows * D * 4);
     }
     if (gram && pl == 3 && !prepacked && ns >= 32 && gram->r <= 32 && (size_t)ns_valid == gram->r)   // one tile per plane
       LAB_HIP(c, launch_gram_v8(nullptr, nullptr, v8, v8_stride, m->kt_count, (ktotal + 31) / 32, nt, paired ? 2 : 1, gram->r, njobs * (paired ? 2 : 1),

@@ -98,6 +98,10 @@ struct ProveShared {           // the streamed step 3 the sub-batches of one cal
   // nothing in it outlives a launch sequence, so ONE area (the largest any of them needs) at dense_off of the allocation serves
   // all of them (6 GB per sub-batch at kappa = 2^14)
   size_t dense_bytes = 0, dense_off = 0;
+  // B resident as byte planes (B8): the sub-batches' digit tiles are the jobs of ONE matrix-core launch per limb — B is read from
+  // HBM once for all of them (the other jobs' blocks hit L2) — through a staging array at stage_off
+  bool resident = false;
+  size_t stage_off = 0;
 };
 #define LAB_HIPC(ctx, expr)                                                                           \
   do {                                                                                                \
@@ -535,6 +539,12 @@ static ProveTask prove_batch_co(lab_ctx* c, size_t np, const lab_prove_input* co
       JobPtrs dig;
       for (int i = 0; i < valid; i++) dig.p[i] = jobs[j0 + i].cTdec;
       if ((rc = digits_to_v8_impl(c, b8, dig, ns, valid, reinterpret_cast<int8_t*>(mf_scratch)))) co_return rc;
+      if (sh && sh->resident && !size_only) {   // (one group: a sub-batch has at most 64 proofs) the driver multiplies every sub-batch's tiles at once
+        sh->groups.push_back(CrsGroup{HD(0, hlhs), perd * D, nullptr, nullptr, 0, ns, valid, mf_scratch});
+        co_await std::suspend_always{};
+        if (sh->rc) co_return sh->rc;
+        break;
+      }
     }
     if ((rc = matvec_mfma_impl(c, HD(j0, hlhs), perd * D, b8, HD(j0, hTdec), perd * D, ns, valid, mf_scratch, D, 1, 0, 0, true, nullptr,
                                fuse_t ? reinterpret_cast<const int8_t*>(mf_scratch) : nullptr))) co_return rc;
@@ -796,8 +806,11 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
         x->c_off != in->c_off || x->d_off != in->d_off)
       return fail(c, LAB_ERR_ARG, "lab_prove_core_batch: all proofs of a batch must share dimensions, constants and the CRS");
   }
-  const bool shared = in && !in->B8 && !in->B && in->crs_seed && (in->C || in->C8) && nsub <= (size_t)CRS_MAX_GROUPS;
-  if (!shared) {   // B resident: every sub-batch streams it from HBM itself
+  const bool shared_stream = in && !in->B8 && !in->B && in->crs_seed && (in->C || in->C8) && nsub <= (size_t)CRS_MAX_GROUPS;
+  // B resident as byte planes: the sub-batches share one pass over it as the jobs of one launch per limb (up to 16 of them)
+  const bool shared_res = in && in->B8 && nsub <= 16;
+  const bool shared = shared_stream || shared_res;
+  if (!shared) {   // B resident as residues: every sub-batch streams it from HBM itself
     int first = LAB_OK;
     for (size_t k = 0; k < nsub; k++) {
       const size_t j0 = k * MAX_JOBS;
@@ -819,21 +832,61 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     off[k + 1] = off[k] + ((need + 255) & ~(size_t)255);
   }
   sh.dense_off = off[nsub];
-  int rc = ensure_scratch(c, off[nsub] + sh.dense_bytes);
+  sh.resident = shared_res;
+  sh.stage_off = sh.dense_off + sh.dense_bytes;
+  const size_t stage_bytes = shared_res ? mfma_stage_bytes(in->B8, MAX_JOBS, nsub) : 0;
+  int rc = ensure_scratch(c, sh.stage_off + stage_bytes);
   if (rc) return rc;
   sh.groups.reserve(nsub);
   std::vector<ProveTask> tasks;
   tasks.reserve(nsub);
+  std::vector<int> early(nsub, 0);      // (resident B) a sub-batch that went through without waiting for the shared launch
+  int first = LAB_OK, flags = 0;
   for (size_t k = 0; k < nsub; k++) {   // steps 1-2 of every sub-batch
     const size_t j0 = k * MAX_JOBS;
     tasks.emplace_back(prove_batch_co(c, sub_np(k), ins + j0, outs + j0, status ? status + j0 : nullptr, allow_digit_ajtai, &sh, false, off[k], nullptr));
-    if (tasks.back().done()) {           // failed before step 3: let the suspended ones leave
-      sh.rc = tasks.back().rc() != LAB_OK ? tasks.back().rc() : LAB_ERR_ARG;
-      for (size_t i = 0; i + 1 < tasks.size(); i++) tasks[i].resume();
-      return sh.rc;
+    if (!tasks.back().done()) continue;
+    const int e = tasks.back().rc();
+    if (shared_res && (e == LAB_OK || e == LAB_ERR_JL_REJECTED || e == LAB_ERR_BPP_CHECK || e == REDO_IN_MAIN_BASIS)) {
+      early[k] = 1;                      // its digits do not have the tile form: it multiplied by itself (finished, or to be redone)
+      continue;
     }
+    sh.rc = e != LAB_OK ? e : LAB_ERR_ARG;   // failed before step 3: let the suspended ones leave
+    for (size_t i = 0; i + 1 < tasks.size(); i++)
+      if (!tasks[i].done()) tasks[i].resume();
+    return sh.rc;
   }
-  {
+  if (shared_res) {
+    // full groups that sit equally spaced in the allocation go through one launch per limb as its jobs; the others (a last, shorter
+    // sub-batch: the launch stores every job's sets up to ONE valid count) one by one
+    const lab_mat8* b8 = in->B8;
+    const size_t ng = sh.groups.size();
+    size_t nmulti = 0;
+    if (ng >= 2) {
+      const ptrdiff_t ds = static_cast<char*>(sh.groups[1].scratch) - static_cast<char*>(sh.groups[0].scratch);
+      const ptrdiff_t dout = sh.groups[1].out.base - sh.groups[0].out.base;
+      nmulti = 1;
+      while (nmulti < ng && ds > 0 && dout > 0 && sh.groups[nmulti].ns == sh.groups[0].ns && sh.groups[nmulti].ns_valid == sh.groups[0].ns_valid &&
+             sh.groups[nmulti].out.plane_stride == sh.groups[0].out.plane_stride &&
+             static_cast<char*>(sh.groups[nmulti].scratch) - static_cast<char*>(sh.groups[0].scratch) == (ptrdiff_t)nmulti * ds &&
+             sh.groups[nmulti].out.base - sh.groups[0].out.base == (ptrdiff_t)nmulti * dout)
+        nmulti++;
+      if (nmulti < 2 || sh.groups[0].ns != MAX_JOBS) nmulti = 0;
+      if (nmulti) {
+        const CrsGroup& G = sh.groups[0];
+        const MfmaJobBuffers jb{(size_t)ds, reinterpret_cast<uint32_t*>(static_cast<char*>(c->scratch) + sh.stage_off)};
+        rc = matvec_mfma_impl(c, G.out, G.out_set_stride, b8, ConstHatView(), 0, G.ns, G.ns_valid, G.scratch, D, nmulti, (size_t)dout, 0, true, nullptr,
+                              static_cast<const int8_t*>(G.scratch), nullptr, nullptr, 0, &jb);
+        flags |= 4;
+      }
+    }
+    for (size_t g = nmulti; g < ng && rc == LAB_OK; g++) {
+      const CrsGroup& G = sh.groups[g];
+      rc = matvec_mfma_impl(c, G.out, G.out_set_stride, b8, ConstHatView(), 0, G.ns, G.ns_valid, G.scratch, D, 1, 0, 0, true, nullptr,
+                            static_cast<const int8_t*>(G.scratch));
+    }
+    sh.rc = rc;
+  } else {
     const size_t r = in->r, kappa = in->kappa, k1 = in->kappa1, nmat = r * (size_t)in->t1, pairs = r * (r + 1) / 2;
     std::vector<uint64_t> offs(2 * nmat);
     for (size_t m = 0; m < nmat; m++) {   // CRS::fetch_B_ik_row (src/structs.rs:78-82), as in the body
@@ -846,15 +899,15 @@ static int prove_batch_impl(lab_ctx* c, size_t np, const lab_prove_input* const*
     rc = crs_stream_create(c, in->C ? in->C->basis : mat8_basis(in->C8), nmat, k1, kappa, ns_max, &cs, (uint64_t)pairs * in->t2, sh.groups.size());
     if (rc == LAB_OK) {
       rc = crs_stream_run(cs, in->crs_seed, offs.data(), nmat, sh.groups.data(), sh.groups.size());
+      if (sh.groups.size() >= 2) flags |= 4;
       if (rc == LAB_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, LAB_ERR_HIP, "lab_prove_core: streamed outer commitment failed");
       crs_stream_destroy(cs);
     }
     sh.rc = rc;
   }
-  int first = LAB_OK, flags = 0;
   std::vector<size_t> redo;
   for (size_t k = 0; k < nsub; k++) {     // steps 4-10 of every sub-batch
-    tasks[k].resume();
+    if (!early[k]) tasks[k].resume();
     const int e = tasks[k].done() ? tasks[k].rc() : LAB_ERR_HIP;
     if (e == REDO_IN_MAIN_BASIS) { redo.push_back(k); continue; }
     flags |= c->prove_flags;

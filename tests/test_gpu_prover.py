@@ -398,6 +398,46 @@ def test_t_chain_in_slices_of_the_batch():
     ctx.close()
 
 
+@pytest.mark.parametrize("nproofs,mfma_basis", [(70, True), (130, True), (200, True), (270, True), (130, False)])
+def test_more_than_64_proofs_share_one_pass_over_resident_B(nproofs, mfma_basis):
+    # B resident as byte planes (B8): a call of more than 64 proofs runs its sub-batches of 64 up to the digit tiles of t, multiplies
+    # ALL of them in one launch per limb (the full sub-batches as jobs that share the matrix through L2, a shorter last one by
+    # itself) and lets each sub-batch finish.  Every transcript == the same proofs proved 64 at a time == the multiply-add path on
+    # unpacked matrices (sample) == the oracle (last proof).
+    import labrador_snark_amd as lab
+    q, n, r, kappa, kappa1 = Q_REF33, 2, 3, 6, 130      # 130 rows: 5 row tiles, the last with 2 rows
+    ctx = lab.Context(q, 0, **ctx_kw(q))
+    p = cases.Params(q, n, r, kappa, kappa1)
+    k = lab.RuntimeConstants(q, n, r, kappa, kappa1, p.kappa2)
+    crs = lab.ResidentCRS(ctx, k, compact=True, mfma_basis=mfma_basis).fill_synthetic(1000)
+    ws, sts, tapes = [], [], []
+    want_last = None
+    for j in range(nproofs):
+        case, (S, phi, a, tape) = cases.oracle_case(p, seed=1500 + j)
+        ws.append(S); sts.append(lab.State(phi, a, case.b_prime)); tapes.append(tape)
+        if j == nproofs - 1:
+            want_last = case.prove()
+    ref = lab.prove_core_batch(ctx, k, ws[:5] + ws[-3:], sts[:5] + sts[-3:], crs, tapes[:5] + tapes[-3:])
+    crs.pack_mfma()
+    got, codes = lab.prove_core_batch(ctx, k, ws, sts, crs, tapes, raise_on_reject=False)
+    flags = ctx.prove_flags()
+    by64 = []
+    for j0 in range(0, nproofs, 64):
+        by64 += lab.prove_core_batch(ctx, k, ws[j0:j0 + 64], sts[j0:j0 + 64], crs, tapes[j0:j0 + 64])
+    assert codes == [0] * nproofs
+    assert bool(flags & 4) == (nproofs >= 128)      # two or more full sub-batches went through one launch per limb
+    fields = ("t_i_all", "g_mat", "h_mat", "u_1", "u_2", "z", "b_prime_prime", "projection_int")
+    for j in range(nproofs):
+        for f in fields:
+            assert np.array_equal(getattr(got[j], f), getattr(by64[j], f)), (j, f)
+    for a_, b_ in zip(list(range(5)) + list(range(nproofs - 3, nproofs)), range(8)):
+        for f in fields:
+            assert np.array_equal(getattr(got[a_], f), getattr(ref[b_], f)), (a_, f)
+    assert np.array_equal(got[-1].t_i_all, want_last["t"]) and np.array_equal(got[-1].u_1, want_last["u1"])
+    crs.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("nb,r,kappa", [(3, 17, 37), (2, 5, 33), (4, 20, 70), (6, 32, 96), (2, 9, 64)])
 def test_t_from_the_staging_arrays_of_every_limb(nb, r, kappa):
     # t = A S of a batch leaves the matrix cores in one slot-major staging array per limb; k_stage_to_coeffs turns them into t mod q
