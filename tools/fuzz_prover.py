@@ -36,7 +36,7 @@ def main():
         q = qs[int(rng.integers(0, len(qs)))]
         n, r = int(rng.integers(1, 7)), int(rng.choice([1, 2, 5, 8, 9, 16, 17, 24, 32, 33, 40]))
         kappa, kappa1 = int(rng.integers(1, 100)), int(rng.integers(1, 40))
-        nb = int(rng.choice([1, 2, 3, 4, 5, 8, 66, 70]))
+        nb = int(rng.choice([1, 2, 3, 4, 5, 8, 66, 70, 130, 260]))
         if large:
             while True:
                 n, r = int(rng.integers(1, 71)), int(rng.choice([2, 8, 17, 32]))
